@@ -1,0 +1,186 @@
+/*
+ * seghiero_hip.h -- C ABI of libseghiero_hip.so: the MI355X (gfx950) kernels of the SegHiero
+ * training hot path.
+ *
+ * The reference (Shadowfear36/SegHiero) has no native layer: its "operator API" for this path is
+ * the chain of ATen ops issued by its Python modules.  Each entry point below replaces one such
+ * chain; the reference site is cited per function (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every tensor is fp32 (labels: uint8), activations are NHWC ("channels_last"), weights OHWI
+ *     (= a PyTorch [O,I,KH,KW] tensor in channels_last memory format);
+ *   - `ld*` arguments are pixel (row) strides in ELEMENTS, so a kernel can read/write a channel
+ *     slice of a wider concat buffer;
+ *   - `stream` is a hipStream_t passed as void*; all functions are asynchronous on it, hold no
+ *     global state, never allocate, never synchronise; the caller owns every buffer;
+ *   - return value: 0 = launched, SH_EINVAL = rejected arguments (nothing launched),
+ *     SH_ELAUNCH = HIP reported a launch error.  Nothing throws across this boundary.
+ */
+#ifndef SEGHIERO_HIP_H
+#define SEGHIERO_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SH_OK 0
+#define SH_EINVAL (-1)
+#define SH_ELAUNCH (-2)
+
+/* library / device info ------------------------------------------------------------------- */
+int sh_abi_version(void);                       /* bumps when a signature changes */
+int sh_conv_tile_rows(void);                    /* rows per stat-partial of sh_conv_fprop (=64) */
+
+/* layout --------------------------------------------------------------------------------- */
+/* NCHW -> NHWC with channel padding to Cpad (zeros).  Replaces the implicit layout of
+ * `img_t` entering `self.stem_conv` (models/backbone/resnet.py:65). */
+int sh_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int Cpad, void* stream);
+/* NHWC (Cpad channels per pixel, first C used) -> NCHW. */
+int sh_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, int Cpad, void* stream);
+
+/* dense convolution as implicit GEMM on fp32 MFMA ----------------------------------------- */
+/* y[n,oh,ow,co] = bias[co] + sum x[n, oh*s-p+kh*d, ow*s-p+kw*d, ci] * w[co,kh,kw,ci]
+ * Replaces nn.Conv2d forward: torchvision Bottleneck convs behind models/backbone/resnet.py:65-73,
+ * and every 1x1 conv of models/head/sep_aspp_contrast_head.py (:15-22, :51, :79, :95, :181, :189, :207).
+ * Cin % 4 == 0.  stat_partials (optional): [ceil(M/64)][2][Cout] floats receiving per-64-row-tile
+ * sum(y) and sum(y*y) per channel (train-mode BatchNorm statistics, F.batch_norm). */
+int sh_conv_fprop(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
+                  float* stat_partials, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                  int stride, int pad, int dil, void* stream);
+/* dx = conv_transpose(dy, w) (+ addend).  Autograd's grad_input of the same nn.Conv2d.
+ * mode 0: gather form over the input pixels.  mode 1 (1x1, pad 0 only): rows of the output grid are
+ * scattered to input pixel (oh*s, ow*s) and ACCUMULATED into dx (dx must hold the other summand). */
+int sh_conv_dgrad(const float* dy, int lddy, const float* w, const float* addend, int ldadd,
+                  float* dx, int lddx, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                  int stride, int pad, int dil, int mode, void* stream);
+/* dw[co,kh,kw,ci] = sum_pixels dy * x.  Autograd's grad_weight of the same nn.Conv2d.
+ * workspace: sh_conv_wgrad_workspace(...) bytes (split-K slabs, reduced deterministically). */
+int64_t sh_conv_wgrad_workspace(int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                int stride, int pad, int dil);
+int sh_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw, float* workspace,
+                  int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                  int dil, void* stream);
+
+/* depthwise 3x3 (groups = C), stride 1, padding = dilation ---------------------------------- */
+/* Replaces DepthwiseSeparableConv.depthwise (models/head/sep_aspp_contrast_head.py:43-46, :56).
+ * w is [C][3][3].  stat_partials: [sh_dw_partials(N,H,W)][2][C]. */
+int sh_dw_partials(int N, int H, int W);
+int sh_dwconv_fprop(const float* x, int ldx, const float* w, float* y, int ldy, float* stat_partials,
+                    int N, int H, int W, int C, int dil, void* stream);
+int sh_dwconv_dgrad(const float* dy, int lddy, const float* w, float* dx, int lddx,
+                    int N, int H, int W, int C, int dil, int accumulate, void* stream);
+/* dw_partials: [sh_dw_partials(N,H,W)][9][C] floats; dw: [C][9] */
+int sh_dwconv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw_partials, float* dw,
+                    int N, int H, int W, int C, int dil, void* stream);
+
+/* batch norm ------------------------------------------------------------------------------ */
+/* Train-mode nn.BatchNorm2d (every BN of the path; math: SURVEY A.2).  Reduces the stat partials in
+ * f64, writes mean/invstd/scale/shift and updates the running statistics (momentum, unbiased var). */
+int sh_bn_finalize(const float* partials, int n_partials, int C, double count, const float* gamma,
+                   const float* beta, float eps, float momentum, float* running_mean,
+                   float* running_var, float* mean, float* invstd, float* scale, float* shift,
+                   void* stream);
+/* Eval-mode coefficients from the running statistics. */
+int sh_bn_eval_coefs(const float* gamma, const float* beta, const float* running_mean,
+                     const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
+/* Per-channel statistics partials of an arbitrary tensor (used where no conv epilogue produced them). */
+int sh_stats_partials_count(int64_t M);
+int sh_channel_stats(const float* y, int ldy, int64_t M, int C, float* partials, void* stream);
+/* out = [relu]( y*scale + shift [+ residual] ).  Replaces BN-apply + ReLU (+ the Bottleneck residual add). */
+int sh_bn_act(const float* y, int ldy, const float* scale, const float* shift, const float* residual,
+              int ldr, float* out, int ldo, int64_t M, int C, int relu, void* stream);
+/* Backward of the above.  g = dout * (out > 0 if relu).  reduce: partials [n][2][C] of (sum g, sum g*xhat);
+ * finalize: dgamma, dbeta; apply: dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)), optionally dres = g. */
+int sh_bn_bwd_reduce(const float* dout, int lddo, const float* out, int ldo, const float* y, int ldy,
+                     const float* mean, const float* invstd, float* partials, int64_t M, int C,
+                     int relu, void* stream);
+int sh_bn_bwd_finalize(const float* partials, int n_partials, int C, const float* gamma,
+                       const float* invstd, double count, float* dgamma, float* dbeta, float* c1,
+                       float* c2, void* stream);
+int sh_bn_bwd_apply(const float* dout, int lddo, const float* out, int ldo, const float* y, int ldy,
+                    const float* mean, const float* invstd, const float* gamma, const float* c1,
+                    const float* c2, float* dy, int lddy, float* dres, int lddres, int64_t M, int C,
+                    int relu, void* stream);
+
+/* pooling / resampling -------------------------------------------------------------------- */
+/* nn.MaxPool2d(3, 2, 1) (models/backbone/resnet.py:68) and its backward (first-max tie rule). */
+int sh_maxpool_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int sh_maxpool_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+/* nn.AdaptiveAvgPool2d(1) (sep_aspp_contrast_head.py:93,104): x [N,HW,C] -> y [N,C]; backward broadcasts. */
+int sh_avgpool_fwd(const float* x, int ldx, float* y, int N, int HW, int C, void* stream);
+int sh_avgpool_bwd(const float* dy, float* dx, int lddx, int N, int HW, int C, float scale, int accumulate, void* stream);
+/* broadcast [N,C] -> [N,HW,C slice] (the 1x1 -> HxW bilinear of sep_aspp_contrast_head.py:106) and its
+ * backward (sum over HW). */
+int sh_broadcast_hw(const float* x, float* y, int ldy, int N, int HW, int C, void* stream);
+int sh_sum_hw(const float* dy, int lddy, float* dx, int N, int HW, int C, void* stream);
+/* F.interpolate(mode='bilinear', align_corners=False) NHWC (sep_aspp_contrast_head.py:235-238) and its backward. */
+int sh_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int h, int w, int H, int W, int C, void* stream);
+int sh_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int h, int w, int H, int W, int C, void* stream);
+/* F.normalize(p=2, dim=1, eps=1e-12) over channels (sep_aspp_contrast_head.py:29). */
+int sh_l2norm_fwd(const float* x, float* y, float* norm, int64_t M, int C, void* stream);
+int sh_l2norm_bwd(const float* dy, const float* y, const float* norm, float* dx, int64_t M, int C, void* stream);
+
+/* losses ---------------------------------------------------------------------------------- */
+/* Fused: bilinear resize of logits [N,h,w,ldl] to the label grid [N,H,W] (train.py:282-284), coarse target by
+ * bucket ranges (hiera_triplet_loss.py:11-38), sigmoid hierarchical BCE (:41-107) and the two all-pixel-mean
+ * CE terms (:183-187; cross_entropy_loss.py:7-30, utils.py:6-55).  h==H && w==W means "already full resolution".
+ *   buckets_host: HOST int32 [n_coarse][2] (start,end).   labels: uint8 [N,H,W] (255 = ignore).
+ *   sums (device double[8]) <- {bce_fine, bce_coarse, ce_fine, ce_coarse, n_valid_fine, n_valid_coarse, n_pixels, 0}
+ *   loss_out (device float[1]) <- 5*(bce_f/(max(nvf,1)*nf) + bce_c/(max(nvc,1)*nc)) + ce_f/npix + ce_c/npix
+ *   partials: float [sh_hiera2_partials(N,H,W)][8] scratch.  coarse_out (optional): uint8 [N,H,W] coarse targets. */
+int sh_hiera2_partials(int N, int H, int W);
+int sh_hiera2_loss_fwd(const float* logits, int ldl, const uint8_t* labels, const int* buckets_host, int n_fine,
+                       int n_coarse, double* sums, float* loss_out, float* partials, uint8_t* coarse_out,
+                       int N, int h, int w, int H, int W, void* stream);
+/* d(loss_out)/d(logits) * gscale * gscale_dev[0] into dlogits [N,h,w,lddl] (gather form, deterministic; lanes
+ * >= C of each row are zeroed).  Uses the counts left in `sums` by the forward. */
+int sh_hiera2_loss_bwd(const float* logits, int ldl, const uint8_t* labels, const int* buckets_host, int n_fine,
+                       int n_coarse, const double* sums, const float* gscale_dev, float gscale, float* dlogits,
+                       int lddl, int N, int h, int w, int H, int W, void* stream);
+/* Fused bilinear resize + nn.CrossEntropyLoss(ignore_index=255) (valid-pixel mean) of the aux head
+ * (train.py:309-313).  sums double[2] = {ce_sum, n_valid}; loss_out = ce_sum / n_valid. */
+int sh_ce_loss_fwd(const float* logits, int ldl, const uint8_t* labels, int C, double* sums, float* loss_out,
+                   float* partials, int N, int h, int w, int H, int W, void* stream);
+int sh_ce_loss_bwd(const float* logits, int ldl, const uint8_t* labels, int C, const double* sums,
+                   const float* gscale_dev, float gscale, float* dlogits, int lddl, int N, int h, int w, int H,
+                   int W, void* stream);
+/* int64 label map -> uint8 (the reference hands the loss i64 labels, train.py:262). */
+int sh_labels_to_u8(const int64_t* in, uint8_t* out, int64_t n, void* stream);
+/* Tree-triplet (tree_triplet_loss.py:15-65, rmi_tree_triplet_loss.py:14-70): nearest label resize to the
+ * embedding grid, per anchor class the first <= max_triplet anchor / positive / negative rows in raster order,
+ * hinge(d_ap - d_an + margin) mean, mean over the classes that produced triplets.
+ *   emb: [N,h,w,D] unit-norm rows.  masks: device u64 [256][2][4] = per anchor class the 256-bit membership sets of
+ *   positive and negative labels; anchor_ok: device u64 [4] = classes that may be anchors.
+ *   out (device float[2]) <- {loss (0 if no class), class_count}.  workspace: sh_triplet_workspace(N*h*w) bytes,
+ *   kept for the backward.  bwd ACCUMULATES gscale*gscale_dev[0]*d(loss)/d(emb) into demb (zero it first). */
+int64_t sh_triplet_workspace(int64_t M);
+int sh_triplet_fwd(const float* emb, const uint8_t* labels, const uint64_t* masks, const uint64_t* anchor_ok,
+                   int max_triplet, float margin, float* out, void* workspace, int N, int h, int w, int D, int H,
+                   int W, void* stream);
+int sh_triplet_bwd(const float* emb, const void* workspace, const float* out, const float* gscale_dev, float gscale,
+                   float* demb, int N, int h, int w, int D, void* stream);
+/* out = (main + (count > 0 ? factor*trip_out[0] : 0)) * loss_weight, count = ready_count ? ready_count[0] : trip_out[1]
+ * (hiera_triplet_loss.py:193-211). */
+int sh_combine_loss(const float* main_loss, const float* trip_out, const float* ready_count, float factor,
+                    float loss_weight, float* out, void* stream);
+/* fine argmax + pixel accuracy + confusion matrix (train.py:37-49, 381-385; mIoU is build-defined).
+ * counts: int64 [2 + n_fine*n_fine] = {correct, valid, confusion[gt][pred]...} (accumulated; zero it first). */
+int sh_pixel_metrics(const float* logits, int ldl, const uint8_t* labels, int n_fine, long long* counts,
+                     int N, int h, int w, int H, int W, void* stream);
+
+/* optimizer ------------------------------------------------------------------------------- */
+/* torch.optim.SGD(momentum, weight_decay) step (train.py:239-246, 317) over up to SH_SGD_MAX tensors per call:
+ * g += wd*w; v = first ? g : mom*v + g; w -= lr*v. */
+#define SH_SGD_MAX 48
+int sh_sgd_step(int n_tensors, float* const* w, const float* const* g, float* const* v, const int64_t* numel,
+                float lr, float momentum, float weight_decay, int first_step, float gscale, void* stream);
+
+/* misc ------------------------------------------------------------------------------------ */
+int sh_fill(float* p, float v, int64_t n, void* stream);
+int sh_axpy(float* y, const float* x, float a, int64_t n, void* stream);   /* y += a*x */
+int sh_copy(void* dst, const void* src, int64_t bytes, void* stream);      /* async device-to-device copy */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,309 @@
+// BatchNorm statistics / apply / backward, layout converters and small elementwise helpers (gfx950).
+// All HBM-bound: 16-byte loads where the channel count allows, grid-stride loops capped at 2048 blocks,
+// wave-shuffle -> LDS -> per-block partials, and f64 for every cross-block combine (deterministic two-stage
+// reductions, no float atomics).
+#include "common.h"
+
+static inline unsigned grid_for(long long work_items, int block = 256, int cap = 4096) {
+    long long g = sh_cdiv(work_items, block);
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+// ---------------------------------------------------------------------------------------------- layout
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           int C, long long HW, int Cpad, long long total) {
+    // one thread per output element (n, hw, c); reads are strided by HW but C is tiny (3) for the only user
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % Cpad);
+        const long long q = i / Cpad, hw = q % HW, n = q / HW;
+        y[i] = c < C ? x[(n * C + c) * HW + hw] : 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           int C, long long HW, int Cpad, long long total) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long hw = i % HW, q = i / HW;
+        const int c = (int)(q % C);
+        const long long n = q / C;
+        y[i] = x[(n * HW + hw) * Cpad + c];
+    }
+}
+extern "C" int sh_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int Cpad, void* stream) {
+    if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || Cpad < C) return SH_EINVAL;
+    const long long total = (long long)N * H * W * Cpad;
+    nchw_to_nhwc_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>(x, y, C, (long long)H * W, Cpad, total);
+    return sh_launch_status();
+}
+extern "C" int sh_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, int Cpad, void* stream) {
+    if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || Cpad < C) return SH_EINVAL;
+    const long long total = (long long)N * H * W * C;
+    nhwc_to_nchw_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>(x, y, C, (long long)H * W, Cpad, total);
+    return sh_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------- misc
+__global__ __launch_bounds__(256) void fill_kernel(float* p, float v, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = v;
+}
+__global__ __launch_bounds__(256) void axpy_kernel(float* y, const float* x, float a, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] += a * x[i];
+}
+extern "C" int sh_fill(float* p, float v, int64_t n, void* stream) {
+    if (!p || n < 0) return SH_EINVAL;
+    if (n == 0) return SH_OK;
+    fill_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(p, v, n);
+    return sh_launch_status();
+}
+extern "C" int sh_axpy(float* y, const float* x, float a, int64_t n, void* stream) {
+    if (!y || !x || n < 0) return SH_EINVAL;
+    if (n == 0) return SH_OK;
+    axpy_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(y, x, a, n);
+    return sh_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------- stat partial reduce
+// partials: [P][2][C] floats.  Block = 4 channels x 256 row-groups; f64 accumulation; LDS tree.
+// Writes sums[0][c], sums[1][c] (double) into LDS-resident result then calls the functor on thread < 4.
+template <typename F>
+__device__ __forceinline__ void reduce_partials_4ch(const float* __restrict__ partials, int P, int C, int c0, F&& fin) {
+    __shared__ double red[8][4];   // [stat*4+ch][wave]
+    const int t = threadIdx.x;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool vec = (C & 3) == 0;
+    for (int p = t; p < P; p += 256) {
+        const float* r0 = partials + ((long long)p * 2 + 0) * C + c0;
+        const float* r1 = partials + ((long long)p * 2 + 1) * C + c0;
+        if (vec) {
+            const f32x4 a = ld4(r0), b = ld4(r1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[j] += (double)a[j]; acc[4 + j] += (double)b[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c0 + j < C) { acc[j] += (double)r0[j]; acc[4 + j] += (double)r1[j]; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = wave_sum_d(acc[j]);
+    if ((t & 63) == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[j][t >> 6] = acc[j];
+    }
+    __syncthreads();
+    if (t < 4 && c0 + t < C) {
+        const double s = red[t][0] + red[t][1] + red[t][2] + red[t][3];
+        const double q = red[4 + t][0] + red[4 + t][1] + red[4 + t][2] + red[4 + t][3];
+        fin(c0 + t, s, q);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int P, int C, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, float momentum, float* running_mean,
+                                                          float* running_var, float* mean, float* invstd, float* scale,
+                                                          float* shift) {
+    reduce_partials_4ch(partials, P, C, blockIdx.x * 4, [&](int c, double s, double q) {
+        const double mu = s / count;
+        double var = q / count - mu * mu;
+        if (var < 0) var = 0;
+        const float fmu = (float)mu, fvar = (float)var;
+        const float is = 1.0f / sqrtf(fvar + eps);
+        mean[c] = fmu;
+        invstd[c] = is;
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        const float sc = g * is;
+        scale[c] = sc;
+        shift[c] = b - fmu * sc;
+        if (running_mean) {
+            const double unbiased = count > 1 ? var * (count / (count - 1.0)) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * fmu;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    });
+}
+extern "C" int sh_bn_finalize(const float* partials, int n_partials, int C, double count, const float* gamma,
+                              const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                              float* mean, float* invstd, float* scale, float* shift, void* stream) {
+    if (!partials || n_partials <= 0 || C <= 0 || count <= 0 || !mean || !invstd || !scale || !shift) return SH_EINVAL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return SH_EINVAL;
+    bn_finalize_kernel<<<(unsigned)sh_cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(
+        partials, n_partials, C, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+    return sh_launch_status();
+}
+
+__global__ __launch_bounds__(256) void bn_eval_coefs_kernel(const float* gamma, const float* beta, const float* rm,
+                                                            const float* rv, float eps, int C, float* scale, float* shift) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float is = 1.0f / sqrtf(rv[c] + eps);
+    const float sc = (gamma ? gamma[c] : 1.f) * is;
+    scale[c] = sc;
+    shift[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
+}
+extern "C" int sh_bn_eval_coefs(const float* gamma, const float* beta, const float* running_mean,
+                                const float* running_var, float eps, int C, float* scale, float* shift, void* stream) {
+    if (!running_mean || !running_var || !scale || !shift || C <= 0) return SH_EINVAL;
+    bn_eval_coefs_kernel<<<(unsigned)sh_cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(gamma, beta, running_mean, running_var, eps, C, scale, shift);
+    return sh_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------- generic channel stats
+// partial p covers rows [256p, 256p+256); block = (row chunk, 64-channel chunk); thread = (channel, row group of 4).
+#define STAT_ROWS 256
+template <int KIND>   // 0: (sum y, sum y^2)   1: BN backward (sum g, sum g*xhat)
+__global__ __launch_bounds__(256) void channel_partials_kernel(const float* __restrict__ y, long long ldy,
+                                                               const float* __restrict__ dout, long long lddo,
+                                                               const float* __restrict__ out, long long ldo,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               float* __restrict__ partials, long long M, int C, int relu) {
+    __shared__ float red[2][4][64];
+    const int t = threadIdx.x, cl = t & 63, g = t >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    const long long rbeg = (long long)blockIdx.x * STAT_ROWS;
+    const long long rend = rbeg + STAT_ROWS < M ? rbeg + STAT_ROWS : M;
+    float s = 0.f, q = 0.f;
+    if (c < C) {
+        float mu = 0.f, is = 0.f;
+        if (KIND == 1) { mu = mean[c]; is = invstd[c]; }
+        for (long long r = rbeg + g; r < rend; r += 4) {
+            if (KIND == 0) {
+                const float v = y[r * ldy + c];
+                s += v; q += v * v;
+            } else {
+                float gv = dout[r * lddo + c];
+                if (relu && !(out[r * ldo + c] > 0.f)) gv = 0.f;
+                const float xh = (y[r * ldy + c] - mu) * is;
+                s += gv; q += gv * xh;
+            }
+        }
+    }
+    red[0][g][cl] = s; red[1][g][cl] = q;
+    __syncthreads();
+    if (t < 128) {
+        const int st = t >> 6, cc = t & 63, ch = blockIdx.y * 64 + cc;
+        if (ch < C)
+            partials[((long long)blockIdx.x * 2 + st) * C + ch] = (red[st][0][cc] + red[st][1][cc]) + (red[st][2][cc] + red[st][3][cc]);
+    }
+}
+extern "C" int sh_stats_partials_count(int64_t M) { return (int)sh_cdiv(M, STAT_ROWS); }
+extern "C" int sh_channel_stats(const float* y, int ldy, int64_t M, int C, float* partials, void* stream) {
+    if (!y || !partials || M <= 0 || C <= 0 || ldy < C) return SH_EINVAL;
+    dim3 grid((unsigned)sh_cdiv(M, STAT_ROWS), (unsigned)sh_cdiv(C, 64));
+    channel_partials_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(y, ldy, nullptr, 0, nullptr, 0, nullptr, nullptr, partials, M, C, 0);
+    return sh_launch_status();
+}
+extern "C" int sh_bn_bwd_reduce(const float* dout, int lddo, const float* out, int ldo, const float* y, int ldy,
+                                const float* mean, const float* invstd, float* partials, int64_t M, int C, int relu,
+                                void* stream) {
+    if (!dout || !y || !mean || !invstd || !partials || M <= 0 || C <= 0 || lddo < C || ldy < C) return SH_EINVAL;
+    if (relu && (!out || ldo < C)) return SH_EINVAL;
+    dim3 grid((unsigned)sh_cdiv(M, STAT_ROWS), (unsigned)sh_cdiv(C, 64));
+    channel_partials_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(y, ldy, dout, lddo, out, ldo, mean, invstd, partials, M, C, relu);
+    return sh_launch_status();
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int P, int C,
+                                                              const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                              double count, float* dgamma, float* dbeta, float* c1, float* c2) {
+    reduce_partials_4ch(partials, P, C, blockIdx.x * 4, [&](int c, double s, double q) {
+        if (dbeta) dbeta[c] = (float)s;
+        if (dgamma) dgamma[c] = (float)q;
+        c1[c] = (float)(s / count);
+        c2[c] = (float)(q / count);
+    });
+}
+extern "C" int sh_bn_bwd_finalize(const float* partials, int n_partials, int C, const float* gamma, const float* invstd,
+                                  double count, float* dgamma, float* dbeta, float* c1, float* c2, void* stream) {
+    if (!partials || n_partials <= 0 || C <= 0 || count <= 0 || !c1 || !c2) return SH_EINVAL;
+    bn_bwd_finalize_kernel<<<(unsigned)sh_cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(partials, n_partials, C, gamma, invstd, count, dgamma, dbeta, c1, c2);
+    return sh_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------- BN apply (+residual, +ReLU)
+template <int V>
+__global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y, long long ldy, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, const float* __restrict__ res, long long ldr,
+                                                     float* __restrict__ out, long long ldo, long long M, int C, int relu) {
+    const int cv = C / V;
+    const long long total = M * cv;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long m = i / cv;
+        const int c = (int)(i - m * cv) * V;
+        if (V == 4) {
+            f32x4 v = ld4(y + m * ldy + c) * ld4(scale + c) + ld4(shift + c);
+            if (res) v += ld4(res + m * ldr + c);
+            if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            st4(out + m * ldo + c, v);
+        } else {
+            float v = y[m * ldy + c] * scale[c] + shift[c];
+            if (res) v += res[m * ldr + c];
+            if (relu) v = fmaxf(v, 0.f);
+            out[m * ldo + c] = v;
+        }
+    }
+}
+static inline bool vec4_ok(int C, long long a, long long b = 0, long long c = 0, long long d = 0, long long e = 0) {
+    return (C & 3) == 0 && ((a | b | c | d | e) & 3) == 0;
+}
+static inline bool ptr16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+extern "C" int sh_bn_act(const float* y, int ldy, const float* scale, const float* shift, const float* residual, int ldr,
+                         float* out, int ldo, int64_t M, int C, int relu, void* stream) {
+    if (!y || !scale || !shift || !out || M <= 0 || C <= 0 || ldy < C || ldo < C) return SH_EINVAL;
+    if (residual && ldr < C) return SH_EINVAL;
+    const bool v4 = vec4_ok(C, ldy, ldo, residual ? ldr : 0) && ptr16(y) && ptr16(out) && ptr16(scale) && ptr16(shift) && (!residual || ptr16(residual));
+    if (v4) bn_act_kernel<4><<<grid_for(M * (C / 4)), 256, 0, (hipStream_t)stream>>>(y, ldy, scale, shift, residual, ldr, out, ldo, M, C, relu);
+    else bn_act_kernel<1><<<grid_for(M * C), 256, 0, (hipStream_t)stream>>>(y, ldy, scale, shift, residual, ldr, out, ldo, M, C, relu);
+    return sh_launch_status();
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, long long lddo, const float* __restrict__ out,
+                                                           long long ldo, const float* __restrict__ y, long long ldy,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ c1,
+                                                           const float* __restrict__ c2, float* __restrict__ dy, long long lddy,
+                                                           float* __restrict__ dres, long long lddres, long long M, int C, int relu) {
+    const int cv = C / V;
+    const long long total = M * cv;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long m = i / cv;
+        const int c = (int)(i - m * cv) * V;
+        if (V == 4) {
+            f32x4 g = ld4(dout + m * lddo + c);
+            if (relu) {
+                const f32x4 o = ld4(out + m * ldo + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (!(o[j] > 0.f)) g[j] = 0.f;
+            }
+            const f32x4 is = ld4(invstd + c);
+            const f32x4 xh = (ld4(y + m * ldy + c) - ld4(mean + c)) * is;
+            f32x4 ga = {1.f, 1.f, 1.f, 1.f};
+            if (gamma) ga = ld4(gamma + c);
+            const f32x4 r = ga * is * (g - ld4(c1 + c) - xh * ld4(c2 + c));
+            st4(dy + m * lddy + c, r);
+            if (dres) st4(dres + m * lddres + c, g);
+        } else {
+            float g = dout[m * lddo + c];
+            if (relu && !(out[m * ldo + c] > 0.f)) g = 0.f;
+            const float is = invstd[c];
+            const float xh = (y[m * ldy + c] - mean[c]) * is;
+            dy[m * lddy + c] = (gamma ? gamma[c] : 1.f) * is * (g - c1[c] - xh * c2[c]);
+            if (dres) dres[m * lddres + c] = g;
+        }
+    }
+}
+extern "C" int sh_bn_bwd_apply(const float* dout, int lddo, const float* out, int ldo, const float* y, int ldy,
+                               const float* mean, const float* invstd, const float* gamma, const float* c1, const float* c2,
+                               float* dy, int lddy, float* dres, int lddres, int64_t M, int C, int relu, void* stream) {
+    if (!dout || !y || !mean || !invstd || !c1 || !c2 || !dy || M <= 0 || C <= 0 || lddo < C || ldy < C || lddy < C) return SH_EINVAL;
+    if (relu && (!out || ldo < C)) return SH_EINVAL;
+    if (dres && lddres < C) return SH_EINVAL;
+    const bool v4 = vec4_ok(C, lddo, ldy, lddy, relu ? ldo : 0, dres ? lddres : 0) && ptr16(dout) && ptr16(y) && ptr16(dy) &&
+                    ptr16(mean) && ptr16(invstd) && ptr16(c1) && ptr16(c2) && (!gamma || ptr16(gamma)) && (!relu || ptr16(out)) && (!dres || ptr16(dres));
+    if (v4) bn_bwd_apply_kernel<4><<<grid_for(M * (C / 4)), 256, 0, (hipStream_t)stream>>>(dout, lddo, out, ldo, y, ldy, mean, invstd, gamma, c1, c2, dy, lddy, dres, lddres, M, C, relu);
+    else bn_bwd_apply_kernel<1><<<grid_for(M * C), 256, 0, (hipStream_t)stream>>>(dout, lddo, out, ldo, y, ldy, mean, invstd, gamma, c1, c2, dy, lddy, dres, lddres, M, C, relu);
+    return sh_launch_status();
+}

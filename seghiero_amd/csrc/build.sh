@@ -1,0 +1,18 @@
+#!/bin/bash
+# Build libseghiero_hip.so for gfx950 (in-tree; cross-compiles without a GPU).
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function"
+OBJS=()
+pids=()
+for f in conv_gemm bn_elementwise pool_resample dwconv loss sgd; do
+  if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ] || [ common.h -nt "$f.o" ] || [ ../../include/seghiero_hip.h -nt "$f.o" ]; then
+    $HIPCC $FLAGS -c "$f.hip" -o "$f.o" &
+    pids+=($!)
+  fi
+  OBJS+=("$f.o")
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libseghiero_hip.so "${OBJS[@]}"
+echo "built $(cd .. && pwd)/libseghiero_hip.so"

@@ -1,0 +1,494 @@
+// Dense convolution (fprop / dgrad / wgrad) as implicit GEMM on the gfx950 fp32 matrix cores.
+//
+// One kernel template covers the three GEMMs of an nn.Conv2d (reference: torchvision Bottleneck convs behind
+// models/backbone/resnet.py:65-73; the 1x1 convs of models/head/sep_aspp_contrast_head.py):
+//
+//   FPROP : Y[m=(n,oh,ow)][co]   = sum_k  im2col(X)[m][k=(kh,kw,ci)] * W[co][k]
+//   DGRAD : dX[m=(n,ih,iw)][ci]  = sum_k  col2im-gather(dY)[m][k=(kh,kw,co)] * W[co][kh][kw][ci]
+//   WGRAD : dW[co][n'=(kh,kw,ci)] = sum_pix dY[pix][co] * im2col(X)[pix][n']      (split over pixels)
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate, bit-for-bit an fmaf chain), so results
+// stay inside the fp32 tolerance the parity tests state.  Tiles: 256 threads = 4 waves as 2x2, each wave
+// TMxTN MFMA tiles of 32x32; block tile (64*TM)x(64*TN), K step 32, double-buffered LDS, register-staged
+// prefetch of the next K tile (issue loads -> MFMA on the current tile -> write LDS -> one barrier).
+// NHWC activations make every gathered row a contiguous run of channels, so all global loads are 16-byte
+// and 128-byte coalesced; out-of-image taps / K tails are zero-filled in registers.
+#include "common.h"
+
+enum { FPROP = 0, DGRAD = 1, WGRAD = 2 };
+
+struct ConvP {
+    const float* a;
+    const float* b;
+    float* c;
+    const float* extra;     // fprop: bias[Cout] ; dgrad: addend[M][ldadd]
+    float* partials;        // fprop: BN stat partials
+    long long lda, ldb, ldc, ldadd;
+    int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, dil;
+    int M, Nn, K;           // GEMM sizes (for WGRAD K = number of output pixels)
+    int scatter;            // dgrad mode 1
+    int sH, sW, sstride;    // scatter-store geometry
+    int kchunk;             // wgrad: pixels per split
+    int tiles_m, tiles_n, n_partials;
+};
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+template <int MODE, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, KP = BK + 4;
+    constexpr bool A_KC = (MODE != WGRAD);   // A tile in LDS as [row][k] (else [k][row])
+    constexpr bool B_KC = (MODE == FPROP);
+    constexpr int A_ELEMS = A_KC ? BM * KP : BK * BM;
+    constexpr int B_ELEMS = B_KC ? BN * KP : BK * BN;
+    constexpr int NA = 2 * TM, NB = 2 * TN;  // float4 per thread per tile
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+
+    const unsigned nblk = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+    const unsigned bid = xcd_remap(blockIdx.x, nblk);
+    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    int kbeg = 0, kend = p.K;
+    if constexpr (MODE == WGRAD) {
+        kbeg = blockIdx.y * p.kchunk;
+        kend = min(p.K, kbeg + p.kchunk);
+    }
+    const int nkt = (kend - kbeg + BK - 1) / BK;
+
+    // ------------------------------------------------------------------ per-thread loader state
+    // KC tiles: thread -> (k-chunk kc = t&7, rows r0 + 32*i).  RC tiles: thread -> (col chunk, k rows).
+    const int kc = t & 7, r0 = t >> 3;
+    int a_y[NA], a_x[NA], a_nb[NA];          // FPROP/DGRAD A rows
+    if constexpr (MODE == FPROP) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int m = m0 + r0 + 32 * i;
+            if (m < p.M) {
+                const int ow = m % p.Wo, q = m / p.Wo, oh = q % p.Ho, n = q / p.Ho;
+                a_y[i] = oh * p.stride - p.pad; a_x[i] = ow * p.stride - p.pad; a_nb[i] = n * p.H * p.W;
+            } else { a_y[i] = -(1 << 28); a_x[i] = 0; a_nb[i] = 0; }
+        }
+    } else if constexpr (MODE == DGRAD) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int m = m0 + r0 + 32 * i;
+            if (m < p.M) {
+                const int iw = m % p.W, q = m / p.W, ih = q % p.H, n = q / p.H;
+                a_y[i] = ih + p.pad; a_x[i] = iw + p.pad; a_nb[i] = n * p.Ho * p.Wo;
+            } else { a_y[i] = -(1 << 28); a_x[i] = 0; a_nb[i] = 0; }
+        }
+    }
+    // RC geometry
+    constexpr int A_RC_CPR = BM / 4, A_RC_KPP = 256 / A_RC_CPR;   // float4 per k-row, k-rows per pass
+    constexpr int B_RC_CPR = BN / 4, B_RC_KPP = 256 / B_RC_CPR;
+    const int a_rc = t % A_RC_CPR, a_k0 = t / A_RC_CPR;
+    const int b_rc = t % B_RC_CPR, b_k0 = t / B_RC_CPR;
+    int wg_dh = 0, wg_dw = 0, wg_ci = 0; bool wg_ok = false;      // WGRAD B column (tap, ci)
+    if constexpr (MODE == WGRAD) {
+        const int nn = n0 + 4 * b_rc;
+        wg_ok = nn < p.Nn;
+        const int tap = nn / p.Cin; wg_ci = nn - tap * p.Cin;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        wg_dh = kh * p.dil - p.pad; wg_dw = kw * p.dil - p.pad;
+    }
+
+    f32x4 ra[NA], rb[NB];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    auto load_tile = [&](int kt) {
+        const int kbase = kbeg + kt * BK;
+        // ---------------- A
+        if constexpr (MODE == FPROP) {
+            const int k = kbase + 4 * kc;
+            const bool kok = k < p.K;
+            const int tap = k / p.Cin, ci = k - tap * p.Cin;
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+            const int dh = kh * p.dil, dw = kw * p.dil;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int ih = a_y[i] + dh, iw = a_x[i] + dw;
+                const bool ok = kok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                ra[i] = ok ? ld4(p.a + (long long)(a_nb[i] + ih * p.W + iw) * p.lda + ci) : zero4;
+            }
+        } else if constexpr (MODE == DGRAD) {
+            const int k = kbase + 4 * kc;
+            const bool kok = k < p.K;
+            const int tap = k / p.Cout, co = k - tap * p.Cout;
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+            const int dh = kh * p.dil, dw = kw * p.dil;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                int th = a_y[i] - dh, tw = a_x[i] - dw;
+                bool ok = kok && th >= 0 && tw >= 0;
+                if (p.stride > 1) {
+                    ok = ok && (th % p.stride == 0) && (tw % p.stride == 0);
+                    th /= p.stride; tw /= p.stride;
+                }
+                ok = ok && th < p.Ho && tw < p.Wo;
+                ra[i] = ok ? ld4(p.a + (long long)(a_nb[i] + th * p.Wo + tw) * p.lda + co) : zero4;
+            }
+        } else {  // WGRAD A = dY[pix][co]
+            const int co = m0 + 4 * a_rc;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int pix = kbase + a_k0 + A_RC_KPP * i;
+                const bool ok = pix < kend && co < p.M;
+                ra[i] = ok ? ld4(p.a + (long long)pix * p.lda + co) : zero4;
+            }
+        }
+        // ---------------- B
+        if constexpr (MODE == FPROP) {
+            const int k = kbase + 4 * kc;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int j = n0 + r0 + 32 * i;
+                const bool ok = k < p.K && j < p.Nn;
+                rb[i] = ok ? ld4(p.b + (long long)j * p.K + k) : zero4;
+            }
+        } else if constexpr (MODE == DGRAD) {
+            const int ci = n0 + 4 * b_rc;
+            const int T = p.KH * p.KW;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int k = kbase + b_k0 + B_RC_KPP * i;
+                const int tap = k / p.Cout, co = k - tap * p.Cout;
+                const bool ok = k < p.K && ci < p.Nn;
+                rb[i] = ok ? ld4(p.b + ((long long)co * T + tap) * p.Cin + ci) : zero4;
+            }
+        } else {  // WGRAD B = im2col(X)[pix][(tap,ci)]
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int pix = kbase + b_k0 + B_RC_KPP * i;
+                bool ok = wg_ok && pix < kend;
+                const int ow = pix % p.Wo, q = pix / p.Wo, oh = q % p.Ho, n = q / p.Ho;
+                const int ih = oh * p.stride + wg_dh, iw = ow * p.stride + wg_dw;
+                ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                rb[i] = ok ? ld4(p.b + ((long long)(n * p.H + ih) * p.W + iw) * p.ldb + wg_ci) : zero4;
+            }
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        float* As = smem + buf * (A_ELEMS + B_ELEMS);
+        float* Bs = As + A_ELEMS;
+        if constexpr (A_KC) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) st4(As + (r0 + 32 * i) * KP + 4 * kc, ra[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) st4(As + (a_k0 + A_RC_KPP * i) * BM + 4 * a_rc, ra[i]);
+        }
+        if constexpr (B_KC) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) st4(Bs + (r0 + 32 * i) * KP + 4 * kc, rb[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) st4(Bs + (b_k0 + B_RC_KPP * i) * BN + 4 * b_rc, rb[i]);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nkt > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    const int arow = wm * 32 * TM + l31, brow = wn * 32 * TN + l31;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        const float* As = smem + buf * (A_ELEMS + B_ELEMS);
+        const float* Bs = As + A_ELEMS;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 8) {
+            float av[TM][4], bv[TN][4];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if constexpr (A_KC) {
+                    const f32x4 v = ld4(As + (arow + 32 * i) * KP + kk + 4 * h);
+                    av[i][0] = v[0]; av[i][1] = v[1]; av[i][2] = v[2]; av[i][3] = v[3];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) av[i][e] = As[(kk + 4 * h + e) * BM + arow + 32 * i];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (B_KC) {
+                    const f32x4 v = ld4(Bs + (brow + 32 * j) * KP + kk + 4 * h);
+                    bv[j][0] = v[0]; bv[j][1] = v[1]; bv[j][2] = v[2]; bv[j][3] = v[3];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bv[j][e] = Bs[(kk + 4 * h + e) * BN + brow + 32 * j];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(av[i][e], bv[j][e], acc[i][j]);
+        }
+        if (kt + 1 < nkt) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    if constexpr (MODE == WGRAD) {
+        float* slab = p.c + (long long)blockIdx.y * p.M * p.Nn;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * 32 * TN + 32 * j + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 32 * TM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (m < p.M && n < p.Nn) slab[(long long)m * p.Nn + n] = acc[i][j][r];
+                }
+            }
+        return;
+    } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * 32 * TN + 32 * j + l31;
+            const bool nok = n < p.Nn;
+            float bias = 0.f;
+            if constexpr (MODE == FPROP) bias = (p.extra != nullptr && nok) ? p.extra[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 32 * TM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (m < p.M && nok) {
+                        if constexpr (MODE == FPROP) {
+                            p.c[(long long)m * p.ldc + n] = acc[i][j][r] + bias;
+                        } else {
+                            float v = acc[i][j][r];
+                            if (p.extra != nullptr) v += p.extra[(long long)m * p.ldadd + n];
+                            if (p.scatter) {
+                                const int ow = m % p.W, q = m / p.W, oh = q % p.H, nb = q / p.H;
+                                float* dst = p.c + ((long long)(nb * p.sH + oh * p.sstride) * p.sW + ow * p.sstride) * p.ldc + n;
+                                *dst += v;
+                            } else {
+                                p.c[(long long)m * p.ldc + n] = v;
+                            }
+                        }
+                    }
+                }
+        }
+        if constexpr (MODE == FPROP) {
+            if (p.partials != nullptr) {   // block-uniform
+                float s[TN], q[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float ss = 0.f, qq = 0.f;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; ss += v; qq += v * v; }
+                    ss += __shfl_xor(ss, 32, 64); qq += __shfl_xor(qq, 32, 64);
+                    s[j] = ss; q[j] = qq;
+                }
+                if constexpr (TM == 2) {   // a wave covers exactly one 64-row partial
+                    const int pidx = tile_m * 2 + wm;
+                    if (h == 0 && pidx < p.n_partials) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const int n = n0 + wn * 32 * TN + 32 * j + l31;
+                            if (n < p.Nn) {
+                                p.partials[((long long)pidx * 2 + 0) * p.Nn + n] = s[j];
+                                p.partials[((long long)pidx * 2 + 1) * p.Nn + n] = q[j];
+                            }
+                        }
+                    }
+                } else {                   // two waves (wm = 0,1) share the 64-row partial: combine in LDS
+                    float* red = smem;     // [2 wm][2][BN]; main loop ended with a barrier
+                    if (h == 0) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const int c = wn * 32 * TN + 32 * j + l31;
+                            red[(wm * 2 + 0) * BN + c] = s[j];
+                            red[(wm * 2 + 1) * BN + c] = q[j];
+                        }
+                    }
+                    __syncthreads();
+                    if (t < 2 * BN) {
+                        const int st = t / BN, c = t - st * BN, n = n0 + c;
+                        if (n < p.Nn)
+                            p.partials[((long long)tile_m * 2 + st) * p.Nn + n] = red[st * BN + c] + red[(2 + st) * BN + c];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// slab reduce: dw[i] = sum_s slab[s][i]
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                          long long n4, long long n, int S) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 s = ld4(slab + 4 * i);
+    for (int k = 1; k < S; ++k) s += ld4(slab + (long long)k * n + 4 * i);
+    st4(dw + 4 * i, s);
+}
+
+// ---------------------------------------------------------------------------------------- host side
+template <int MODE, int TM, int TN>
+static int launch_variant(const ConvP& p, int splits, hipStream_t st) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, KP = BK + 4;
+    constexpr int A_ELEMS = (MODE != WGRAD) ? BM * KP : BK * BM;
+    constexpr int B_ELEMS = (MODE == FPROP) ? BN * KP : BK * BN;
+    constexpr size_t lds = 2 * (size_t)(A_ELEMS + B_ELEMS) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<MODE, TM, TN>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits);
+    conv_gemm_kernel<MODE, TM, TN><<<grid, 256, lds, st>>>(p);
+    return sh_launch_status();
+}
+
+static void pick_tiles(long long M, long long Nn, int& TM, int& TN) {
+    TN = Nn <= 64 ? 1 : 2;
+    TM = 2;
+    if (sh_cdiv(M, 128) * sh_cdiv(Nn, 64 * TN) < 256) {
+        TM = 1;
+        if (TN == 2 && sh_cdiv(M, 64) * sh_cdiv(Nn, 128) < 256) TN = 1;
+    }
+    if (M <= 64) TM = 1;
+}
+
+template <int MODE>
+static int launch_conv(ConvP& p, int TM, int TN, int splits, hipStream_t st) {
+    p.tiles_m = (int)sh_cdiv(p.M, 64 * TM);
+    p.tiles_n = (int)sh_cdiv(p.Nn, 64 * TN);
+    if (TM == 2 && TN == 2) return launch_variant<MODE, 2, 2>(p, splits, st);
+    if (TM == 2 && TN == 1) return launch_variant<MODE, 2, 1>(p, splits, st);
+    if (TM == 1 && TN == 2) return launch_variant<MODE, 1, 2>(p, splits, st);
+    return launch_variant<MODE, 1, 1>(p, splits, st);
+}
+
+static bool conv_geom(ConvP& p, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || dil <= 0 || pad < 0) return false;
+    if (Cin % 4 != 0) return false;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW;
+    p.stride = stride; p.pad = pad; p.dil = dil;
+    p.Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+    p.Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+    if (p.Ho <= 0 || p.Wo <= 0) return false;
+    if ((long long)N * H * W >= (1ll << 31) || (long long)N * p.Ho * p.Wo >= (1ll << 31)) return false;
+    if ((long long)KH * KW * (long long)(Cin > Cout ? Cin : Cout) >= (1ll << 30)) return false;
+    p.scatter = 0; p.sH = p.sW = p.sstride = 0; p.kchunk = 0; p.n_partials = 0;
+    p.extra = nullptr; p.partials = nullptr; p.ldadd = 0;
+    return true;
+}
+
+extern "C" int sh_conv_tile_rows(void) { return 64; }
+
+extern "C" int sh_conv_fprop(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
+                             float* stat_partials, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                             int stride, int pad, int dil, void* stream) {
+    ConvP p{};
+    if (!x || !w || !y || !conv_geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil)) return SH_EINVAL;
+    if (ldx < Cin || ldy < Cout || (ldx & 3)) return SH_EINVAL;
+    p.a = x; p.b = w; p.c = y; p.extra = bias; p.partials = stat_partials;
+    p.lda = ldx; p.ldc = ldy;
+    p.M = N * p.Ho * p.Wo; p.Nn = Cout; p.K = KH * KW * Cin;
+    p.n_partials = (int)sh_cdiv(p.M, 64);
+    int TM, TN;
+    pick_tiles(p.M, p.Nn, TM, TN);
+    return launch_conv<FPROP>(p, TM, TN, 1, (hipStream_t)stream);
+}
+
+extern "C" int sh_conv_dgrad(const float* dy, int lddy, const float* w, const float* addend, int ldadd,
+                             float* dx, int lddx, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                             int stride, int pad, int dil, int mode, void* stream) {
+    ConvP p{};
+    if (!dy || !w || !dx || !conv_geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil)) return SH_EINVAL;
+    // Cout % 4 != 0 is accepted for 1x1 convs when dy rows are padded to a multiple of 4 (padding lanes finite)
+    if (lddy < Cout || (lddy & 3) || lddx < Cin) return SH_EINVAL;
+    if ((Cout & 3) && !(KH * KW == 1 && lddy >= ((Cout + 3) & ~3))) return SH_EINVAL;
+    if (addend && ldadd < Cin) return SH_EINVAL;
+    p.a = dy; p.b = w; p.c = dx; p.extra = addend; p.ldadd = ldadd;
+    p.lda = lddy; p.ldc = lddx;
+    p.Nn = Cin; p.K = KH * KW * Cout;
+    if (mode == 1) {
+        if (KH != 1 || KW != 1 || pad != 0) return SH_EINVAL;
+        // GEMM over the OUTPUT grid (a stride-1 1x1 conv there); rows scattered to (oh*s, ow*s) and accumulated.
+        p.scatter = 1; p.sH = H; p.sW = W; p.sstride = stride;
+        p.H = p.Ho; p.W = p.Wo; p.stride = 1;
+        p.M = N * p.Ho * p.Wo;
+    } else if (mode == 0) {
+        p.M = N * H * W;
+    } else {
+        return SH_EINVAL;
+    }
+    int TM, TN;
+    pick_tiles(p.M, p.Nn, TM, TN);
+    return launch_conv<DGRAD>(p, TM, TN, 1, (hipStream_t)stream);
+}
+
+struct WgradPlan { int TM, TN, splits, kchunk; };
+static WgradPlan wgrad_plan(int Cout, long long Nn, long long npix) {
+    WgradPlan g;
+    g.TM = Cout <= 64 ? 1 : 2;
+    g.TN = Nn <= 64 ? 1 : 2;
+    long long tiles = sh_cdiv(Cout, 64 * g.TM) * sh_cdiv(Nn, 64 * g.TN);
+    if (tiles < 64 && g.TM == 2 && g.TN == 2) { /* keep the big tile: parallelism comes from the pixel split */ }
+    long long want = sh_cdiv(1024, tiles);
+    long long maxs = sh_cdiv(npix, 256);
+    long long s = want < 1 ? 1 : want;
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    long long chunk = sh_cdiv(sh_cdiv(npix, s), 32) * 32;
+    g.kchunk = (int)chunk;
+    g.splits = (int)sh_cdiv(npix, chunk);
+    return g;
+}
+
+extern "C" int64_t sh_conv_wgrad_workspace(int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                           int stride, int pad, int dil) {
+    ConvP p{};
+    if (!conv_geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil)) return SH_EINVAL;
+    const long long Nn = (long long)KH * KW * Cin, npix = (long long)N * p.Ho * p.Wo;
+    WgradPlan g = wgrad_plan(Cout, Nn, npix);
+    return (int64_t)g.splits * Cout * Nn * (int64_t)sizeof(float);
+}
+
+extern "C" int sh_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw, float* workspace,
+                             int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                             int dil, void* stream) {
+    ConvP p{};
+    if (!x || !dy || !dw || !workspace || !conv_geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil)) return SH_EINVAL;
+    if (lddy < ((Cout + 3) & ~3) || (lddy & 3) || ldx < Cin || (ldx & 3)) return SH_EINVAL;
+    p.a = dy; p.b = x; p.c = workspace;
+    p.lda = lddy; p.ldb = ldx;
+    p.M = Cout; p.Nn = KH * KW * Cin; p.K = N * p.Ho * p.Wo;
+    WgradPlan g = wgrad_plan(Cout, p.Nn, p.K);
+    p.kchunk = g.kchunk;
+    int rc = launch_conv<WGRAD>(p, g.TM, g.TN, g.splits, (hipStream_t)stream);
+    if (rc != SH_OK) return rc;
+    const long long n = (long long)Cout * p.Nn, n4 = n / 4;   // Nn % 4 == 0
+    slab_reduce_kernel<<<(unsigned)sh_cdiv(n4, 256), 256, 0, (hipStream_t)stream>>>(workspace, dw, n4, n, g.splits);
+    return sh_launch_status();
+}

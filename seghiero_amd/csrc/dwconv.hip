@@ -1,0 +1,171 @@
+// Depthwise 3x3 convolution (groups = C, stride 1, padding = dilation), NHWC, fp32.
+// reference: DepthwiseSeparableConv.depthwise, models/head/sep_aspp_contrast_head.py:43-46,56 (the three ASPP
+// branches with dilation 12/24/36 and the two sep_bottleneck convs with dilation 1).
+//
+// HBM-bound (AI 2.2 FLOP/B): one thread per (pixel, 4 channels), nine 16-byte taps, weights staged once per block
+// in LDS as [tap][channel].  Taps that fall outside the image for EVERY pixel (dilation >= H and >= W, the
+// centre-tap degeneration of SURVEY A.1) are skipped block-uniformly.  The forward also emits the per-channel
+// (sum, sum^2) partials of its output for the following train-mode BatchNorm, so the tensor is not re-read.
+#include "common.h"
+
+#define DW_PIX 64          // pixels per block
+#define DW_CH 64           // channels per block (16 float4 lanes)
+
+extern "C" int sh_dw_partials(int N, int H, int W) { return (int)sh_cdiv((long long)N * H * W, DW_PIX); }
+
+// block: 256 threads = 16 channel-quads x 16 pixel lanes; each thread loops 4 pixels.
+template <int MODE>   // 0 fprop (+stats), 1 dgrad (flipped taps)
+__global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ w,
+                                                     float* __restrict__ y, long long ldy, float* __restrict__ partials,
+                                                     int H, int W, int C, int dil, long long M, int accumulate) {
+    __shared__ float ws[9][DW_CH];
+    __shared__ float red[2][16][DW_CH];
+    const int t = threadIdx.x, cq = t & 15, pl = t >> 4;
+    const int c0 = blockIdx.y * DW_CH;
+    for (int i = t; i < 9 * DW_CH; i += 256) {
+        const int tap = i / DW_CH, cc = i % DW_CH;
+        const int src_tap = MODE == 0 ? tap : 8 - tap;      // dgrad = correlation with the flipped kernel
+        ws[tap][cc] = (c0 + cc < C) ? w[(long long)(c0 + cc) * 9 + src_tap] : 0.f;
+    }
+    __syncthreads();
+    const int c = c0 + cq * 4;
+    const bool cok = c < C;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    const bool tap_row_ok = dil < H, tap_col_ok = dil < W;   // off-centre taps can touch the image at all?
+#pragma unroll
+    for (int it = 0; it < DW_PIX / 16; ++it) {
+        const long long m = (long long)blockIdx.x * DW_PIX + it * 16 + pl;
+        if (m < M && cok) {
+            const int ow = (int)(m % W);
+            const long long r = m / W;
+            const int oh = (int)(r % H);
+            const long long n = r / H;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                if (kh != 1 && !tap_row_ok) continue;
+                const int ih = oh + (kh - 1) * dil;
+                if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    if (kw != 1 && !tap_col_ok) continue;
+                    const int iw = ow + (kw - 1) * dil;
+                    if ((unsigned)iw >= (unsigned)W) continue;
+                    const f32x4 v = ld4(x + ((n * H + ih) * W + iw) * ldx + c);
+                    const f32x4 wv = ld4(&ws[kh * 3 + kw][cq * 4]);
+                    acc += v * wv;
+                }
+            }
+            if (MODE == 1 && accumulate) acc += ld4(y + m * ldy + c);
+            st4(y + m * ldy + c, acc);
+            s += acc; q += acc * acc;
+        }
+    }
+    if (MODE == 0 && partials != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { red[0][pl][cq * 4 + j] = s[j]; red[1][pl][cq * 4 + j] = q[j]; }
+        __syncthreads();
+        if (t < 2 * DW_CH) {
+            const int st = t / DW_CH, cc = t % DW_CH;
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a += red[st][k][cc];
+            if (c0 + cc < C) partials[((long long)blockIdx.x * 2 + st) * C + c0 + cc] = a;
+        }
+    }
+}
+
+// wgrad: dw[c][tap] = sum_pix dy[pix][c] * x[pix + tap][c]; per-block partials [P][9][C], then a column reduce.
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ dy,
+                                                           long long lddy, float* __restrict__ partials, int H, int W, int C,
+                                                           int dil, long long M) {
+    __shared__ float red[16][DW_CH];
+    const int t = threadIdx.x, cq = t & 15, pl = t >> 4;
+    const int c0 = blockIdx.y * DW_CH, c = c0 + cq * 4;
+    const bool cok = c < C;
+    f32x4 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < DW_PIX / 16; ++it) {
+        const long long m = (long long)blockIdx.x * DW_PIX + it * 16 + pl;
+        if (m < M && cok) {
+            const int ow = (int)(m % W);
+            const long long r = m / W;
+            const int oh = (int)(r % H);
+            const long long n = r / H;
+            const f32x4 g = ld4(dy + m * lddy + c);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int ih = oh + (kh - 1) * dil;
+                if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int iw = ow + (kw - 1) * dil;
+                    if ((unsigned)iw >= (unsigned)W) continue;
+                    acc[kh * 3 + kw] += g * ld4(x + ((n * H + ih) * W + iw) * ldx + c);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[pl][cq * 4 + j] = acc[k][j];
+        __syncthreads();
+        if (t < DW_CH) {
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a += red[r][t];
+            if (c0 + t < C) partials[((long long)blockIdx.x * 9 + k) * C + c0 + t] = a;
+        }
+    }
+}
+// dw[c][tap] = sum_p partials[p][tap][c]   (f64 accumulate; one block per 64 (tap,c) columns, 4 row groups)
+__global__ __launch_bounds__(256) void dwconv_wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int P, int C) {
+    __shared__ double red[4][64];
+    const int t = threadIdx.x, cl = t & 63, g = t >> 6;
+    const int col = blockIdx.x * 64 + cl;       // col = tap*C + c
+    double s = 0;
+    if (col < 9 * C)
+        for (int p = g; p < P; p += 4) s += (double)partials[(long long)p * 9 * C + col];
+    red[g][cl] = s;
+    __syncthreads();
+    if (t < 64 && col < 9 * C) {
+        const int tap = col / C, c = col % C;
+        dw[(long long)c * 9 + tap] = (float)((red[0][t] + red[1][t]) + (red[2][t] + red[3][t]));
+    }
+}
+
+static bool dw_args_ok(const void* a, const void* b, const void* c, int N, int H, int W, int C, int dil, int ld1, int ld2) {
+    return a && b && c && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && dil > 0 && ld1 >= C && ld2 >= C && !(ld1 & 3) && !(ld2 & 3);
+}
+extern "C" int sh_dwconv_fprop(const float* x, int ldx, const float* w, float* y, int ldy, float* stat_partials,
+                               int N, int H, int W, int C, int dil, void* stream) {
+    if (!dw_args_ok(x, w, y, N, H, W, C, dil, ldx, ldy)) return SH_EINVAL;
+    const long long M = (long long)N * H * W;
+    dim3 grid((unsigned)sh_cdiv(M, DW_PIX), (unsigned)sh_cdiv(C, DW_CH));
+    dwconv_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, w, y, ldy, stat_partials, H, W, C, dil, M, 0);
+    return sh_launch_status();
+}
+extern "C" int sh_dwconv_dgrad(const float* dy, int lddy, const float* w, float* dx, int lddx, int N, int H, int W, int C,
+                               int dil, int accumulate, void* stream) {
+    if (!dw_args_ok(dy, w, dx, N, H, W, C, dil, lddy, lddx)) return SH_EINVAL;
+    const long long M = (long long)N * H * W;
+    dim3 grid((unsigned)sh_cdiv(M, DW_PIX), (unsigned)sh_cdiv(C, DW_CH));
+    dwconv_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(dy, lddy, w, dx, lddx, nullptr, H, W, C, dil, M, accumulate);
+    return sh_launch_status();
+}
+extern "C" int sh_dwconv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw_partials, float* dw,
+                               int N, int H, int W, int C, int dil, void* stream) {
+    if (!dw_args_ok(x, dy, dw, N, H, W, C, dil, ldx, lddy) || !dw_partials) return SH_EINVAL;
+    const long long M = (long long)N * H * W;
+    const int P = (int)sh_cdiv(M, DW_PIX);
+    dim3 grid((unsigned)P, (unsigned)sh_cdiv(C, DW_CH));
+    dwconv_wgrad_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, dy, lddy, dw_partials, H, W, C, dil, M);
+    int rc = sh_launch_status();
+    if (rc != SH_OK) return rc;
+    dwconv_wgrad_reduce_kernel<<<(unsigned)sh_cdiv(9 * C, 64), 256, 0, (hipStream_t)stream>>>(dw_partials, dw, P, C);
+    return sh_launch_status();
+}

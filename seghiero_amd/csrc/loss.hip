@@ -1,0 +1,676 @@
+// Fused loss / metric kernels of the SegHiero training step (gfx950).
+//
+//  * sh_hiera2_loss  : bilinear resize of the 1/4-resolution logits to the label grid (train.py:282-284) fused with
+//                      the coarse-target lookup (hiera_triplet_loss.py:11-38), the sigmoid hierarchical BCE (:41-107)
+//                      and both all-pixel-mean CE terms (:183-187).  The 218 MB full-resolution logit tensor of the
+//                      reference is never materialised: forward = one pass producing 6 sums, backward = one gather-form
+//                      pass producing d/d(low-res logits) directly (deterministic, no atomics).
+//  * sh_ce_loss      : the same for the aux head's nn.CrossEntropyLoss(ignore_index=255) (train.py:309-313).
+//  * sh_triplet_*    : tree-triplet (tree_triplet_loss.py:15-65 / rmi_tree_triplet_loss.py:14-70).
+//  * sh_pixel_metrics: fine argmax, pixel accuracy counts (train.py:37-49, 381-385) and a confusion matrix.
+// All are HBM/latency-bound reductions: wave shuffles -> LDS -> one partial per block -> f64 finalize.
+#include "common.h"
+
+#define IGN 255
+#define MAXB 32       // max coarse buckets
+#define MAXF 64       // max fine classes
+
+struct H2Tab {
+    int nf, nc;
+    int bs[MAXB], be[MAXB];
+    signed char bucket_of[MAXF];
+};
+
+struct Lerp { int i0, i1; float w0, w1; };
+__device__ __forceinline__ Lerp lerp_src(int dst, float scale, int in) {
+    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    Lerp L;
+    L.i0 = (int)s;
+    if (L.i0 > in - 1) L.i0 = in - 1;
+    L.i1 = L.i0 + (L.i0 < in - 1 ? 1 : 0);
+    L.w1 = s - (float)L.i0;
+    L.w0 = 1.f - L.w1;
+    return L;
+}
+__device__ __forceinline__ void contrib_range(int i, float inv_scale, int out, int& lo, int& hi) {
+    lo = (int)floorf(((float)i - 0.5f) * inv_scale - 0.5f) - 1;
+    hi = (int)ceilf(((float)i + 1.5f) * inv_scale - 0.5f) + 1;
+    if (i == 0) lo = 0;
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > out - 1 ? out - 1 : hi;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// interpolate C channels of pixel (oy,ox) from the low-res logits of image n
+template <int MAXC>
+__device__ __forceinline__ void fetch_logits(const float* __restrict__ base, long long ldl, int w, const Lerp& ly, const Lerp& lx,
+                                             bool identity, int C, float (&z)[MAXC]) {
+    if (identity) {
+        const float* p = base + ((long long)ly.i0 * w + lx.i0) * ldl;
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j) z[j] = j < C ? p[j] : 0.f;
+    } else {
+        const float* p00 = base + ((long long)ly.i0 * w + lx.i0) * ldl;
+        const float* p01 = base + ((long long)ly.i0 * w + lx.i1) * ldl;
+        const float* p10 = base + ((long long)ly.i1 * w + lx.i0) * ldl;
+        const float* p11 = base + ((long long)ly.i1 * w + lx.i1) * ldl;
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j)
+            z[j] = j < C ? ly.w0 * (lx.w0 * p00[j] + lx.w1 * p01[j]) + ly.w1 * (lx.w0 * p10[j] + lx.w1 * p11[j]) : 0.f;
+    }
+}
+
+__device__ __forceinline__ int coarse_of(int f, const H2Tab& T) {
+    int c = IGN;
+    for (int i = 0; i < T.nc; ++i)
+        if (f >= T.bs[i] && f < T.be[i]) c = i;     // later buckets overwrite, like the reference's sequential masked writes
+    return c;
+}
+
+// log-softmax CE of z[off..off+n) against target tgt: returns -log p_tgt; optionally adds coef*(softmax - onehot) to g
+template <int MAXC, bool GRAD>
+__device__ __forceinline__ float softmax_ce(const float (&z)[MAXC], int off, int n, int tgt, float coef, float (&g)[MAXC]) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) if (j >= off && j < off + n) mx = fmaxf(mx, z[j]);
+    float se = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) if (j >= off && j < off + n) se += expf(z[j] - mx);
+    const float lse = mx + logf(se);
+    float zt = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+        if (j >= off && j < off + n) {
+            if (j - off == tgt) zt = z[j];
+            if (GRAD) g[j] += coef * (expf(z[j] - lse) - (j - off == tgt ? 1.f : 0.f));
+        }
+    }
+    return lse - zt;
+}
+
+// Per-pixel 2-level terms.  out[0..3] = bce_fine, bce_coarse, ce_fine, ce_coarse.  With GRAD: g[j] += d/dz_j of
+//   af*bce_fine + ac*bce_coarse + b*(ce_fine + ce_coarse).
+template <int MAXC, bool GRAD>
+__device__ __forceinline__ void hiera2_pixel(const float (&z)[MAXC], int f, int c, const H2Tab& T, float af, float ac, float b,
+                                             float (&out)[4], float (&g)[MAXC]) {
+    const float eps = 1e-8f;
+    const int nf = T.nf, nc = T.nc;
+    float p[MAXC];
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) p[j] = j < nf + nc ? sigmoidf_(z[j]) : 0.f;
+    out[0] = out[1] = out[2] = out[3] = 0.f;
+    if (f != IGN) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) {
+            if (k < nf) {
+                const float s = p[k];
+                if (k == f) {
+                    const int bi = T.bucket_of[k];
+                    float tt = 2.f; int tj = -1;
+#pragma unroll
+                    for (int j = 0; j < MAXC; ++j) if (bi >= 0 && j == nf + bi) { tt = p[j]; tj = j; }
+                    const bool s_is_min = (bi < 0) || (s <= tt);
+                    const float m = s_is_min ? s : tt;
+                    acc += -logf(m + eps);
+                    if (GRAD) {
+                        const float d = -af / (m + eps);
+                        if (s_is_min) g[k] += d * s * (1.f - s);
+                        else {
+#pragma unroll
+                            for (int j = 0; j < MAXC; ++j) if (j == tj) g[j] += d * tt * (1.f - tt);
+                        }
+                    }
+                } else {
+                    acc += -logf(1.f - s + eps);
+                    if (GRAD) g[k] += af / (1.f - s + eps) * s * (1.f - s);
+                }
+            }
+        }
+        out[0] = acc;
+        out[2] = softmax_ce<MAXC, GRAD>(z, 0, nf, f, b, g);
+    }
+    if (c != IGN) {
+        float acc = 0.f;
+        for (int i = 0; i < nc; ++i) {
+            float ti = 0.f;
+#pragma unroll
+            for (int j = 0; j < MAXC; ++j) if (j == nf + i) ti = p[j];
+            if (i == c) {
+                acc += -logf(ti + eps);
+                if (GRAD) {
+                    const float d = -ac / (ti + eps) * ti * (1.f - ti);
+#pragma unroll
+                    for (int j = 0; j < MAXC; ++j) if (j == nf + i) g[j] += d;
+                }
+            } else {
+                // max over [fine channels of bucket i ..., coarse channel i], first maximum wins (torch.max tie rule)
+                float best = -INFINITY; int bj = -1;
+#pragma unroll
+                for (int j = 0; j < MAXC; ++j)
+                    if (j < nf && j >= T.bs[i] && j < T.be[i] && p[j] > best) { best = p[j]; bj = j; }
+                if (ti > best) { best = ti; bj = nf + i; }
+                acc += -logf(1.f - best + eps);
+                if (GRAD) {
+                    const float d = ac / (1.f - best + eps) * best * (1.f - best);
+#pragma unroll
+                    for (int j = 0; j < MAXC; ++j) if (j == bj) g[j] += d;
+                }
+            }
+        }
+        out[1] = acc;
+        out[3] = softmax_ce<MAXC, GRAD>(z, nf, nc, c, b, g);
+    }
+}
+
+// block reduce NV floats -> partials[blockIdx.x][8]
+template <int NV>
+__device__ __forceinline__ void block_reduce_store(float (&v)[NV], float* __restrict__ partials) {
+    __shared__ float red[NV][4];
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = wave_sum(v[j]);
+    if ((t & 63) == 0) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) red[j][t >> 6] = v[j];
+    }
+    __syncthreads();
+    if (t < 8) partials[(long long)blockIdx.x * 8 + t] = t < NV ? (red[t][0] + red[t][1]) + (red[t][2] + red[t][3]) : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------ 2-level forward
+#define LOSS_PIX_PER_BLOCK 1024
+template <int MAXC>
+__global__ __launch_bounds__(256) void hiera2_fwd_kernel(const float* __restrict__ logits, long long ldl, const uint8_t* __restrict__ labels,
+                                                         const H2Tab T, float* __restrict__ partials, uint8_t* __restrict__ coarse_out,
+                                                         int h, int w, int H, int W, float sy, float sx, long long total) {
+    const bool identity = (h == H && w == W);
+    const int C = T.nf + T.nc;
+    float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const long long base = (long long)blockIdx.x * LOSS_PIX_PER_BLOCK;
+#pragma unroll 1
+    for (int it = 0; it < LOSS_PIX_PER_BLOCK / 256; ++it) {
+        const long long i = base + it * 256 + threadIdx.x;
+        if (i >= total) break;
+        const int f = labels[i];
+        const int c = f == IGN ? IGN : coarse_of(f, T);
+        if (coarse_out) coarse_out[i] = (uint8_t)c;
+        if (f == IGN) continue;       // coarse is 255 too (255 is in no bucket): nothing contributes
+        const int ox = (int)(i % W);
+        const long long q = i / W;
+        const int oy = (int)(q % H);
+        const long long n = q / H;
+        const Lerp ly = lerp_src(oy, sy, h), lx = lerp_src(ox, sx, w);
+        float z[MAXC], g[MAXC], o[4];
+        fetch_logits<MAXC>(logits + n * h * w * ldl, ldl, w, ly, lx, identity, C, z);
+        hiera2_pixel<MAXC, false>(z, f, c, T, 0.f, 0.f, 0.f, o, g);
+        v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+        v[4] += 1.f; v[5] += (c != IGN) ? 1.f : 0.f;
+    }
+    block_reduce_store<6>(v, partials);
+}
+// sums[0..3] = the four sums, sums[4] = n_valid_fine, sums[5] = n_valid_coarse, sums[6] = n_pixels; loss_out = scalar loss
+__global__ __launch_bounds__(256) void hiera2_finalize_kernel(const float* __restrict__ partials, int nblk, double npix, int nf, int nc,
+                                                              double* __restrict__ sums, float* __restrict__ loss_out) {
+    __shared__ double red[8][4];
+    const int t = threadIdx.x;
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = t; b < nblk; b += 256)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += (double)partials[(long long)b * 8 + j];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = wave_sum_d(a[j]);
+    if ((t & 63) == 0)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[j][t >> 6] = a[j];
+    __syncthreads();
+    if (t == 0) {
+        double s[8];
+        for (int j = 0; j < 8; ++j) s[j] = (red[j][0] + red[j][1]) + (red[j][2] + red[j][3]);
+        s[6] = npix;
+        for (int j = 0; j < 8; ++j) sums[j] = s[j];
+        const double nvf = s[4] < 1.0 ? 1.0 : s[4], nvc = s[5] < 1.0 ? 1.0 : s[5];
+        const double lf = s[0] / (nvf * nf), lc = nc > 0 ? s[1] / (nvc * nc) : 0.0;
+        // the reference evaluates every term in f32; round each term to f32 before combining like it does
+        const float hiera = 5.0f * ((float)lf + (float)lc);
+        loss_out[0] = hiera + (float)(s[2] / npix) + (float)(s[3] / npix);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ 2-level backward (gather form)
+template <int MAXC>
+__global__ __launch_bounds__(256) void hiera2_bwd_kernel(const float* __restrict__ logits, long long ldl, const uint8_t* __restrict__ labels,
+                                                         const H2Tab T, const double* __restrict__ sums, const float* __restrict__ gscale_dev,
+                                                         float gscale, float* __restrict__ dlogits, long long lddl, int h, int w, int H,
+                                                         int W, float sy, float sx, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const bool identity = (h == H && w == W);
+    const int C = T.nf + T.nc;
+    const int ix = (int)(i % w);
+    const long long q = i / w;
+    const int iy = (int)(q % h);
+    const long long n = q / h;
+    const float gs = gscale * (gscale_dev ? gscale_dev[0] : 1.f);
+    const double nvf = sums[4] < 1.0 ? 1.0 : sums[4], nvc = sums[5] < 1.0 ? 1.0 : sums[5];
+    const float af = gs * (float)(5.0 / (nvf * T.nf)), ac = T.nc > 0 ? gs * (float)(5.0 / (nvc * T.nc)) : 0.f;
+    const float b = gs * (float)(1.0 / sums[6]);
+    float acc[MAXC];
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) acc[j] = 0.f;
+    int ylo, yhi, xlo, xhi;
+    if (identity) { ylo = yhi = iy; xlo = xhi = ix; }
+    else { contrib_range(iy, 1.f / sy, H, ylo, yhi); contrib_range(ix, 1.f / sx, W, xlo, xhi); }
+    const float* base = logits + n * h * w * ldl;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+        const Lerp ly = lerp_src(oy, sy, h);
+        const float wy = identity ? 1.f : (ly.i0 == iy ? ly.w0 : 0.f) + (ly.i1 == iy ? ly.w1 : 0.f);
+        if (wy == 0.f) continue;
+        for (int ox = xlo; ox <= xhi; ++ox) {
+            const Lerp lx = lerp_src(ox, sx, w);
+            const float wx = identity ? 1.f : (lx.i0 == ix ? lx.w0 : 0.f) + (lx.i1 == ix ? lx.w1 : 0.f);
+            if (wx == 0.f) continue;
+            const int f = labels[(n * H + oy) * W + ox];
+            if (f == IGN) continue;
+            const int c = coarse_of(f, T);
+            float z[MAXC], g[MAXC], o[4];
+#pragma unroll
+            for (int j = 0; j < MAXC; ++j) g[j] = 0.f;
+            fetch_logits<MAXC>(base, ldl, w, ly, lx, identity, C, z);
+            hiera2_pixel<MAXC, true>(z, f, c, T, af, ac, b, o, g);
+            const float wgt = wy * wx;
+#pragma unroll
+            for (int j = 0; j < MAXC; ++j) acc[j] += wgt * g[j];
+        }
+    }
+    float* dst = dlogits + ((n * h + iy) * w + ix) * lddl;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) if (j < lddl) dst[j] = j < C ? acc[j] : 0.f;   // padding lanes are zeroed (dgrad reads them)
+}
+
+extern "C" int sh_hiera2_partials(int N, int H, int W) { return (int)sh_cdiv((long long)N * H * W, LOSS_PIX_PER_BLOCK); }
+
+static bool make_tab(H2Tab& T, const int* buckets, int nf, int nc) {
+    if (nf <= 0 || nf > MAXF || nc < 0 || nc > MAXB || nf + nc > 32 || (nc > 0 && !buckets)) return false;
+    T.nf = nf; T.nc = nc;
+    for (int k = 0; k < MAXF; ++k) T.bucket_of[k] = -1;
+    for (int i = 0; i < MAXB; ++i) { T.bs[i] = 0; T.be[i] = 0; }
+    for (int i = 0; i < nc; ++i) {
+        T.bs[i] = buckets[2 * i]; T.be[i] = buckets[2 * i + 1];
+        for (int k = T.bs[i]; k < T.be[i] && k < nf; ++k) if (k >= 0) T.bucket_of[k] = (signed char)i;
+    }
+    return true;
+}
+
+extern "C" int sh_hiera2_loss_fwd(const float* logits, int ldl, const uint8_t* labels, const int* buckets_host, int n_fine,
+                                  int n_coarse, double* sums, float* loss_out, float* partials, uint8_t* coarse_out,
+                                  int N, int h, int w, int H, int W, void* stream) {
+    H2Tab T;
+    if (!logits || !labels || !sums || !loss_out || !partials || N <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SH_EINVAL;
+    if (!make_tab(T, buckets_host, n_fine, n_coarse) || ldl < n_fine + n_coarse) return SH_EINVAL;
+    const long long total = (long long)N * H * W;
+    const int nblk = (int)sh_cdiv(total, LOSS_PIX_PER_BLOCK);
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    hipStream_t st = (hipStream_t)stream;
+    const int C = n_fine + n_coarse;
+    if (C <= 8) hiera2_fwd_kernel<8><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total);
+    else if (C <= 16) hiera2_fwd_kernel<16><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total);
+    else hiera2_fwd_kernel<32><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total);
+    int rc = sh_launch_status();
+    if (rc != SH_OK) return rc;
+    hiera2_finalize_kernel<<<1, 256, 0, st>>>(partials, nblk, (double)total, n_fine, n_coarse, sums, loss_out);
+    return sh_launch_status();
+}
+
+extern "C" int sh_hiera2_loss_bwd(const float* logits, int ldl, const uint8_t* labels, const int* buckets_host, int n_fine,
+                                  int n_coarse, const double* sums, const float* gscale_dev, float gscale, float* dlogits,
+                                  int lddl, int N, int h, int w, int H, int W, void* stream) {
+    H2Tab T;
+    if (!logits || !labels || !sums || !dlogits || N <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SH_EINVAL;
+    if (!make_tab(T, buckets_host, n_fine, n_coarse) || ldl < n_fine + n_coarse || lddl < n_fine + n_coarse || lddl > 32) return SH_EINVAL;
+    const long long total = (long long)N * h * w;
+    const unsigned nblk = (unsigned)sh_cdiv(total, 256);
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    hipStream_t st = (hipStream_t)stream;
+    const int C = lddl;   // kernel writes lddl lanes (padding zeroed), so size the register arrays for it
+    if (C <= 8) hiera2_bwd_kernel<8><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, sums, gscale_dev, gscale, dlogits, lddl, h, w, H, W, sy, sx, total);
+    else if (C <= 16) hiera2_bwd_kernel<16><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, sums, gscale_dev, gscale, dlogits, lddl, h, w, H, W, sy, sx, total);
+    else hiera2_bwd_kernel<32><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, sums, gscale_dev, gscale, dlogits, lddl, h, w, H, W, sy, sx, total);
+    return sh_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------ aux CE (valid-pixel mean)
+template <int MAXC>
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, long long ldl, const uint8_t* __restrict__ labels, int C,
+                                                     float* __restrict__ partials, int h, int w, int H, int W, float sy, float sx, long long total) {
+    const bool identity = (h == H && w == W);
+    float v[2] = {0.f, 0.f};
+    const long long base = (long long)blockIdx.x * LOSS_PIX_PER_BLOCK;
+#pragma unroll 1
+    for (int it = 0; it < LOSS_PIX_PER_BLOCK / 256; ++it) {
+        const long long i = base + it * 256 + threadIdx.x;
+        if (i >= total) break;
+        const int f = labels[i];
+        if (f == IGN) continue;
+        const int ox = (int)(i % W);
+        const long long q = i / W;
+        const int oy = (int)(q % H);
+        const long long n = q / H;
+        const Lerp ly = lerp_src(oy, sy, h), lx = lerp_src(ox, sx, w);
+        float z[MAXC], g[MAXC];
+        fetch_logits<MAXC>(logits + n * h * w * ldl, ldl, w, ly, lx, identity, C, z);
+        v[0] += softmax_ce<MAXC, false>(z, 0, C, f, 0.f, g);
+        v[1] += 1.f;
+    }
+    block_reduce_store<2>(v, partials);
+}
+__global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restrict__ partials, int nblk, double* __restrict__ sums, float* __restrict__ loss_out) {
+    __shared__ double red[2][4];
+    const int t = threadIdx.x;
+    double a0 = 0, a1 = 0;
+    for (int b = t; b < nblk; b += 256) { a0 += (double)partials[(long long)b * 8]; a1 += (double)partials[(long long)b * 8 + 1]; }
+    a0 = wave_sum_d(a0); a1 = wave_sum_d(a1);
+    if ((t & 63) == 0) { red[0][t >> 6] = a0; red[1][t >> 6] = a1; }
+    __syncthreads();
+    if (t == 0) {
+        const double s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), c = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        sums[0] = s; sums[1] = c;
+        loss_out[0] = (float)(s / c);      // 0/0 -> NaN like nn.CrossEntropyLoss on an all-ignored batch
+    }
+}
+template <int MAXC>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, long long ldl, const uint8_t* __restrict__ labels, int C,
+                                                     const double* __restrict__ sums, const float* __restrict__ gscale_dev, float gscale,
+                                                     float* __restrict__ dlogits, long long lddl, int h, int w, int H, int W, float sy, float sx,
+                                                     long long total) {
+    // one WAVE per low-res pixel: the contributing window (up to (2*16+2)^2 pixels for the x16 aux resize) is strided over lanes
+    const int lane = threadIdx.x & 63;
+    const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= total) return;
+    const bool identity = (h == H && w == W);
+    const int ix = (int)(i % w);
+    const long long q = i / w;
+    const int iy = (int)(q % h);
+    const long long n = q / h;
+    const float b = gscale * (gscale_dev ? gscale_dev[0] : 1.f) * (float)(1.0 / sums[1]);
+    float acc[MAXC];
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) acc[j] = 0.f;
+    int ylo, yhi, xlo, xhi;
+    if (identity) { ylo = yhi = iy; xlo = xhi = ix; }
+    else { contrib_range(iy, 1.f / sy, H, ylo, yhi); contrib_range(ix, 1.f / sx, W, xlo, xhi); }
+    const int nx = xhi - xlo + 1, ncand = (yhi - ylo + 1) * nx;
+    const float* base = logits + n * h * w * ldl;
+    for (int k = lane; k < ncand; k += 64) {
+        const int oy = ylo + k / nx, ox = xlo + k % nx;
+        const Lerp ly = lerp_src(oy, sy, h), lx = lerp_src(ox, sx, w);
+        const float wy = identity ? 1.f : (ly.i0 == iy ? ly.w0 : 0.f) + (ly.i1 == iy ? ly.w1 : 0.f);
+        const float wx = identity ? 1.f : (lx.i0 == ix ? lx.w0 : 0.f) + (lx.i1 == ix ? lx.w1 : 0.f);
+        const float wgt = wy * wx;
+        if (wgt == 0.f) continue;
+        const int f = labels[(n * H + oy) * W + ox];
+        if (f == IGN) continue;
+        float z[MAXC], g[MAXC];
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j) g[j] = 0.f;
+        fetch_logits<MAXC>(base, ldl, w, ly, lx, identity, C, z);
+        softmax_ce<MAXC, true>(z, 0, C, f, b, g);
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j) acc[j] += wgt * g[j];
+    }
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) acc[j] = wave_sum(acc[j]);
+    if (lane == 0) {
+        float* dst = dlogits + ((n * h + iy) * w + ix) * lddl;
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j) if (j < lddl) dst[j] = j < C ? acc[j] : 0.f;
+    }
+}
+extern "C" int sh_ce_loss_fwd(const float* logits, int ldl, const uint8_t* labels, int C, double* sums, float* loss_out,
+                              float* partials, int N, int h, int w, int H, int W, void* stream) {
+    if (!logits || !labels || !sums || !loss_out || !partials || C <= 0 || C > 32 || ldl < C || N <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SH_EINVAL;
+    const long long total = (long long)N * H * W;
+    const int nblk = (int)sh_cdiv(total, LOSS_PIX_PER_BLOCK);
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    hipStream_t st = (hipStream_t)stream;
+    if (C <= 8) ce_fwd_kernel<8><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total);
+    else if (C <= 16) ce_fwd_kernel<16><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total);
+    else ce_fwd_kernel<32><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total);
+    int rc = sh_launch_status();
+    if (rc != SH_OK) return rc;
+    ce_finalize_kernel<<<1, 256, 0, st>>>(partials, nblk, sums, loss_out);
+    return sh_launch_status();
+}
+extern "C" int sh_ce_loss_bwd(const float* logits, int ldl, const uint8_t* labels, int C, const double* sums, const float* gscale_dev,
+                              float gscale, float* dlogits, int lddl, int N, int h, int w, int H, int W, void* stream) {
+    if (!logits || !labels || !sums || !dlogits || C <= 0 || C > 32 || ldl < C || lddl < C || lddl > 32 || N <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SH_EINVAL;
+    const long long total = (long long)N * h * w;
+    const unsigned nblk = (unsigned)sh_cdiv(total, 4);
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    hipStream_t st = (hipStream_t)stream;
+    if (lddl <= 8) ce_bwd_kernel<8><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, sums, gscale_dev, gscale, dlogits, lddl, h, w, H, W, sy, sx, total);
+    else if (lddl <= 16) ce_bwd_kernel<16><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, sums, gscale_dev, gscale, dlogits, lddl, h, w, H, W, sy, sx, total);
+    else ce_bwd_kernel<32><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, sums, gscale_dev, gscale, dlogits, lddl, h, w, H, W, sy, sx, total);
+    return sh_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------ labels
+__global__ __launch_bounds__(256) void labels_to_u8_kernel(const long long* __restrict__ in, uint8_t* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = (uint8_t)in[i];
+}
+extern "C" int sh_labels_to_u8(const int64_t* in, uint8_t* out, int64_t n, void* stream) {
+    if (!in || !out || n <= 0) return SH_EINVAL;
+    long long g = sh_cdiv(n, 256); if (g > 4096) g = 4096;
+    labels_to_u8_kernel<<<(unsigned)g, 256, 0, (hipStream_t)stream>>>((const long long*)in, out, n);
+    return sh_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------ tree-triplet
+// workspace layout (ints): [0..M) u8 labels (packed, M bytes rounded to 4) | per class c in 0..255: rec[c] = {m, pad, pad, pad,
+//   idxA[T], idxP[T], idxN[T], active[T]}  with T = TRIP_MAX.   class_loss: float[256] after the records.
+#define TRIP_MAX 256
+#define TRIP_REC (4 + 4 * TRIP_MAX)
+struct TripWs { uint8_t* lab; int* rec; float* closs; };
+__host__ __device__ inline TripWs trip_ws(void* ws, long long M) {
+    TripWs t;
+    t.lab = (uint8_t*)ws;
+    const long long off = ((M + 15) / 16) * 16;
+    t.rec = (int*)((uint8_t*)ws + off);
+    t.closs = (float*)(t.rec + 256 * TRIP_REC);
+    return t;
+}
+extern "C" int64_t sh_triplet_workspace(int64_t M) { return ((M + 15) / 16) * 16 + 256ll * TRIP_REC * 4 + 256 * 4 + 64; }
+
+__global__ __launch_bounds__(256) void trip_labels_kernel(const uint8_t* __restrict__ labels, uint8_t* __restrict__ out, int h, int w, int H,
+                                                          int W, float sy, float sx, long long M) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const int x = (int)(i % w);
+    const long long q = i / w;
+    const int y = (int)(q % h);
+    const long long n = q / h;
+    int iy = (int)floorf((float)y * sy), ix = (int)floorf((float)x * sx);   // ATen nearest: min(floor(dst*scale), in-1)
+    iy = iy > H - 1 ? H - 1 : iy; ix = ix > W - 1 ? W - 1 : ix;
+    out[i] = labels[(n * H + iy) * W + ix];
+}
+// masks: [256][2][4] u64 (pos, neg membership bitsets per anchor class); anchor_ok: [4] u64.
+__device__ __forceinline__ bool bit256(const unsigned long long* m, int v) { return (m[v >> 6] >> (v & 63)) & 1ull; }
+
+__global__ __launch_bounds__(256) void trip_class_kernel(const float* __restrict__ emb, int D, const unsigned long long* __restrict__ masks,
+                                                         const unsigned long long* __restrict__ anchor_ok, int max_triplet, float margin,
+                                                         void* ws, long long M) {
+    __shared__ int cnt[3];
+    __shared__ int wave_off[3][4];
+    __shared__ int idx[3][TRIP_MAX];
+    __shared__ float wsum[4];
+    const int cls = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    TripWs W = trip_ws(ws, M);
+    int* rec = W.rec + (long long)cls * TRIP_REC;
+    if (!bit256(anchor_ok, cls)) { if (t == 0) { rec[0] = 0; W.closs[cls] = 0.f; } return; }
+    const unsigned long long* pm = masks + (long long)cls * 8;
+    const unsigned long long* nm = pm + 4;
+    if (t < 3) cnt[t] = 0;
+    __syncthreads();
+    // ordered compaction of the first max_triplet anchor / positive / negative rows (raster order)
+    for (long long basei = 0; basei < M; basei += 256) {
+        const long long i = basei + t;
+        const int lab = i < M ? W.lab[i] : -1;
+        bool fl[3];
+        fl[0] = lab == cls;
+        fl[1] = lab >= 0 && bit256(pm, lab);
+        fl[2] = lab >= 0 && bit256(nm, lab);
+        int pre[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const unsigned long long bal = __ballot(fl[k]);
+            pre[k] = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) wave_off[k][wv] = __popcll(bal);
+        }
+        __syncthreads();
+        int basec[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int o = cnt[k];
+            for (int v = 0; v < wv; ++v) o += wave_off[k][v];
+            basec[k] = o;
+            const int pos = o + pre[k];
+            if (fl[k] && pos < max_triplet) idx[k][pos] = (int)i;
+        }
+        __syncthreads();
+        if (t < 3) cnt[t] = cnt[t] + wave_off[t][0] + wave_off[t][1] + wave_off[t][2] + wave_off[t][3];
+        __syncthreads();
+        (void)basec;
+        if (cnt[0] >= max_triplet && cnt[1] >= max_triplet && cnt[2] >= max_triplet) break;   // block-uniform
+    }
+    int m = min(min(cnt[0], cnt[1]), min(cnt[2], max_triplet));
+    if (m == 0) { if (t == 0) { rec[0] = 0; W.closs[cls] = 0.f; } return; }
+    float part = 0.f;
+    for (int j = wv; j < m; j += 4) {
+        const float* a = emb + (long long)idx[0][j] * D;
+        const float* p = emb + (long long)idx[1][j] * D;
+        const float* n = emb + (long long)idx[2][j] * D;
+        float dap = 0.f, dan = 0.f;
+        for (int d = lane; d < D; d += 64) { const float av = a[d]; dap += av * p[d]; dan += av * n[d]; }
+        dap = wave_sum(dap); dan = wave_sum(dan);
+        const float tl = (1.f - dap) - (1.f - dan) + margin;
+        if (lane == 0) {
+            rec[4 + j] = idx[0][j]; rec[4 + TRIP_MAX + j] = idx[1][j]; rec[4 + 2 * TRIP_MAX + j] = idx[2][j];
+            rec[4 + 3 * TRIP_MAX + j] = tl > 0.f ? 1 : 0;
+            part += tl > 0.f ? tl : 0.f;
+        }
+    }
+    if (lane == 0) wsum[wv] = part;
+    __syncthreads();
+    if (t == 0) { rec[0] = m; W.closs[cls] = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) / (float)m; }
+}
+__global__ void trip_finalize_kernel(void* ws, long long M, float* out) {
+    // out[0] = mean over used classes (0 if none), out[1] = class_count
+    TripWs W = trip_ws(ws, M);
+    if (threadIdx.x == 0) {
+        float s = 0.f; int c = 0;
+        for (int k = 0; k < 256; ++k) if (W.rec[(long long)k * TRIP_REC] > 0) { s += W.closs[k]; ++c; }
+        out[0] = c > 0 ? s / (float)c : 0.f;
+        out[1] = (float)c;
+    }
+}
+__global__ __launch_bounds__(256) void trip_bwd_kernel(const float* __restrict__ emb, int D, void* ws, long long M, const float* __restrict__ out,
+                                                       const float* __restrict__ gscale_dev, float gscale, float* __restrict__ demb) {
+    const int cls = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    TripWs W = trip_ws(ws, M);
+    const int* rec = W.rec + (long long)cls * TRIP_REC;
+    const int m = rec[0];
+    if (m == 0) return;
+    const float coef = gscale * (gscale_dev ? gscale_dev[0] : 1.f) / ((float)m * out[1]);
+    for (int j = wv; j < m; j += 4) {
+        if (!rec[4 + 3 * TRIP_MAX + j]) continue;
+        const long long ia = rec[4 + j], ip = rec[4 + TRIP_MAX + j], in = rec[4 + 2 * TRIP_MAX + j];
+        for (int d = lane; d < D; d += 64) {
+            const float av = emb[ia * D + d], pv = emb[ip * D + d], nv = emb[in * D + d];
+            atomicAdd(demb + ia * D + d, coef * (nv - pv));
+            atomicAdd(demb + ip * D + d, -coef * av);
+            atomicAdd(demb + in * D + d, coef * av);
+        }
+    }
+}
+extern "C" int sh_triplet_fwd(const float* emb, const uint8_t* labels, const uint64_t* masks, const uint64_t* anchor_ok, int max_triplet,
+                              float margin, float* out, void* workspace, int N, int h, int w, int D, int H, int W, void* stream) {
+    if (!emb || !labels || !masks || !anchor_ok || !out || !workspace || N <= 0 || h <= 0 || w <= 0 || D <= 0 || H <= 0 || W <= 0) return SH_EINVAL;
+    if (max_triplet <= 0 || max_triplet > TRIP_MAX) return SH_EINVAL;
+    const long long M = (long long)N * h * w;
+    hipStream_t st = (hipStream_t)stream;
+    TripWs ws = trip_ws(workspace, M);
+    trip_labels_kernel<<<(unsigned)sh_cdiv(M, 256), 256, 0, st>>>(labels, ws.lab, h, w, H, W, (float)H / (float)h, (float)W / (float)w, M);
+    trip_class_kernel<<<256, 256, 0, st>>>(emb, D, (const unsigned long long*)masks, (const unsigned long long*)anchor_ok, max_triplet, margin, workspace, M);
+    trip_finalize_kernel<<<1, 64, 0, st>>>(workspace, M, out);
+    return sh_launch_status();
+}
+extern "C" int sh_triplet_bwd(const float* emb, const void* workspace, const float* out, const float* gscale_dev, float gscale, float* demb,
+                              int N, int h, int w, int D, void* stream) {
+    if (!emb || !workspace || !out || !demb || N <= 0 || h <= 0 || w <= 0 || D <= 0) return SH_EINVAL;
+    const long long M = (long long)N * h * w;
+    trip_bwd_kernel<<<256, 256, 0, (hipStream_t)stream>>>(emb, D, const_cast<void*>(workspace), M, out, gscale_dev, gscale, demb);
+    return sh_launch_status();
+}
+
+// combine: out = (main + (min_count > 0 ? factor * trip : 0)) * loss_weight        (hiera_triplet_loss.py:200-211)
+__global__ void combine_loss_kernel(const float* main_loss, const float* trip_out, const float* ready_count, float factor, float lw, float* out) {
+    if (threadIdx.x == 0) {
+        const float cnt = ready_count ? ready_count[0] : trip_out[1];
+        out[0] = (main_loss[0] + (cnt > 0.f ? factor * trip_out[0] : 0.f)) * lw;
+    }
+}
+extern "C" int sh_combine_loss(const float* main_loss, const float* trip_out, const float* ready_count, float factor, float loss_weight,
+                               float* out, void* stream) {
+    if (!main_loss || !trip_out || !out) return SH_EINVAL;
+    combine_loss_kernel<<<1, 64, 0, (hipStream_t)stream>>>(main_loss, trip_out, ready_count, factor, loss_weight, out);
+    return sh_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------ metrics
+template <int MAXC>
+__global__ __launch_bounds__(256) void pixel_metrics_kernel(const float* __restrict__ logits, long long ldl, const uint8_t* __restrict__ labels,
+                                                            int nf, unsigned long long* __restrict__ counts, int h, int w, int H, int W, float sy,
+                                                            float sx, long long total) {
+    __shared__ unsigned int hist[2 + 32 * 32];
+    const bool identity = (h == H && w == W);
+    for (int i = threadIdx.x; i < 2 + nf * nf; i += 256) hist[i] = 0;
+    __syncthreads();
+    const long long base = (long long)blockIdx.x * LOSS_PIX_PER_BLOCK;
+#pragma unroll 1
+    for (int it = 0; it < LOSS_PIX_PER_BLOCK / 256; ++it) {
+        const long long i = base + it * 256 + threadIdx.x;
+        if (i >= total) break;
+        const int f = labels[i];
+        if (f == IGN) continue;
+        const int ox = (int)(i % W);
+        const long long q = i / W;
+        const int oy = (int)(q % H);
+        const long long n = q / H;
+        const Lerp ly = lerp_src(oy, sy, h), lx = lerp_src(ox, sx, w);
+        float z[MAXC];
+        fetch_logits<MAXC>(logits + n * h * w * ldl, ldl, w, ly, lx, identity, nf, z);
+        int am = 0; float best = z[0];
+#pragma unroll
+        for (int j = 1; j < MAXC; ++j) if (j < nf && z[j] > best) { best = z[j]; am = j; }
+        atomicAdd(&hist[1], 1u);
+        if (am == f) atomicAdd(&hist[0], 1u);
+        if (f < nf) atomicAdd(&hist[2 + f * nf + am], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 + nf * nf; i += 256)
+        if (hist[i]) atomicAdd(&counts[i], (unsigned long long)hist[i]);
+}
+extern "C" int sh_pixel_metrics(const float* logits, int ldl, const uint8_t* labels, int n_fine, long long* counts, int N, int h, int w,
+                                int H, int W, void* stream) {
+    if (!logits || !labels || !counts || n_fine <= 0 || n_fine > 32 || ldl < n_fine || N <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SH_EINVAL;
+    const long long total = (long long)N * H * W;
+    const int nblk = (int)sh_cdiv(total, LOSS_PIX_PER_BLOCK);
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* c = (unsigned long long*)counts;
+    if (n_fine <= 8) pixel_metrics_kernel<8><<<nblk, 256, 0, st>>>(logits, ldl, labels, n_fine, c, h, w, H, W, sy, sx, total);
+    else if (n_fine <= 16) pixel_metrics_kernel<16><<<nblk, 256, 0, st>>>(logits, ldl, labels, n_fine, c, h, w, H, W, sy, sx, total);
+    else pixel_metrics_kernel<32><<<nblk, 256, 0, st>>>(logits, ldl, labels, n_fine, c, h, w, H, W, sy, sx, total);
+    return sh_launch_status();
+}

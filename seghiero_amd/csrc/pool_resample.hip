@@ -1,0 +1,276 @@
+// Max-pool, global average pool / broadcast, bilinear resize (fwd + gather-form bwd), channel L2-normalise.
+// NHWC, HBM-bound: one thread per (pixel, 4 channels) with 16-byte accesses; backward passes are written in
+// gather form so they are deterministic and need no atomics.
+#include "common.h"
+
+static inline unsigned grid_for(long long work_items, int block = 256, int cap = 8192) {
+    long long g = sh_cdiv(work_items, block);
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+#define GRID_STRIDE(i, total) for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (total); i += (long long)gridDim.x * 256)
+
+// ------------------------------------------------------------------------------------------ maxpool 3x3 / 2 / pad 1
+// reference: nn.MaxPool2d(kernel_size=3, stride=2, padding=1) behind models/backbone/resnet.py:68
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
+                                                          int Ho, int Wo, int C4, long long total) {
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C4);
+        long long q = i / C4;
+        const int ow = (int)(q % Wo); q /= Wo;
+        const int oh = (int)(q % Ho);
+        const long long n = q / Ho;
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * 2 - 1 + kh;
+            if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * 2 - 1 + kw;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                const f32x4 v = ld4(x + (((n * H + ih) * W + iw) * C4 + c) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[j] = (v[j] > m[j] || v[j] != v[j]) ? v[j] : m[j];
+            }
+        }
+        st4(y + i * 4, m);
+    }
+}
+// backward, gather form: input pixel (ih,iw) receives dy from every window whose FIRST maximum (row-major scan,
+// the rule ATen's max_pool2d uses) is this pixel.
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ dx, int H, int W, int Ho, int Wo, int C4,
+                                                          long long total) {
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C4);
+        long long q = i / C4;
+        const int iw = (int)(q % W); q /= W;
+        const int ih = (int)(q % H);
+        const long long n = q / H;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // windows containing (ih,iw): oh in {(ih+1)/2 - 1, (ih+1)/2} filtered by the containment test
+        for (int oh = (ih + 1) / 2 - 1; oh <= (ih + 1) / 2; ++oh) {
+            if (oh < 0 || oh >= Ho) continue;
+            if (ih < oh * 2 - 1 || ih > oh * 2 + 1) continue;
+            for (int ow = (iw + 1) / 2 - 1; ow <= (iw + 1) / 2; ++ow) {
+                if (ow < 0 || ow >= Wo) continue;
+                if (iw < ow * 2 - 1 || iw > ow * 2 + 1) continue;
+                // is (ih,iw) the first max of window (oh,ow)?  scan the window in row-major order
+                f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                int bidx[4] = {-1, -1, -1, -1};
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int yy = oh * 2 - 1 + kh;
+                    if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int xx = ow * 2 - 1 + kw;
+                        if ((unsigned)xx >= (unsigned)W) continue;
+                        const f32x4 v = ld4(x + (((n * H + yy) * W + xx) * C4 + c) * 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (v[j] > best[j] || v[j] != v[j]) { best[j] = v[j]; bidx[j] = yy * W + xx; }
+                    }
+                }
+                const f32x4 g = ld4(dy + (((n * Ho + oh) * Wo + ow) * C4 + c) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (bidx[j] == ih * W + iw) acc[j] += g[j];
+            }
+        }
+        st4(dx + i * 4, acc);
+    }
+}
+extern "C" int sh_maxpool_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return SH_EINVAL;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)N * Ho * Wo * (C / 4);
+    maxpool_fwd_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>(x, y, H, W, Ho, Wo, C / 4, total);
+    return sh_launch_status();
+}
+extern "C" int sh_maxpool_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
+    if (!x || !dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return SH_EINVAL;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)N * H * W * (C / 4);
+    maxpool_bwd_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>(x, dy, dx, H, W, Ho, Wo, C / 4, total);
+    return sh_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------ global average pool
+// x [N][HW][ldx] -> y [N][C].  block = (n, 64-channel chunk); 4 row groups; f32 partial sums, f64 combine.
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, long long ldx, float* __restrict__ y,
+                                                          int HW, int C, float inv) {
+    __shared__ double red[4][64];
+    const int t = threadIdx.x, cl = t & 63, g = t >> 6, c = blockIdx.y * 64 + cl;
+    const long long n = blockIdx.x;
+    double s = 0;
+    if (c < C) {
+        float part = 0.f;
+        int cnt = 0;
+        for (int r = g; r < HW; r += 4) {
+            part += x[(n * HW + r) * ldx + c];
+            if (++cnt == 64) { s += part; part = 0.f; cnt = 0; }
+        }
+        s += part;
+    }
+    red[g][cl] = s;
+    __syncthreads();
+    if (t < 64 && c < C) y[n * C + c] = (float)(((red[0][t] + red[1][t]) + (red[2][t] + red[3][t])) * (double)inv);
+}
+extern "C" int sh_avgpool_fwd(const float* x, int ldx, float* y, int N, int HW, int C, void* stream) {
+    if (!x || !y || N <= 0 || HW <= 0 || C <= 0 || ldx < C) return SH_EINVAL;
+    dim3 grid(N, (unsigned)sh_cdiv(C, 64));
+    avgpool_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, y, HW, C, 1.0f / (float)HW);
+    return sh_launch_status();
+}
+extern "C" int sh_sum_hw(const float* dy, int lddy, float* dx, int N, int HW, int C, void* stream) {
+    if (!dy || !dx || N <= 0 || HW <= 0 || C <= 0 || lddy < C) return SH_EINVAL;
+    dim3 grid(N, (unsigned)sh_cdiv(C, 64));
+    avgpool_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(dy, lddy, dx, HW, C, 1.0f);
+    return sh_launch_status();
+}
+// dx[n][r][c] (+)= dy[n][c] * scale
+__global__ __launch_bounds__(256) void bcast_kernel(const float* __restrict__ v, float* __restrict__ out, long long ldo, int HW,
+                                                    int C, float scale, int accumulate, long long total) {
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        const long long q = i / C, n = q / HW;
+        const float val = v[n * C + c] * scale;
+        float* dst = out + q * ldo + c;
+        *dst = accumulate ? *dst + val : val;
+    }
+}
+extern "C" int sh_avgpool_bwd(const float* dy, float* dx, int lddx, int N, int HW, int C, float scale, int accumulate, void* stream) {
+    if (!dy || !dx || N <= 0 || HW <= 0 || C <= 0 || lddx < C) return SH_EINVAL;
+    const long long total = (long long)N * HW * C;
+    bcast_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>(dy, dx, lddx, HW, C, scale, accumulate, total);
+    return sh_launch_status();
+}
+extern "C" int sh_broadcast_hw(const float* x, float* y, int ldy, int N, int HW, int C, void* stream) {
+    return sh_avgpool_bwd(x, y, ldy, N, HW, C, 1.0f, 0, stream);
+}
+
+// ------------------------------------------------------------------------------------------ bilinear (align_corners=False)
+// ATen's rule: src = scale*(dst+0.5)-0.5 clamped at 0, scale = in/out (f32); i1 = i0 + (i0 < in-1).
+struct Lerp { int i0, i1; float w0, w1; };
+__device__ __forceinline__ Lerp lerp_src(int dst, float scale, int in) {
+    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    Lerp L;
+    L.i0 = (int)s;
+    if (L.i0 > in - 1) L.i0 = in - 1;
+    L.i1 = L.i0 + (L.i0 < in - 1 ? 1 : 0);
+    L.w1 = s - (float)L.i0;
+    L.w0 = 1.f - L.w1;
+    return L;
+}
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ x, long long ldx, float* __restrict__ y,
+                                                           long long ldy, int h, int w, int H, int W, int C4, float sy, float sx,
+                                                           long long total) {
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C4) * 4;
+        long long q = i / C4;
+        const int ox = (int)(q % W); q /= W;
+        const int oy = (int)(q % H);
+        const long long n = q / H;
+        const Lerp ly = lerp_src(oy, sy, h), lx = lerp_src(ox, sx, w);
+        const float* b = x + n * h * w * ldx + c;
+        const f32x4 v00 = ld4(b + ((long long)ly.i0 * w + lx.i0) * ldx), v01 = ld4(b + ((long long)ly.i0 * w + lx.i1) * ldx);
+        const f32x4 v10 = ld4(b + ((long long)ly.i1 * w + lx.i0) * ldx), v11 = ld4(b + ((long long)ly.i1 * w + lx.i1) * ldx);
+        const f32x4 r = ly.w0 * (lx.w0 * v00 + lx.w1 * v01) + ly.w1 * (lx.w0 * v10 + lx.w1 * v11);
+        st4(y + ((n * H + oy) * W + ox) * ldy + c, r);
+    }
+}
+// gather-form backward: each input pixel scans the output window that can reference it and re-derives the forward weights.
+__device__ __forceinline__ void contrib_range(int i, float inv_scale, int out, int& lo, int& hi) {
+    // outputs with src in (i-1, i+1): dst in ((i-0.5)/scale-0.5, (i+1.5)/scale-0.5); widen by 1 for rounding, exact test later
+    lo = (int)floorf(((float)i - 0.5f) * inv_scale - 0.5f) - 1;
+    hi = (int)ceilf(((float)i + 1.5f) * inv_scale - 0.5f) + 1;
+    if (i == 0) lo = 0;           // clamped sources all map to 0
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > out - 1 ? out - 1 : hi;
+}
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy, long long lddy, float* __restrict__ dx,
+                                                           long long lddx, int h, int w, int H, int W, int C4, float sy, float sx,
+                                                           long long total) {
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C4) * 4;
+        long long q = i / C4;
+        const int ix = (int)(q % w); q /= w;
+        const int iy = (int)(q % h);
+        const long long n = q / h;
+        int ylo, yhi, xlo, xhi;
+        contrib_range(iy, 1.f / sy, H, ylo, yhi);
+        contrib_range(ix, 1.f / sx, W, xlo, xhi);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int oy = ylo; oy <= yhi; ++oy) {
+            const Lerp ly = lerp_src(oy, sy, h);
+            const float wy = (ly.i0 == iy ? ly.w0 : 0.f) + (ly.i1 == iy ? ly.w1 : 0.f);
+            if (wy == 0.f) continue;
+            const float* row = dy + ((n * H + oy) * W) * lddy + c;
+            for (int ox = xlo; ox <= xhi; ++ox) {
+                const Lerp lx = lerp_src(ox, sx, w);
+                const float wx = (lx.i0 == ix ? lx.w0 : 0.f) + (lx.i1 == ix ? lx.w1 : 0.f);
+                if (wx == 0.f) continue;
+                acc += (wy * wx) * ld4(row + (long long)ox * lddy);
+            }
+        }
+        st4(dx + ((n * h + iy) * w + ix) * lddx + c, acc);
+    }
+}
+extern "C" int sh_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int h, int w, int H, int W, int C, void* stream) {
+    if (!x || !y || N <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || ldx < C || ldy < C || (ldx & 3) || (ldy & 3)) return SH_EINVAL;
+    const long long total = (long long)N * H * W * (C / 4);
+    bilinear_fwd_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>(x, ldx, y, ldy, h, w, H, W, C / 4, (float)h / (float)H, (float)w / (float)W, total);
+    return sh_launch_status();
+}
+extern "C" int sh_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int h, int w, int H, int W, int C, void* stream) {
+    if (!dy || !dx || N <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || lddx < C || lddy < C || (lddx & 3) || (lddy & 3)) return SH_EINVAL;
+    const long long total = (long long)N * h * w * (C / 4);
+    bilinear_bwd_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>(dy, lddy, dx, lddx, h, w, H, W, C / 4, (float)h / (float)H, (float)w / (float)W, total);
+    return sh_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------ channel L2 normalise
+// F.normalize(p=2, dim=1, eps=1e-12): y = x / max(||x||, eps).  One wave per pixel row.
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ norm,
+                                                         long long M, int C) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) { const float v = xr[c]; s += v * v; }
+    s = wave_sum(s);
+    const float nrm = fmaxf(sqrtf(s), 1e-12f);
+    for (int c = lane; c < C; c += 64) y[row * C + c] = xr[c] / nrm;
+    if (lane == 0) norm[row] = nrm;
+}
+// dx = (dy - y * <dy, y>) / norm       (for norm > eps; the clamped branch gives dx = dy / eps)
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                         const float* __restrict__ norm, float* __restrict__ dx, long long M, int C) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float d = 0.f;
+    for (int c = lane; c < C; c += 64) d += dy[row * C + c] * y[row * C + c];
+    d = wave_sum(d);
+    const float nrm = norm[row];
+    const bool clamped = !(nrm > 1e-12f);
+    for (int c = lane; c < C; c += 64) {
+        const float g = dy[row * C + c];
+        dx[row * C + c] = clamped ? g / nrm : (g - y[row * C + c] * d) / nrm;
+    }
+}
+extern "C" int sh_l2norm_fwd(const float* x, float* y, float* norm, int64_t M, int C, void* stream) {
+    if (!x || !y || !norm || M <= 0 || C <= 0) return SH_EINVAL;
+    l2norm_fwd_kernel<<<(unsigned)sh_cdiv(M, 4), 256, 0, (hipStream_t)stream>>>(x, y, norm, M, C);
+    return sh_launch_status();
+}
+extern "C" int sh_l2norm_bwd(const float* dy, const float* y, const float* norm, float* dx, int64_t M, int C, void* stream) {
+    if (!dy || !y || !norm || !dx || M <= 0 || C <= 0) return SH_EINVAL;
+    l2norm_bwd_kernel<<<(unsigned)sh_cdiv(M, 4), 256, 0, (hipStream_t)stream>>>(dy, y, norm, dx, M, C);
+    return sh_launch_status();
+}

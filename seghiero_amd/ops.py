@@ -1,0 +1,476 @@
+"""Typed Python wrappers over the C ABI (include/seghiero_hip.h) for torch tensors.
+
+Everything here is plumbing: PyTorch provides device memory (the caching allocator) and the current
+HIP stream; all arithmetic happens in libseghiero_hip.so.  Activations are logical NCHW tensors whose
+memory is NHWC (``channels_last``), possibly a channel slice of a wider buffer (pixel stride ``ld``).
+"""
+import ctypes
+
+import torch
+
+from ._lib import LIB, SegHieroHipError
+
+_call = LIB.call
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_gpu(t):
+    if not t.is_cuda:
+        raise SegHieroHipError("seghiero_amd runs on the MI355X only: tensor is on %s (no CPU fallback)" % t.device)
+
+
+# ----------------------------------------------------------------------------- tensor helpers
+def new_act(n, c, h, w, device, ld=None, zero=False):
+    """Logical [n,c,h,w] fp32 tensor over NHWC memory with pixel stride ld (>= c, default c)."""
+    ld = c if ld is None else ld
+    buf = (torch.zeros if zero else torch.empty)((n, h, w, ld), device=device, dtype=torch.float32)
+    t = buf.permute(0, 3, 1, 2)
+    return t if ld == c else t[:, :c]
+
+
+def pad4(c):
+    return (c + 3) & ~3
+
+
+def pm(t):
+    """(data_ptr, ld) of a logical-NCHW tensor with NHWC memory; raises if the strides are anything else.
+
+    Element (n,c,h,w) must live at ((n*H + h)*W + w)*ld + c; strides of size-1 dims are ignored."""
+    _require_gpu(t)
+    if t.dim() != 4 or t.dtype != torch.float32:
+        raise SegHieroHipError(f"expected a 4-D fp32 tensor, got {tuple(t.shape)} {t.dtype}")
+    n, c, h, w = t.shape
+    s = t.stride()
+    if w > 1:
+        ld = s[3]
+    elif h > 1:
+        ld = s[2]
+    elif n > 1:
+        ld = s[0]
+    else:
+        ld = c
+    ok = (c == 1 or s[1] == 1) and (w == 1 or s[3] == ld) and (h == 1 or s[2] == w * ld) and \
+        (n == 1 or s[0] == h * w * ld) and ld >= c
+    if not ok:
+        raise SegHieroHipError(f"tensor is not NHWC-strided: shape {tuple(t.shape)} strides {s}")
+    return t.data_ptr(), ld
+
+
+def is_nhwc(t):
+    try:
+        pm(t)
+        return True
+    except SegHieroHipError:
+        return False
+
+
+def to_nhwc(t, cpad=None):
+    """Any-layout logical NCHW fp32 tensor -> NHWC-memory tensor (copy only when needed)."""
+    _require_gpu(t)
+    n, c, h, w = t.shape
+    cpad = c if cpad is None else cpad
+    if is_nhwc(t) and pm(t)[1] >= cpad:
+        return t
+    if t.dtype != torch.float32:
+        raise SegHieroHipError("fp32 only")
+    out = new_act(n, c, h, w, t.device, ld=cpad, zero=cpad != c)
+    if t.is_contiguous():
+        _call("sh_nchw_to_nhwc", t.data_ptr(), out.data_ptr(), n, c, h, w, cpad, _st())
+    else:
+        out.copy_(t)       # exotic strides: let torch do the gather (never on the hot path)
+    return out
+
+
+# ----------------------------------------------------------------------------- conv
+def conv_out_hw(h, w, kh, kw, stride, pad, dil):
+    return (h + 2 * pad - dil * (kh - 1) - 1) // stride + 1, (w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+
+
+def w_ohwi(weight):
+    """[O,I,KH,KW] parameter -> pointer to OHWI memory (the parameter is kept in channels_last)."""
+    o, i, kh, kw = weight.shape
+    if kh * kw == 1 or i == 1:
+        if not weight.is_contiguous() and not weight.is_contiguous(memory_format=torch.channels_last):
+            raise SegHieroHipError("weight must be dense")
+        return weight
+    if not weight.is_contiguous(memory_format=torch.channels_last):
+        raise SegHieroHipError("conv weight must be in channels_last (OHWI) memory; call module.to_native_layout()")
+    return weight
+
+
+def conv_fprop(x, weight, bias, y, partials, stride, pad, dil):
+    n, cin, h, w = x.shape
+    o, _, kh, kw = weight.shape
+    xp, ldx = pm(x)
+    yp, ldy = pm(y)
+    _call("sh_conv_fprop", xp, ldx, w_ohwi(weight).data_ptr(), None if bias is None else bias.data_ptr(), yp, ldy,
+          None if partials is None else partials.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, _st())
+
+
+def conv_dgrad(dy, weight, dx, stride, pad, dil, addend=None, mode=0):
+    n, cin, h, w = dx.shape
+    o, _, kh, kw = weight.shape
+    dyp, lddy = pm(dy)
+    dxp, lddx = pm(dx)
+    ap, lda = (None, 0) if addend is None else pm(addend)
+    _call("sh_conv_dgrad", dyp, lddy, w_ohwi(weight).data_ptr(), ap, lda, dxp, lddx, n, h, w, cin, o, kh, kw,
+          stride, pad, dil, mode, _st())
+
+
+_WS = {}
+
+
+def workspace(nbytes, device, tag="ws"):
+    """Grow-only scratch buffer per (device, tag); safe because every user runs on the one compute stream."""
+    key = (device, tag)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def conv_wgrad(x, dy, dweight, stride, pad, dil):
+    n, cin, h, w = x.shape
+    o, _, kh, kw = dweight.shape
+    need = LIB.raw("sh_conv_wgrad_workspace")(n, h, w, cin, o, kh, kw, stride, pad, dil)
+    if need < 0:
+        raise SegHieroHipError("sh_conv_wgrad_workspace rejected the geometry")
+    ws = workspace(need, x.device, "wgrad")
+    xp, ldx = pm(x)
+    dyp, lddy = pm(dy)
+    _call("sh_conv_wgrad", xp, ldx, dyp, lddy, dweight.data_ptr(), ws.data_ptr(), n, h, w, cin, o, kh, kw,
+          stride, pad, dil, _st())
+
+
+def conv_partials(m, cout, device):
+    return torch.empty((-(-m // 64), 2, cout), device=device, dtype=torch.float32)
+
+
+# ----------------------------------------------------------------------------- depthwise
+def dw_partials_rows(n, h, w):
+    return LIB.raw("sh_dw_partials")(n, h, w)
+
+
+def dwconv_fprop(x, weight, y, partials, dil):
+    n, c, h, w = x.shape
+    xp, ldx = pm(x)
+    yp, ldy = pm(y)
+    _call("sh_dwconv_fprop", xp, ldx, weight.data_ptr(), yp, ldy, None if partials is None else partials.data_ptr(),
+          n, h, w, c, dil, _st())
+
+
+def dwconv_dgrad(dy, weight, dx, dil, accumulate=False):
+    n, c, h, w = dx.shape
+    dyp, lddy = pm(dy)
+    dxp, lddx = pm(dx)
+    _call("sh_dwconv_dgrad", dyp, lddy, weight.data_ptr(), dxp, lddx, n, h, w, c, dil, int(accumulate), _st())
+
+
+def dwconv_wgrad(x, dy, dweight, dil):
+    n, c, h, w = x.shape
+    p = dw_partials_rows(n, h, w)
+    ws = workspace(p * 9 * c * 4, x.device, "dwwgrad")
+    xp, ldx = pm(x)
+    dyp, lddy = pm(dy)
+    _call("sh_dwconv_wgrad", xp, ldx, dyp, lddy, ws.data_ptr(), dweight.data_ptr(), n, h, w, c, dil, _st())
+
+
+# ----------------------------------------------------------------------------- batch norm
+def bn_finalize(partials, count, gamma, beta, eps, momentum, running_mean, running_var, c, device):
+    coefs = torch.empty((4, c), device=device, dtype=torch.float32)      # mean, invstd, scale, shift
+    _call("sh_bn_finalize", partials.data_ptr(), partials.shape[0], c, float(count),
+          None if gamma is None else gamma.data_ptr(), None if beta is None else beta.data_ptr(), eps, momentum,
+          None if running_mean is None else running_mean.data_ptr(),
+          None if running_var is None else running_var.data_ptr(),
+          coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(), coefs[3].data_ptr(), _st())
+    return coefs
+
+
+def bn_eval_coefs(gamma, beta, running_mean, running_var, eps):
+    c = running_mean.numel()
+    coefs = torch.empty((4, c), device=running_mean.device, dtype=torch.float32)
+    _call("sh_bn_eval_coefs", gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(), eps, c,
+          coefs[2].data_ptr(), coefs[3].data_ptr(), _st())
+    return coefs
+
+
+def channel_stats(y):
+    n, c, h, w = y.shape
+    m = n * h * w
+    p = LIB.raw("sh_stats_partials_count")(m)
+    partials = torch.empty((p, 2, c), device=y.device, dtype=torch.float32)
+    yp, ldy = pm(y)
+    _call("sh_channel_stats", yp, ldy, m, c, partials.data_ptr(), _st())
+    return partials
+
+
+def bn_act(y, coefs, out, relu, residual=None):
+    n, c, h, w = y.shape
+    yp, ldy = pm(y)
+    op, ldo = pm(out)
+    rp, ldr = (None, 0) if residual is None else pm(residual)
+    _call("sh_bn_act", yp, ldy, coefs[2].data_ptr(), coefs[3].data_ptr(), rp, ldr, op, ldo, n * h * w, c, int(relu), _st())
+
+
+def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None):
+    """-> (dy, dgamma, dbeta, dres).  out may be None when relu is False."""
+    n, c, h, w = y.shape
+    m = n * h * w
+    dev = y.device
+    dop, lddo = pm(dout)
+    yp, ldy = pm(y)
+    op, ldo = (None, 0) if out is None else pm(out)
+    p = LIB.raw("sh_stats_partials_count")(m)
+    partials = torch.empty((p, 2, c), device=dev, dtype=torch.float32)
+    _call("sh_bn_bwd_reduce", dop, lddo, op, ldo, yp, ldy, coefs[0].data_ptr(), coefs[1].data_ptr(), partials.data_ptr(),
+          m, c, int(relu), _st())
+    red = torch.empty((4, c), device=dev, dtype=torch.float32)           # dgamma, dbeta, c1, c2
+    _call("sh_bn_bwd_finalize", partials.data_ptr(), p, c, None if gamma is None else gamma.data_ptr(),
+          coefs[1].data_ptr(), float(m), red[0].data_ptr(), red[1].data_ptr(), red[2].data_ptr(), red[3].data_ptr(), _st())
+    ld = pad4(c) if dy_ld is None else dy_ld
+    dy = new_act(n, c, h, w, dev, ld=ld, zero=ld != c)
+    dres = new_act(n, c, h, w, dev) if want_dres else None
+    dyp, lddy = pm(dy)
+    drp, lddr = (None, 0) if dres is None else pm(dres)
+    _call("sh_bn_bwd_apply", dop, lddo, op, ldo, yp, ldy, coefs[0].data_ptr(), coefs[1].data_ptr(),
+          None if gamma is None else gamma.data_ptr(), red[2].data_ptr(), red[3].data_ptr(), dyp, lddy, drp, lddr,
+          m, c, int(relu), _st())
+    return dy, red[0], red[1], dres
+
+
+# ----------------------------------------------------------------------------- pooling / resampling
+def maxpool_fwd(x):
+    n, c, h, w = x.shape
+    xp, ldx = pm(x)
+    if ldx != c:
+        raise SegHieroHipError("maxpool needs a dense NHWC tensor")
+    y = new_act(n, c, (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1, x.device)
+    _call("sh_maxpool_fwd", xp, y.data_ptr(), n, h, w, c, _st())
+    return y
+
+
+def maxpool_bwd(x, dy):
+    n, c, h, w = x.shape
+    dyp, ld = pm(dy)
+    if ld != c:
+        raise SegHieroHipError("maxpool backward needs a dense NHWC gradient")
+    dx = new_act(n, c, h, w, x.device)
+    _call("sh_maxpool_bwd", x.data_ptr(), dyp, dx.data_ptr(), n, h, w, c, _st())
+    return dx
+
+
+def avgpool_fwd(x):
+    n, c, h, w = x.shape
+    xp, ldx = pm(x)
+    y = new_act(n, c, 1, 1, x.device)
+    _call("sh_avgpool_fwd", xp, ldx, y.data_ptr(), n, h * w, c, _st())
+    return y
+
+
+def avgpool_bwd(dy, dx, accumulate):
+    n, c, h, w = dx.shape
+    dxp, lddx = pm(dx)
+    _call("sh_avgpool_bwd", dy.data_ptr(), dxp, lddx, n, h * w, c, 1.0 / (h * w), int(accumulate), _st())
+
+
+def broadcast_hw(x, out):
+    n, c, h, w = out.shape
+    op, ldo = pm(out)
+    _call("sh_broadcast_hw", x.data_ptr(), op, ldo, n, h * w, c, _st())
+
+
+def sum_hw(dy):
+    n, c, h, w = dy.shape
+    dyp, ld = pm(dy)
+    dx = new_act(n, c, 1, 1, dy.device)
+    _call("sh_sum_hw", dyp, ld, dx.data_ptr(), n, h * w, c, _st())
+    return dx
+
+
+def bilinear_fwd(x, out):
+    n, c, h, w = x.shape
+    _, _, H, W = out.shape
+    xp, ldx = pm(x)
+    op, ldo = pm(out)
+    _call("sh_bilinear_fwd", xp, ldx, op, ldo, n, h, w, H, W, c, _st())
+
+
+def bilinear_bwd(dy, h, w):
+    n, c, H, W = dy.shape
+    dyp, ld = pm(dy)
+    dx = new_act(n, c, h, w, dy.device)
+    _call("sh_bilinear_bwd", dyp, ld, dx.data_ptr(), c, n, h, w, H, W, c, _st())
+    return dx
+
+
+def l2norm_fwd(x):
+    n, c, h, w = x.shape
+    xp, ld = pm(x)
+    if ld != c:
+        raise SegHieroHipError("l2norm needs a dense NHWC tensor")
+    y = new_act(n, c, h, w, x.device)
+    norm = torch.empty((n * h * w,), device=x.device, dtype=torch.float32)
+    _call("sh_l2norm_fwd", xp, y.data_ptr(), norm.data_ptr(), n * h * w, c, _st())
+    return y, norm
+
+
+def l2norm_bwd(dy, y, norm):
+    n, c, h, w = y.shape
+    dy = to_nhwc(dy)
+    dyp, ld = pm(dy)
+    if ld != c:
+        dy = dense_copy(dy)
+        dyp = dy.data_ptr()
+    dx = new_act(n, c, h, w, y.device)
+    _call("sh_l2norm_bwd", dyp, y.data_ptr(), norm.data_ptr(), dx.data_ptr(), n * h * w, c, _st())
+    return dx
+
+
+def dense_copy(t, ld=None):
+    """Copy a (possibly channel-sliced) NHWC tensor into a fresh buffer with pixel stride ld (padding zeroed)."""
+    n, c, h, w = t.shape
+    ld = c if ld is None else ld
+    out = new_act(n, c, h, w, t.device, ld=ld, zero=ld != c)
+    ones = torch.ones((2, c), device=t.device, dtype=torch.float32)
+    ones[1].zero_()
+    tp, ldt = pm(t)
+    op, ldo = pm(out)
+    _call("sh_bn_act", tp, ldt, ones[0].data_ptr(), ones[1].data_ptr(), None, 0, op, ldo, n * h * w, c, 0, _st())
+    return out
+
+
+def fill_(t, v):
+    _call("sh_fill", t.data_ptr(), float(v), t.numel(), _st())
+
+
+# ----------------------------------------------------------------------------- labels / losses
+def labels_u8(label):
+    _require_gpu(label)
+    if label.dtype == torch.uint8:
+        return label.contiguous()
+    if label.dtype != torch.int64:
+        raise SegHieroHipError("labels must be int64 or uint8")
+    label = label.contiguous()
+    out = torch.empty(label.shape, device=label.device, dtype=torch.uint8)
+    _call("sh_labels_to_u8", label.data_ptr(), out.data_ptr(), label.numel(), _st())
+    return out
+
+
+def _buckets(hiera_index):
+    flat = [int(v) for pair in hiera_index for v in (pair[0], pair[-1])]
+    return (ctypes.c_int * max(len(flat), 1))(*flat)
+
+
+def hiera2_fwd(logits, labels8, n_fine, hiera_index, want_coarse=False):
+    """-> (loss[1] f32, sums[8] f64, coarse u8 or None)."""
+    n, c, h, w = logits.shape
+    _, H, W = labels8.shape
+    lp, ldl = pm(logits)
+    dev = logits.device
+    nblk = LIB.raw("sh_hiera2_partials")(n, H, W)
+    partials = torch.empty((nblk, 8), device=dev, dtype=torch.float32)
+    sums = torch.empty((8,), device=dev, dtype=torch.float64)
+    loss = torch.empty((1,), device=dev, dtype=torch.float32)
+    coarse = torch.empty_like(labels8) if want_coarse else None
+    _call("sh_hiera2_loss_fwd", lp, ldl, labels8.data_ptr(), _buckets(hiera_index), n_fine, len(hiera_index),
+          sums.data_ptr(), loss.data_ptr(), partials.data_ptr(), None if coarse is None else coarse.data_ptr(),
+          n, h, w, H, W, _st())
+    return loss, sums, coarse
+
+
+def hiera2_bwd(logits, labels8, n_fine, hiera_index, sums, gscale_dev, gscale):
+    n, c, h, w = logits.shape
+    _, H, W = labels8.shape
+    lp, ldl = pm(logits)
+    d = new_act(n, c, h, w, logits.device, ld=pad4(c))
+    dp, ldd = pm(d)
+    _call("sh_hiera2_loss_bwd", lp, ldl, labels8.data_ptr(), _buckets(hiera_index), n_fine, len(hiera_index),
+          sums.data_ptr(), None if gscale_dev is None else gscale_dev.data_ptr(), float(gscale), dp, ldd,
+          n, h, w, H, W, _st())
+    return d
+
+
+def ce_fwd(logits, labels8):
+    n, c, h, w = logits.shape
+    _, H, W = labels8.shape
+    lp, ldl = pm(logits)
+    dev = logits.device
+    nblk = LIB.raw("sh_hiera2_partials")(n, H, W)
+    partials = torch.empty((nblk, 8), device=dev, dtype=torch.float32)
+    sums = torch.empty((2,), device=dev, dtype=torch.float64)
+    loss = torch.empty((1,), device=dev, dtype=torch.float32)
+    _call("sh_ce_loss_fwd", lp, ldl, labels8.data_ptr(), c, sums.data_ptr(), loss.data_ptr(), partials.data_ptr(),
+          n, h, w, H, W, _st())
+    return loss, sums
+
+
+def ce_bwd(logits, labels8, sums, gscale_dev, gscale):
+    n, c, h, w = logits.shape
+    _, H, W = labels8.shape
+    lp, ldl = pm(logits)
+    d = new_act(n, c, h, w, logits.device, ld=pad4(c))
+    dp, ldd = pm(d)
+    _call("sh_ce_loss_bwd", lp, ldl, labels8.data_ptr(), c, sums.data_ptr(),
+          None if gscale_dev is None else gscale_dev.data_ptr(), float(gscale), dp, ldd, n, h, w, H, W, _st())
+    return d
+
+
+def triplet_fwd(emb, labels8, masks, anchor_ok, max_triplet=200, margin=0.6):
+    """emb: dense NHWC [n,d,h,w].  -> (out[2] f32 = {loss, class_count}, workspace)."""
+    n, d, h, w = emb.shape
+    _, H, W = labels8.shape
+    ep, ld = pm(emb)
+    if ld != d:
+        raise SegHieroHipError("triplet needs a dense NHWC embedding")
+    need = LIB.raw("sh_triplet_workspace")(n * h * w)
+    ws = torch.empty((need,), device=emb.device, dtype=torch.uint8)
+    out = torch.empty((2,), device=emb.device, dtype=torch.float32)
+    _call("sh_triplet_fwd", ep, labels8.data_ptr(), masks.data_ptr(), anchor_ok.data_ptr(), max_triplet, margin,
+          out.data_ptr(), ws.data_ptr(), n, h, w, d, H, W, _st())
+    return out, ws
+
+
+def triplet_bwd(emb, ws, out, gscale_dev, gscale):
+    n, d, h, w = emb.shape
+    demb = new_act(n, d, h, w, emb.device, zero=True)
+    _call("sh_triplet_bwd", emb.data_ptr(), ws.data_ptr(), out.data_ptr(),
+          None if gscale_dev is None else gscale_dev.data_ptr(), float(gscale), demb.data_ptr(), n, h, w, d, _st())
+    return demb
+
+
+def combine_loss(main, trip_out, ready_count, factor, loss_weight):
+    out = torch.empty((1,), device=main.device, dtype=torch.float32)
+    _call("sh_combine_loss", main.data_ptr(), trip_out.data_ptr(), None if ready_count is None else ready_count.data_ptr(),
+          float(factor), float(loss_weight), out.data_ptr(), _st())
+    return out
+
+
+def pixel_metrics(logits, labels8, n_fine, counts=None):
+    n, c, h, w = logits.shape
+    _, H, W = labels8.shape
+    lp, ldl = pm(logits)
+    if counts is None:
+        counts = torch.zeros((2 + n_fine * n_fine,), device=logits.device, dtype=torch.int64)
+    _call("sh_pixel_metrics", lp, ldl, labels8.data_ptr(), n_fine, counts.data_ptr(), n, h, w, H, W, _st())
+    return counts
+
+
+# ----------------------------------------------------------------------------- optimizer
+SGD_MAX = 48
+
+
+def sgd_step(params, grads, bufs, lr, momentum, weight_decay, first_step, gscale=1.0):
+    st = _st()
+    for i in range(0, len(params), SGD_MAX):
+        ps, gs, vs = params[i:i + SGD_MAX], grads[i:i + SGD_MAX], bufs[i:i + SGD_MAX]
+        k = len(ps)
+        wa = (ctypes.c_void_p * k)(*[p.data_ptr() for p in ps])
+        ga = (ctypes.c_void_p * k)(*[g.data_ptr() for g in gs])
+        va = (ctypes.c_void_p * k)(*[v.data_ptr() for v in vs])
+        na = (ctypes.c_longlong * k)(*[p.numel() for p in ps])
+        _call("sh_sgd_step", k, wa, ga, va, na, float(lr), float(momentum), float(weight_decay), int(first_step),
+              float(gscale), st)

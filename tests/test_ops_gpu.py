@@ -1,0 +1,258 @@
+"""GPU parity of every C-ABI kernel against plain fp32 torch CPU ops of the same reference op (tolerances
+stated per test; integer/index results bit-exact).  Calls go through the C ABI via seghiero_amd.ops."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from seghiero_amd import ops as o
+    return o
+
+
+DEV = "cuda:0"
+
+
+def nhwc(t):
+    """CPU NCHW tensor -> GPU logical-NCHW tensor with NHWC memory."""
+    return t.to(DEV).contiguous(memory_format=torch.channels_last)
+
+
+def wl(t):
+    return t.to(DEV).contiguous(memory_format=torch.channels_last)
+
+
+def close(a, b, rtol, atol, msg=""):
+    np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=rtol, atol=atol, err_msg=msg)
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, k, stride, pad, dil
+    (2, 16, 16, 64, 64, 1, 1, 0, 1),
+    (2, 16, 16, 64, 256, 1, 1, 0, 1),
+    (2, 17, 13, 32, 48, 3, 1, 1, 1),
+    (2, 16, 16, 128, 128, 3, 2, 1, 1),
+    (2, 15, 15, 64, 128, 1, 2, 0, 1),
+    (1, 32, 32, 4, 64, 7, 2, 3, 1),       # stem (Cin padded 3->4)
+    (2, 8, 8, 560, 512, 1, 1, 0, 1),      # K tail: 560 = 17.5 * 32
+    (3, 9, 7, 16, 13, 1, 1, 0, 1),        # Cout not a multiple of 4 (cls_seg)
+    (2, 12, 12, 32, 32, 3, 1, 12, 12),    # dilated dense conv
+    (16, 1, 1, 64, 32, 1, 1, 0, 1),       # image-pool conv: M = batch
+    (2, 40, 40, 64, 160, 3, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fprop_dgrad_wgrad(ops, case):
+    n, h, w, cin, cout, k, s, p, d = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, wt, bias, s, p, d)
+    ho, wo = ref.shape[2:]
+    xg, wg = nhwc(x), wl(wt)
+    ldy = ops.pad4(cout)
+    y = ops.new_act(n, cout, ho, wo, DEV, ld=ldy, zero=True)
+    part = ops.conv_partials(n * ho * wo, cout, DEV)
+    ops.conv_fprop(xg, wg, bias.to(DEV), y, None, s, p, d)
+    close(y, ref, 2e-5, 2e-5, "fprop+bias")
+    y2 = ops.new_act(n, cout, ho, wo, DEV, ld=ldy, zero=True)
+    ops.conv_fprop(xg, wg, None, y2, part, s, p, d)
+    ref_nb = F.conv2d(x, wt, None, s, p, d)
+    close(y2, ref_nb, 2e-5, 2e-5, "fprop")
+    # BN statistic partials: sum and sum of squares per channel
+    close(part[:, 0].sum(0), ref_nb.sum((0, 2, 3)), 1e-4, 1e-3, "stat sum")
+    close(part[:, 1].sum(0), (ref_nb * ref_nb).sum((0, 2, 3)), 1e-4, 1e-3, "stat sumsq")
+    # backward
+    dy = torch.randn(ref.shape, generator=g)
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, s, p, d).backward(dy)
+    dyg = ops.new_act(n, cout, ho, wo, DEV, ld=ldy, zero=True)
+    dyg.copy_(dy.to(DEV))
+    dx = ops.new_act(n, cin, h, w, DEV)
+    ops.conv_dgrad(dyg, wg, dx, s, p, d)
+    close(dx, xr.grad, 1e-4, 1e-4, "dgrad")
+    add = torch.randn(x.shape, generator=g)
+    dx2 = ops.new_act(n, cin, h, w, DEV)
+    ops.conv_dgrad(dyg, wg, dx2, s, p, d, addend=nhwc(add))
+    close(dx2, xr.grad + add, 1e-4, 1e-4, "dgrad+addend")
+    if k == 1 and p == 0:
+        dx3 = nhwc(add.clone())
+        ops.conv_dgrad(dyg, wg, dx3, s, p, d, mode=1)
+        close(dx3, xr.grad + add, 1e-4, 1e-4, "dgrad scatter/accumulate")
+    dw = torch.empty_like(wg)
+    ops.conv_wgrad(xg, dyg, dw, s, p, d)
+    close(dw, wr.grad, 2e-4, 2e-4 * float(wr.grad.abs().max()), "wgrad")
+
+
+def test_conv_reads_and_writes_channel_slices(ops):
+    g = torch.Generator().manual_seed(5)
+    big_in = nhwc(torch.randn(2, 96, 10, 10, generator=g))
+    big_out = ops.new_act(2, 80, 10, 10, DEV, zero=True)
+    wt = torch.randn(32, 64, 1, 1, generator=g) / 8
+    ops.conv_fprop(big_in[:, 32:96], wl(wt), None, big_out[:, 16:48], None, 1, 0, 1)
+    ref = F.conv2d(big_in[:, 32:96].cpu(), wt)
+    close(big_out[:, 16:48], ref, 2e-5, 2e-5)
+    assert float(big_out[:, :16].abs().max()) == 0 and float(big_out[:, 48:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("shape,dil", [((2, 64, 16, 16), 1), ((2, 64, 16, 16), 12), ((2, 32, 16, 16), 24),
+                                       ((2, 560, 9, 11), 1), ((1, 8, 5, 7), 2)])
+def test_dwconv(ops, shape, dil):
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(c + dil)
+    x = torch.randn(shape, generator=g).requires_grad_(True)
+    wt = (torch.randn(c, 1, 3, 3, generator=g) / 3).requires_grad_(True)
+    ref = F.conv2d(x, wt, None, 1, dil, dil, groups=c)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    xg, wg = nhwc(x.detach()), wt.detach().to(DEV).contiguous()
+    y = ops.new_act(n, c, h, w, DEV)
+    part = torch.empty((ops.dw_partials_rows(n, h, w), 2, c), device=DEV)
+    ops.dwconv_fprop(xg, wg, y, part, dil)
+    close(y, ref, 1e-5, 1e-5)
+    close(part[:, 0].sum(0), ref.detach().sum((0, 2, 3)), 1e-4, 1e-3)
+    close(part[:, 1].sum(0), (ref.detach() ** 2).sum((0, 2, 3)), 1e-4, 1e-3)
+    dx = ops.new_act(n, c, h, w, DEV)
+    ops.dwconv_dgrad(nhwc(dy), wg, dx, dil)
+    close(dx, x.grad, 1e-5, 1e-5)
+    ops.dwconv_dgrad(nhwc(dy), wg, dx, dil, accumulate=True)
+    close(dx, 2 * x.grad, 1e-5, 2e-5)
+    dw = torch.empty_like(wg)
+    ops.dwconv_wgrad(xg, nhwc(dy), dw, dil)
+    close(dw, wt.grad, 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 12, 12), (2, 9, 7, 5), (16, 32, 1, 1)])
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False)])
+def test_batchnorm_train_fwd_bwd(ops, shape, relu, res):
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(c)
+    y = (torch.randn(shape, generator=g) * 2 + 0.5).requires_grad_(True)
+    gamma = (0.5 + torch.rand(c, generator=g)).requires_grad_(True)
+    beta = (0.2 * torch.randn(c, generator=g)).requires_grad_(True)
+    resid = torch.randn(shape, generator=g).requires_grad_(True) if res else None
+    rm, rv = torch.zeros(c), torch.ones(c)
+    ref = F.batch_norm(y, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    if res:
+        ref = ref + resid
+    if relu:
+        ref = F.relu(ref)
+    dout = torch.randn(shape, generator=g)
+    ref.backward(dout)
+    yg = nhwc(y.detach())
+    part = ops.channel_stats(yg)
+    rmg, rvg = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    coefs = ops.bn_finalize(part, n * h * w, gamma.detach().to(DEV), beta.detach().to(DEV), 1e-5, 0.1, rmg, rvg, c, DEV)
+    out = ops.new_act(n, c, h, w, DEV)
+    ops.bn_act(yg, coefs, out, relu, None if not res else nhwc(resid.detach()))
+    close(out, ref, 1e-5, 2e-5, "bn fwd")
+    close(rmg, rm, 1e-5, 1e-6, "running_mean")
+    close(rvg, rv, 1e-5, 1e-6, "running_var")
+    dy, dgamma, dbeta, dres = ops.bn_backward(nhwc(dout), out if relu else None, yg, coefs, gamma.detach().to(DEV), relu, want_dres=res)
+    close(dy, y.grad, 1e-4, 2e-5, "bn dy")
+    close(dgamma, gamma.grad, 1e-4, 1e-4, "dgamma")
+    close(dbeta, beta.grad, 1e-4, 1e-4, "dbeta")
+    if res:
+        close(dres, resid.grad, 1e-6, 1e-6, "dres")
+
+
+def test_bn_eval_coefs(ops):
+    g = torch.Generator().manual_seed(1)
+    c = 24
+    y = torch.randn(2, c, 5, 5, generator=g)
+    gamma, beta, rm, rv = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g), torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5
+    ref = F.batch_norm(y, rm, rv, gamma, beta, False, 0.1, 1e-5)
+    coefs = ops.bn_eval_coefs(gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV), 1e-5)
+    out = ops.new_act(2, c, 5, 5, DEV)
+    ops.bn_act(nhwc(y), coefs, out, False)
+    close(out, ref, 1e-5, 1e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 32, 32), (2, 8, 15, 17)])
+def test_maxpool(ops, shape):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(shape, generator=g)
+    x[0, :, 2:6, 2:6] = 1.0          # ties: first max in row-major order takes the gradient
+    x.requires_grad_(True)
+    ref = F.max_pool2d(x, 3, 2, 1)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    xg = nhwc(x.detach())
+    y = ops.maxpool_fwd(xg)
+    assert torch.equal(y.cpu(), ref.detach())
+    dx = ops.maxpool_bwd(xg, nhwc(dy))
+    close(dx, x.grad, 1e-6, 1e-6)
+
+
+def test_avgpool_broadcast(ops):
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(3, 40, 16, 16, generator=g)
+    y = ops.avgpool_fwd(nhwc(x))
+    close(y, F.adaptive_avg_pool2d(x, 1), 1e-6, 1e-6)
+    out = ops.new_act(3, 100, 6, 5, DEV, zero=True)
+    ops.broadcast_hw(y, out[:, 20:60])
+    close(out[:, 20:60], F.interpolate(F.adaptive_avg_pool2d(x, 1), size=(6, 5), mode="bilinear", align_corners=False), 1e-6, 1e-6)
+    dy = torch.randn(3, 40, 6, 5, generator=g)
+    close(ops.sum_hw(nhwc(dy)), dy.sum((2, 3), keepdim=True), 1e-5, 1e-5)
+    dx = nhwc(x.clone())
+    ops.avgpool_bwd(y, dx, accumulate=True)
+    close(dx, x + F.adaptive_avg_pool2d(x, 1) / 256, 1e-6, 1e-6)
+
+
+@pytest.mark.parametrize("src,dst", [((16, 16), (128, 128)), ((3, 2), (19, 13)), ((4, 4), (32, 32)), ((8, 8), (8, 8)), ((10, 12), (5, 6))])
+def test_bilinear(ops, src, dst):
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 16, *src, generator=g).requires_grad_(True)
+    ref = F.interpolate(x, size=dst, mode="bilinear", align_corners=False)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    out = ops.new_act(2, 16, *dst, DEV)
+    ops.bilinear_fwd(nhwc(x.detach()), out)
+    close(out, ref, 1e-5, 1e-6)
+    dx = ops.bilinear_bwd(nhwc(dy), *src)
+    close(dx, x.grad, 1e-5, 1e-5)
+
+
+def test_l2norm(ops):
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 40, 5, 6, generator=g).requires_grad_(True)
+    ref = F.normalize(x, p=2, dim=1)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    y, norm = ops.l2norm_fwd(nhwc(x.detach()))
+    close(y, ref, 1e-6, 1e-6)
+    close(ops.l2norm_bwd(nhwc(dy), y, norm), x.grad, 1e-5, 1e-6)
+
+
+def test_layout_roundtrip(ops):
+    x = torch.randn(2, 3, 9, 7)
+    y = ops.to_nhwc(x.to(DEV), cpad=4)
+    assert ops.pm(y)[1] == 4
+    assert torch.equal(y.cpu(), x)
+
+
+def test_sgd(ops):
+    g = torch.Generator().manual_seed(8)
+    shapes = [(7,), (64, 3, 7, 7), (13, 512, 1, 1), (1001,)] * 20          # 80 tensors -> two launches
+    ps = [torch.randn(s, generator=g) for s in shapes]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    opt = torch.optim.SGD(ref, lr=0.05, momentum=0.9, weight_decay=1e-4)
+    gp = [p.to(DEV) for p in ps]
+    bufs = [torch.zeros_like(p) for p in gp]
+    for step in range(3):
+        grads = [torch.randn(s, generator=g) for s in shapes]
+        for r, gr in zip(ref, grads):
+            r.grad = gr.clone()
+        opt.step()
+        ops.sgd_step(gp, [gr.to(DEV) for gr in grads], bufs, 0.05, 0.9, 1e-4, step == 0)
+    for a, b in zip(gp, ref):
+        close(a, b, 1e-6, 1e-6)
