@@ -1,0 +1,211 @@
+"""ResNetBackbone -- drop-in for reference ``models/backbone/resnet.py:6-75`` on the HIP kernels.
+
+Same constructor (``depth``, ``pretrained``), same attribute names (``stem_conv, stem_bn, stem_relu, stem_pool,
+layer1..layer4``) and therefore the same state_dict keys / shapes as the reference (which takes them from
+torchvision's ResNet), same forward contract ``x[B,3,H,W] -> (c1, c2, c3, c4)`` at strides 4/8/16/32.
+The torch.nn modules below only hold parameters and buffers; the forward runs the implicit-GEMM conv, BN and
+pooling kernels and the backward is hand-scheduled (``_BackboneFn``), so autograd sees ONE node for the trunk.
+
+Superset: depth 18/34/152 are accepted too (README.md:95 promises them; BASELINE config 1 needs 18).
+``pretrained=True`` is a network download in the reference (``resnet.py:35,37``); there is no network here, so it
+warns and keeps the random initialisation (load weights with ``load_state_dict``).
+"""
+import warnings
+
+import torch
+import torch.nn as nn
+
+from . import layers as L
+from . import ops
+from ._lib import SegHieroHipError
+
+_SPECS = {18: ("basic", (2, 2, 2, 2)), 34: ("basic", (3, 4, 6, 3)), 50: ("bottleneck", (3, 4, 6, 3)),
+          101: ("bottleneck", (3, 4, 23, 3)), 152: ("bottleneck", (3, 8, 36, 3))}
+
+
+def _conv(cin, cout, k, stride=1, pad=0):
+    return nn.Conv2d(cin, cout, k, stride=stride, padding=pad, bias=False)
+
+
+class _Block(nn.Module):
+    """Parameter container for one residual block (torchvision naming: conv1/bn1/.../downsample)."""
+
+    def __init__(self, kind, cin, width, stride, downsample):
+        super().__init__()
+        self.kind = kind
+        if kind == "basic":
+            self.conv1, self.bn1 = _conv(cin, width, 3, stride, 1), nn.BatchNorm2d(width)
+            self.relu = nn.ReLU(inplace=True)
+            self.conv2, self.bn2 = _conv(width, width, 3, 1, 1), nn.BatchNorm2d(width)
+        else:
+            self.conv1, self.bn1 = _conv(cin, width, 1), nn.BatchNorm2d(width)
+            self.conv2, self.bn2 = _conv(width, width, 3, stride, 1), nn.BatchNorm2d(width)
+            self.conv3, self.bn3 = _conv(width, width * 4, 1), nn.BatchNorm2d(width * 4)
+            self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def chain(self):
+        if self.kind == "basic":
+            return [(self.conv1, self.bn1), (self.conv2, self.bn2)]
+        return [(self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)]
+
+    def forward(self, x):
+        raise SegHieroHipError("blocks run inside ResNetBackbone.forward (hand-scheduled HIP path)")
+
+
+def _stage(kind, cin, width, n, stride):
+    exp = 1 if kind == "basic" else 4
+    cout = width * exp
+    ds = None
+    if stride != 1 or cin != cout:
+        ds = nn.Sequential(_conv(cin, cout, 1, stride), nn.BatchNorm2d(cout))
+    blocks = [_Block(kind, cin, width, stride, ds)] + [_Block(kind, cout, width, 1, None) for _ in range(n - 1)]
+    return nn.Sequential(*blocks), cout
+
+
+# ----------------------------------------------------------------------------- hand-scheduled fwd / bwd
+def _block_fwd(blk, x, training):
+    chain = blk.chain()
+    recs = []
+    idt, ds_rec = x, None
+    if blk.downsample is not None:
+        dconv, dbn = blk.downsample[0], blk.downsample[1]
+        idt, ds_rec = L.cba_fwd(x, dconv.weight, L.conv_geom(dconv), dbn, False, training)
+    h = x
+    for i, (conv, bn) in enumerate(chain):
+        last = i == len(chain) - 1
+        h, rec = L.cba_fwd(h, conv.weight, L.conv_geom(conv), bn, True, training, residual=idt if last else None)
+        recs.append(rec)
+    return h, (recs, ds_rec)
+
+
+def _block_bwd(blk, saved, dout, gm):
+    recs, ds_rec = saved
+    chain = blk.chain()
+    # last conv: g = dout * relu-mask feeds BN backward AND (as dres) the identity / downsample path
+    conv, bn = chain[-1]
+    d, dw, dg, db, dres = L.cba_bwd(recs[-1], bn, dout, need_dx=True, want_dres=True)
+    gm.put(conv.weight, dw); gm.put(bn.weight, dg); gm.put(bn.bias, db)
+    for i in range(len(chain) - 2, -1, -1):
+        conv, bn = chain[i]
+        first = i == 0
+        addend = dres if (first and ds_rec is None) else None      # identity path summed in the dgrad epilogue
+        d, dw, dg, db, _ = L.cba_bwd(recs[i], bn, d, need_dx=True, addend=addend)
+        gm.put(conv.weight, dw); gm.put(bn.weight, dg); gm.put(bn.bias, db)
+    if ds_rec is not None:
+        dconv, dbn = blk.downsample[0], blk.downsample[1]
+        if dconv.stride[0] > 1:
+            _, dw, dg, db, _ = L.cba_bwd(ds_rec, dbn, dres, scatter_into=d)          # accumulate at strided pixels
+        else:
+            d, dw, dg, db, _ = L.cba_bwd(ds_rec, dbn, dres, need_dx=True, addend=d)
+        gm.put(dconv.weight, dw); gm.put(dbn.weight, dg); gm.put(dbn.bias, db)
+    return d
+
+
+def _all_bns(mod):
+    return [m for m in mod.modules() if isinstance(m, nn.BatchNorm2d)]
+
+
+class _BackboneFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, x, *params):
+        training = mod.training
+        x4 = ops.to_nhwc(x, cpad=4)                                    # NHWC, 3 -> 4 channels (zero)
+        w = mod.stem_conv.weight                                       # [64,3,7,7] -> OHWI with I padded to 4
+        if not w.is_contiguous():
+            raise SegHieroHipError("stem_conv.weight must be contiguous")
+        wpad = ops.new_act(w.shape[0], 4, 7, 7, w.device, zero=True)
+        ops._call("sh_nchw_to_nhwc", w.data_ptr(), wpad.data_ptr(), w.shape[0], 3, 7, 7, 4, ops._st())
+        s_out, s_rec = L.cba_fwd(x4, wpad, L.conv_geom(mod.stem_conv), mod.stem_bn, True, training)
+        pooled = ops.maxpool_fwd(s_out)
+        h = pooled
+        saved, outs = [], []
+        for layer in (mod.layer1, mod.layer2, mod.layer3, mod.layer4):
+            for blk in layer:
+                h, sv = _block_fwd(blk, h, training)
+                saved.append(sv)
+            outs.append(h)
+        if training:
+            L.bump_bn_counters(_all_bns(mod))
+        ctx.mod, ctx.saved, ctx.stem = mod, saved, (x4, wpad, s_rec, s_out)
+        ctx.training = training
+        ctx.params = params
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        if not ctx.training:
+            raise SegHieroHipError("backward through eval-mode BatchNorm is not on the SegHiero hot path")
+        mod, saved = ctx.mod, ctx.saved
+        gm = L.GradMap()
+        layers = [mod.layer1, mod.layer2, mod.layer3, mod.layer4]
+        blocks = [(li, blk) for li, layer in enumerate(layers) for blk in layer]
+        last_of_layer = {}
+        for idx, (li, _) in enumerate(blocks):
+            last_of_layer[li] = idx
+        d = None
+        for idx in range(len(blocks) - 1, -1, -1):
+            li, blk = blocks[idx]
+            if last_of_layer[li] == idx and douts[li] is not None:       # this block's output is c_{li+1}
+                g = L.grad_as_nhwc_padded(douts[li], douts[li].shape[1])
+                if d is None:
+                    d = g
+                else:
+                    ops._call("sh_axpy", d.data_ptr(), _dense(g).data_ptr(), 1.0, d.numel(), ops._st())
+            if d is None:
+                continue
+            d = _block_bwd(blk, saved[idx], d, gm)
+        if d is not None:
+            x4, wpad, s_rec, s_out = ctx.stem
+            dpool = ops.maxpool_bwd(s_out, d)
+            _, dwp, dg, db, _ = L.cba_bwd(s_rec, mod.stem_bn, dpool, need_dx=False)
+            dw = torch.empty_like(mod.stem_conv.weight)
+            ops._call("sh_nhwc_to_nchw", dwp.data_ptr(), dw.data_ptr(), dw.shape[0], 3, 7, 7, 4, ops._st())
+            gm.put(mod.stem_conv.weight, dw); gm.put(mod.stem_bn.weight, dg); gm.put(mod.stem_bn.bias, db)
+        ctx.saved = ctx.stem = None
+        return (None, None) + gm.ordered(ctx.params)
+
+
+def _dense(t):
+    return t if ops.pm(t)[1] == t.shape[1] else ops.dense_copy(t)
+
+
+class ResNetBackbone(nn.Module):
+    def __init__(self, depth: int = 101, pretrained: bool = True):
+        super().__init__()
+        if depth not in _SPECS:
+            raise ValueError("`depth` must be 50 or 101 (this build also accepts 18, 34, 152)")
+        if pretrained:
+            warnings.warn("pretrained=True needs a network download (reference resnet.py:35,37); offline build keeps "
+                          "the random initialisation -- load weights with load_state_dict()", stacklevel=2)
+        kind, counts = _SPECS[depth]
+        self.stem_conv = _conv(3, 64, 7, 2, 3)
+        self.stem_bn = nn.BatchNorm2d(64)
+        self.stem_relu = nn.ReLU(inplace=True)
+        self.stem_pool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        c = 64
+        self.layer1, c = _stage(kind, c, 64, counts[0], 1)
+        self.layer2, c = _stage(kind, c, 128, counts[1], 2)
+        self.layer3, c = _stage(kind, c, 256, counts[2], 2)
+        self.layer4, c = _stage(kind, c, 512, counts[3], 2)
+        exp = 1 if kind == "basic" else 4
+        self.out_channels = (64 * exp, 128 * exp, 256 * exp, 512 * exp)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        L.to_native_layout(self)
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        L.to_native_layout(self)
+        return out
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        L.to_native_layout(self)
+        return out
+
+    def forward(self, x: torch.Tensor):
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("expected input of shape [B, 3, H, W]")
+        return _BackboneFn.apply(self, x, *self.parameters())

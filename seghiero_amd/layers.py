@@ -1,0 +1,172 @@
+"""Forward / backward building blocks shared by the backbone and the head.
+
+These are plain functions over torch tensors (device memory) that launch the HIP kernels through ``ops``; the
+``torch.nn.Conv2d`` / ``BatchNorm2d`` objects they receive are used purely as parameter / buffer containers (so that
+state_dict keys and shapes equal the reference's) -- their ``forward`` is never called.
+
+The backward pass is scheduled by hand (``backbone._BackboneFn``, ``head._HeadFn``) instead of being traced by autograd:
+that is what allows residual / concat gradients to be summed inside the dgrad epilogue, BN statistics to be produced by
+the conv epilogue, and concat buffers to be written in place.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def conv_geom(conv):
+    return conv.stride[0], conv.padding[0], conv.dilation[0]
+
+
+def to_native_layout(module):
+    """Put every dense KxK conv weight of `module` into channels_last (OHWI) memory, in place.  1x1 / depthwise /
+    the 3-channel stem weight are layout-neutral or handled separately.  Idempotent; call after .to(device) or
+    load_state_dict (both preserve it)."""
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d) and m.groups == 1 and m.kernel_size != (1, 1) and m.in_channels % 4 == 0:
+            if not m.weight.data.is_contiguous(memory_format=torch.channels_last):
+                m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+    return module
+
+
+def bump_bn_counters(bns):
+    """num_batches_tracked += 1 for all train-mode BN layers of one forward, in one launch."""
+    ctrs = [b.num_batches_tracked for b in bns if b.num_batches_tracked is not None]
+    if ctrs:
+        torch._foreach_add_(ctrs, 1)
+
+
+# ----------------------------------------------------------------------------- conv + BN (+res) (+ReLU)
+class CBARec:
+    __slots__ = ("x", "y", "out", "coefs", "relu", "geom", "weight")
+
+
+def _bn_coefs(bn, partials, count, training, c, device):
+    if training:
+        mom = 0.1 if bn.momentum is None else bn.momentum
+        return ops.bn_finalize(partials, count, bn.weight, bn.bias, bn.eps, mom, bn.running_mean, bn.running_var, c, device)
+    return ops.bn_eval_coefs(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+
+
+def cba_fwd(x, weight, geom, bn, relu, training, residual=None, out=None):
+    """out = [relu](BN(conv(x, weight)) [+ residual]); `out` may be a channel slice of a concat buffer."""
+    s, p, d = geom
+    n, _, h, w = x.shape
+    o, _, kh, kw = weight.shape
+    ho, wo = ops.conv_out_hw(h, w, kh, kw, s, p, d)
+    ld = ops.pad4(o)
+    y = ops.new_act(n, o, ho, wo, x.device, ld=ld, zero=ld != o)
+    m = n * ho * wo
+    partials = ops.conv_partials(m, o, x.device) if training else None
+    ops.conv_fprop(x, weight, None, y, partials, s, p, d)
+    coefs = _bn_coefs(bn, partials, m, training, o, x.device)
+    if out is None:
+        out = ops.new_act(n, o, ho, wo, x.device, ld=ld, zero=ld != o)
+    ops.bn_act(y, coefs, out, relu, residual)
+    rec = CBARec()
+    rec.x, rec.y, rec.out, rec.coefs, rec.relu, rec.geom, rec.weight = x, y, out, coefs, relu, geom, weight
+    return out, rec
+
+
+def cba_bwd(rec, bn, dout, need_dx=True, addend=None, want_dres=False, scatter_into=None):
+    """-> (dx, dweight, dgamma, dbeta, dres).  `addend` is summed into dx by the dgrad epilogue;
+    `scatter_into` (1x1 strided convs) accumulates the result into an existing dx instead."""
+    s, p, d = rec.geom
+    dy, dgamma, dbeta, dres = ops.bn_backward(dout, rec.out if rec.relu else None, rec.y, rec.coefs, bn.weight,
+                                              rec.relu, want_dres)
+    dw = torch.empty_like(rec.weight)
+    ops.conv_wgrad(rec.x, dy, dw, s, p, d)
+    dx = None
+    if scatter_into is not None:
+        ops.conv_dgrad(dy, rec.weight, scatter_into, s, p, d, mode=1)
+        dx = scatter_into
+    elif need_dx:
+        n, c, h, w = rec.x.shape
+        dx = ops.new_act(n, c, h, w, rec.x.device)
+        ops.conv_dgrad(dy, rec.weight, dx, s, p, d, addend=addend)
+    return dx, dw, dgamma, dbeta, dres
+
+
+# ----------------------------------------------------------------------------- depthwise 3x3 + BN + ReLU
+class DWRec:
+    __slots__ = ("x", "y", "out", "coefs", "dil", "weight")
+
+
+def dw_fwd(x, weight, dil, bn, training):
+    n, c, h, w = x.shape
+    y = ops.new_act(n, c, h, w, x.device)
+    partials = torch.empty((ops.dw_partials_rows(n, h, w), 2, c), device=x.device) if training else None
+    ops.dwconv_fprop(x, weight, y, partials, dil)
+    coefs = _bn_coefs(bn, partials, n * h * w, training, c, x.device)
+    out = ops.new_act(n, c, h, w, x.device)
+    ops.bn_act(y, coefs, out, True)
+    rec = DWRec()
+    rec.x, rec.y, rec.out, rec.coefs, rec.dil, rec.weight = x, y, out, coefs, dil, weight
+    return out, rec
+
+
+def dw_bwd(rec, bn, dout, dx_accumulate_into=None):
+    """-> (dx, dweight, dgamma, dbeta); with dx_accumulate_into the input gradient is added into that tensor."""
+    dy, dgamma, dbeta, _ = ops.bn_backward(dout, rec.out, rec.y, rec.coefs, bn.weight, True)
+    dw = torch.empty_like(rec.weight)
+    ops.dwconv_wgrad(rec.x, dy, dw, rec.dil)
+    if dx_accumulate_into is not None:
+        ops.dwconv_dgrad(dy, rec.weight, dx_accumulate_into, rec.dil, accumulate=True)
+        dx = dx_accumulate_into
+    else:
+        n, c, h, w = rec.x.shape
+        dx = ops.new_act(n, c, h, w, rec.x.device)
+        ops.dwconv_dgrad(dy, rec.weight, dx, rec.dil)
+    return dx, dw, dgamma, dbeta
+
+
+# ----------------------------------------------------------------------------- plain conv (+bias), no BN
+def conv_fwd(x, weight, bias, geom):
+    s, p, d = geom
+    n, _, h, w = x.shape
+    o, _, kh, kw = weight.shape
+    ho, wo = ops.conv_out_hw(h, w, kh, kw, s, p, d)
+    ld = ops.pad4(o)
+    y = ops.new_act(n, o, ho, wo, x.device, ld=ld, zero=ld != o)
+    ops.conv_fprop(x, weight, bias, y, None, s, p, d)
+    return y
+
+
+def conv_bwd(x, weight, geom, dy, need_dx=True, addend=None):
+    """dy must be NHWC with its padding lanes zeroed.  -> (dx, dweight)."""
+    s, p, d = geom
+    dw = torch.empty_like(weight)
+    ops.conv_wgrad(x, dy, dw, s, p, d)
+    dx = None
+    if need_dx:
+        n, c, h, w = x.shape
+        dx = ops.new_act(n, c, h, w, x.device)
+        ops.conv_dgrad(dy, weight, dx, s, p, d, addend=addend)
+    return dx, dw
+
+
+def grad_as_nhwc_padded(g, c):
+    """Incoming autograd gradient -> NHWC tensor whose pixel stride is a multiple of 4 with zeroed padding."""
+    g = ops.to_nhwc(g)
+    ld = ops.pm(g)[1]
+    if ld == c and c % 4 == 0:
+        return g
+    return ops.dense_copy(g, ld=ops.pad4(c))
+
+
+class GradMap:
+    """Collects parameter gradients produced by a hand-scheduled backward and hands them back in parameter order."""
+
+    def __init__(self):
+        self.g = {}
+
+    def put(self, param, grad):
+        if grad is None:
+            return
+        if grad.shape != param.shape:
+            grad = grad.reshape(param.shape)
+        key = id(param)
+        self.g[key] = grad if key not in self.g else self.g[key] + grad
+
+    def ordered(self, params):
+        return tuple(self.g.get(id(p)) for p in params)

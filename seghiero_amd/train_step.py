@@ -1,0 +1,105 @@
+"""The training / validation step of reference ``train.py:260-320`` and ``:327-393`` on the HIP path.
+
+``SegHieroTrainer`` owns what ``train.py:155-246`` builds (backbone, DS-ASPP head, aux head, loss, SGD) and runs one
+step exactly as the reference loop does -- forward, main loss on the logits resized to the label grid, aux head on C3
+with its x16 resize + ``nn.CrossEntropyLoss(ignore_index=255)``, ``loss = main + 0.4 * aux``, backward, SGD -- with
+these fusions (results unchanged):
+
+* the two full-resolution logit tensors of ``train.py:282-284, 310-312`` are never materialised: the bilinear resize is
+  evaluated inside the loss kernels and inside their gather-form backward;
+* ``logit_before_full`` (``train.py:277-279``) is not computed: neither loss reads it;
+* ``loss.item()`` (``train.py:319``) is not called: the step returns device scalars, the caller decides when to sync.
+
+``step`` passed to the loss is the EPOCH, as in the reference (``train.py:287``).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .backbone import ResNetBackbone
+from .head import AuxHead, DepthwiseSeparableASPPContrastHead
+from .hierarchy import build_fine_to_coarse_map, build_hiera_index
+from .loss import HieraTripletLoss
+from .sgd import FusedSGD
+
+
+class _AuxCEFn(torch.autograd.Function):
+    """x16 bilinear resize + nn.CrossEntropyLoss(ignore_index=255) (mean over valid pixels), train.py:309-313."""
+
+    @staticmethod
+    def forward(ctx, logits, label8):
+        lg = ops.to_nhwc(logits)
+        loss, sums = ops.ce_fwd(lg, label8)
+        ctx.save_for_backward(lg, label8, sums)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        lg, label8, sums = ctx.saved_tensors
+        return ops.ce_bwd(lg, label8, sums, g.reshape(1).float(), 1.0), None
+
+
+def aux_ce_loss(aux_logits, label):
+    return _AuxCEFn.apply(aux_logits, ops.labels_u8(label))
+
+
+class SegHieroTrainer:
+    def __init__(self, depth=50, n_fine=9, coarse_to_fine_map=((0, 3), (4, 6), (7,), (8,)), lr=0.01, fine_weight=1.0,
+                 device="cuda:0", head_kw=None, grad_sync=None):
+        cfg_map = [list(x) for x in coarse_to_fine_map]
+        self.n_fine, self.n_coarse = n_fine, len(cfg_map)
+        self.device = torch.device(device)
+        self.backbone = ResNetBackbone(depth=depth, pretrained=False)
+        ch = self.backbone.out_channels
+        kw = dict(in_channels=ch[3], c1_in_channels=ch[0], c1_channels=48, aspp_channels=512,
+                  dilations=(1, 12, 24, 36), num_classes=n_fine + self.n_coarse, proj_dim=256, proj_type="convmlp")
+        kw.update(head_kw or {})
+        self.aspp_head = DepthwiseSeparableASPPContrastHead(**kw)
+        self.aux_head = AuxHead(ch[2], n_fine)
+        self.hiera_loss_fn = HieraTripletLoss(num_classes=n_fine, hiera_map=build_fine_to_coarse_map(cfg_map, n_fine).tolist(),
+                                              hiera_index=build_hiera_index(cfg_map), loss_weight=fine_weight)
+        for m in (self.backbone, self.aspp_head, self.aux_head, self.hiera_loss_fn):
+            m.to(self.device)
+        self.params = list(self.backbone.parameters()) + list(self.aspp_head.parameters()) + list(self.aux_head.parameters())
+        self.optimizer = FusedSGD(self.params, lr=lr, momentum=0.9, weight_decay=1e-4)
+        self.grad_sync = grad_sync
+
+    def modules(self):
+        return {"backbone": self.backbone, "aspp_head": self.aspp_head, "aux_head": self.aux_head}
+
+    def load_state_dicts(self, sd):
+        for k, m in self.modules().items():
+            m.load_state_dict(sd[k])
+
+    def train(self):
+        for m in self.modules().values():
+            m.train()
+
+    def eval(self):
+        for m in self.modules().values():
+            m.eval()
+
+    def forward_loss(self, img, fine_mask, epoch):
+        c1, c2, c3, c4 = self.backbone(img)
+        main_logits, embedding = self.aspp_head([c1, c2, c3, c4])
+        main_loss = self.hiera_loss_fn(epoch, embedding, None, main_logits, fine_mask)
+        aux_loss = aux_ce_loss(self.aux_head(c3), fine_mask)
+        return main_loss + 0.4 * aux_loss, main_loss, aux_loss, main_logits
+
+    def train_step(self, img, fine_mask, epoch=0):
+        """One iteration of train.py:260-320.  Returns the (device) loss scalar; nothing is synchronised."""
+        self.optimizer.zero_grad(set_to_none=True)
+        loss, _, _, _ = self.forward_loss(img, fine_mask, epoch)
+        loss.backward()
+        gscale = 1.0
+        if self.grad_sync is not None:
+            gscale = self.grad_sync.reduce(self.params)
+        self.optimizer.step(grad_scale=gscale)
+        return loss.detach()
+
+    @torch.no_grad()
+    def eval_step(self, img, fine_mask, epoch=0, counts=None):
+        """One iteration of train.py:341-393: loss + fine pixel-accuracy counts (+ confusion matrix for mIoU)."""
+        loss, _, _, logits = self.forward_loss(img, fine_mask, epoch)
+        counts = ops.pixel_metrics(ops.to_nhwc(logits), ops.labels_u8(fine_mask), self.n_fine, counts)
+        return loss, counts
