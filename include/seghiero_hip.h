@@ -42,8 +42,8 @@ int sh_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, int Cp
 /* y[n,oh,ow,co] = bias[co] + sum x[n, oh*s-p+kh*d, ow*s-p+kw*d, ci] * w[co,kh,kw,ci]
  * Replaces nn.Conv2d forward: torchvision Bottleneck convs behind models/backbone/resnet.py:65-73,
  * and every 1x1 conv of models/head/sep_aspp_contrast_head.py (:15-22, :51, :79, :95, :181, :189, :207).
- * Cin % 4 == 0.  stat_partials (optional): [ceil(M/64)][2][Cout] floats receiving per-64-row-tile
- * sum(y) and sum(y*y) per channel (train-mode BatchNorm statistics, F.batch_norm). */
+ * Cin % 4 == 0.  stat_partials (optional): [ceil(M/64)][2][Cout] floats receiving, per 64-row tile and channel,
+ * sum(y) and M2 = sum((y - tile_mean)^2)  (centred partials of the train-mode BatchNorm statistics). */
 int sh_conv_fprop(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
                   float* stat_partials, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                   int stride, int pad, int dil, void* stream);
@@ -65,6 +65,7 @@ int sh_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw,
 /* Replaces DepthwiseSeparableConv.depthwise (models/head/sep_aspp_contrast_head.py:43-46, :56).
  * w is [C][3][3].  stat_partials: [sh_dw_partials(N,H,W)][2][C]. */
 int sh_dw_partials(int N, int H, int W);
+int sh_dw_tile_rows(void);                      /* rows per stat-partial of sh_dwconv_fprop (=64) */
 int sh_dwconv_fprop(const float* x, int ldx, const float* w, float* y, int ldy, float* stat_partials,
                     int N, int H, int W, int C, int dil, void* stream);
 int sh_dwconv_dgrad(const float* dy, int lddy, const float* w, float* dx, int lddx,
@@ -74,17 +75,19 @@ int sh_dwconv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* d
                     int N, int H, int W, int C, int dil, void* stream);
 
 /* batch norm ------------------------------------------------------------------------------ */
-/* Train-mode nn.BatchNorm2d (every BN of the path; math: SURVEY A.2).  Reduces the stat partials in
- * f64, writes mean/invstd/scale/shift and updates the running statistics (momentum, unbiased var). */
+/* Train-mode nn.BatchNorm2d (every BN of the path; math: SURVEY A.2).  Combines the centred stat partials
+ * (sum, M2 over rows_per_partial rows each; count = total rows) in f64, writes mean/invstd/scale/shift and
+ * updates the running statistics (momentum, unbiased var). */
 int sh_bn_finalize(const float* partials, int n_partials, int C, double count, const float* gamma,
                    const float* beta, float eps, float momentum, float* running_mean,
                    float* running_var, float* mean, float* invstd, float* scale, float* shift,
-                   void* stream);
+                   int rows_per_partial, void* stream);
 /* Eval-mode coefficients from the running statistics. */
 int sh_bn_eval_coefs(const float* gamma, const float* beta, const float* running_mean,
                      const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
 /* Per-channel statistics partials of an arbitrary tensor (used where no conv epilogue produced them). */
 int sh_stats_partials_count(int64_t M);
+int sh_stats_tile_rows(void);                   /* rows per stat-partial of sh_channel_stats (=256) */
 int sh_channel_stats(const float* y, int ldy, int64_t M, int C, float* partials, void* stream);
 /* out = [relu]( y*scale + shift [+ residual] ).  Replaces BN-apply + ReLU (+ the Bottleneck residual add). */
 int sh_bn_act(const float* y, int ldy, const float* scale, const float* shift, const float* residual,

@@ -110,7 +110,10 @@ class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mod, x, *params):
         training = mod.training
-        x4 = ops.to_nhwc(x, cpad=4)                                    # NHWC, 3 -> 4 channels (zero)
+        n, _, hh, ww = x.shape
+        x4 = ops.new_act(n, 4, hh, ww, x.device)                       # NHWC, 3 -> 4 channels (4th = 0)
+        xc = x if x.is_contiguous() else x.contiguous()
+        ops._call("sh_nchw_to_nhwc", xc.data_ptr(), x4.data_ptr(), n, 3, hh, ww, 4, ops._st())
         w = mod.stem_conv.weight                                       # [64,3,7,7] -> OHWI with I padded to 4
         if not w.is_contiguous():
             raise SegHieroHipError("stem_conv.weight must be contiguous")

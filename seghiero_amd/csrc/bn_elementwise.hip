@@ -66,8 +66,9 @@ extern "C" int sh_axpy(float* y, const float* x, float a, int64_t n, void* strea
 // ---------------------------------------------------------------------------------------------- stat partial reduce
 // partials: [P][2][C] floats.  Block = 4 channels x 256 row-groups; f64 accumulation; LDS tree.
 // Writes sums[0][c], sums[1][c] (double) into LDS-resident result then calls the functor on thread < 4.
+// CENTRED != 0: partial = (sum, M2 about its own mean) over n_p = min(R, M - p*R) rows -> returns (sum, sum of squares about 0)
 template <typename F>
-__device__ __forceinline__ void reduce_partials_4ch(const float* __restrict__ partials, int P, int C, int c0, F&& fin) {
+__device__ __forceinline__ void reduce_partials_4ch(const float* __restrict__ partials, int P, int C, int c0, int R, long long M, F&& fin) {
     __shared__ double red[8][4];   // [stat*4+ch][wave]
     const int t = threadIdx.x;
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -75,14 +76,16 @@ __device__ __forceinline__ void reduce_partials_4ch(const float* __restrict__ pa
     for (int p = t; p < P; p += 256) {
         const float* r0 = partials + ((long long)p * 2 + 0) * C + c0;
         const float* r1 = partials + ((long long)p * 2 + 1) * C + c0;
+        double inv_n = 0.0;
+        if (R > 0) { const long long left = M - (long long)p * R; inv_n = 1.0 / (double)(left < R ? left : R); }
         if (vec) {
             const f32x4 a = ld4(r0), b = ld4(r1);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { acc[j] += (double)a[j]; acc[4 + j] += (double)b[j]; }
+            for (int j = 0; j < 4; ++j) { acc[j] += (double)a[j]; acc[4 + j] += (double)b[j] + (double)a[j] * (double)a[j] * inv_n; }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (c0 + j < C) { acc[j] += (double)r0[j]; acc[4 + j] += (double)r1[j]; }
+                if (c0 + j < C) { acc[j] += (double)r0[j]; acc[4 + j] += (double)r1[j] + (double)r0[j] * (double)r0[j] * inv_n; }
         }
     }
 #pragma unroll
@@ -103,8 +106,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, float momentum, float* running_mean,
                                                           float* running_var, float* mean, float* invstd, float* scale,
-                                                          float* shift) {
-    reduce_partials_4ch(partials, P, C, blockIdx.x * 4, [&](int c, double s, double q) {
+                                                          float* shift, int R) {
+    reduce_partials_4ch(partials, P, C, blockIdx.x * 4, R, (long long)count, [&](int c, double s, double q) {
         const double mu = s / count;
         double var = q / count - mu * mu;
         if (var < 0) var = 0;
@@ -125,11 +128,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 }
 extern "C" int sh_bn_finalize(const float* partials, int n_partials, int C, double count, const float* gamma,
                               const float* beta, float eps, float momentum, float* running_mean, float* running_var,
-                              float* mean, float* invstd, float* scale, float* shift, void* stream) {
-    if (!partials || n_partials <= 0 || C <= 0 || count <= 0 || !mean || !invstd || !scale || !shift) return SH_EINVAL;
+                              float* mean, float* invstd, float* scale, float* shift, int rows_per_partial, void* stream) {
+    if (!partials || n_partials <= 0 || C <= 0 || count <= 0 || !mean || !invstd || !scale || !shift || rows_per_partial <= 0) return SH_EINVAL;
+    if ((long long)n_partials != sh_cdiv((long long)count, rows_per_partial)) return SH_EINVAL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return SH_EINVAL;
     bn_finalize_kernel<<<(unsigned)sh_cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(
-        partials, n_partials, C, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+        partials, n_partials, C, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, rows_per_partial);
     return sh_launch_status();
 }
 
@@ -179,6 +183,40 @@ __global__ __launch_bounds__(256) void channel_partials_kernel(const float* __re
             }
         }
     }
+    if (KIND == 0) {
+        // centred form: per-thread (n, sum, M2) over its rows, Chan-merged over the 4 row groups
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        if (c < C)
+            for (long long r = rbeg + g; r < rend; r += 4) {
+                const float v = y[r * ldy + c];
+                n += 1.f;
+                const float d = v - mean;
+                mean += d / n;
+                m2 += d * (v - mean);
+            }
+        red[0][g][cl] = n * mean; red[1][g][cl] = m2;
+        __shared__ float cnt[4][64];
+        cnt[g][cl] = n;
+        __syncthreads();
+        if (t < 64) {
+            const int ch = blockIdx.y * 64 + t;
+            if (ch < C) {
+                float N = cnt[0][t], S = red[0][0][t], Q = red[1][0][t];
+#pragma unroll
+                for (int k = 1; k < 4; ++k) {
+                    const float nb = cnt[k][t], sb = red[0][k][t];
+                    if (nb > 0.f) {
+                        if (N > 0.f) { const float dm = S / N - sb / nb; Q += red[1][k][t] + dm * dm * N * nb / (N + nb); }
+                        else Q = red[1][k][t];
+                        N += nb; S += sb;
+                    }
+                }
+                partials[((long long)blockIdx.x * 2 + 0) * C + ch] = S;
+                partials[((long long)blockIdx.x * 2 + 1) * C + ch] = Q;
+            }
+        }
+        return;
+    }
     red[0][g][cl] = s; red[1][g][cl] = q;
     __syncthreads();
     if (t < 128) {
@@ -188,6 +226,7 @@ __global__ __launch_bounds__(256) void channel_partials_kernel(const float* __re
     }
 }
 extern "C" int sh_stats_partials_count(int64_t M) { return (int)sh_cdiv(M, STAT_ROWS); }
+extern "C" int sh_stats_tile_rows(void) { return STAT_ROWS; }
 extern "C" int sh_channel_stats(const float* y, int ldy, int64_t M, int C, float* partials, void* stream) {
     if (!y || !partials || M <= 0 || C <= 0 || ldy < C) return SH_EINVAL;
     dim3 grid((unsigned)sh_cdiv(M, STAT_ROWS), (unsigned)sh_cdiv(C, 64));
@@ -207,7 +246,7 @@ extern "C" int sh_bn_bwd_reduce(const float* dout, int lddo, const float* out, i
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int P, int C,
                                                               const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                               double count, float* dgamma, float* dbeta, float* c1, float* c2) {
-    reduce_partials_4ch(partials, P, C, blockIdx.x * 4, [&](int c, double s, double q) {
+    reduce_partials_4ch(partials, P, C, blockIdx.x * 4, 0, 0, [&](int c, double s, double q) {
         if (dbeta) dbeta[c] = (float)s;
         if (dgamma) dgamma[c] = (float)q;
         c1[c] = (float)(s / count);

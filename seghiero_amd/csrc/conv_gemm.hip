@@ -295,15 +295,30 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p) {
         }
         if constexpr (MODE == FPROP) {
             if (p.partials != nullptr) {   // block-uniform
+                // Per-64-row partial = (sum, M2 = sum of squared deviations from the partial's own mean): the
+                // centred form keeps BatchNorm variance accurate when |mean| >> std (no E[x^2]-E[x]^2 cancellation).
+                const int wrow0 = m0 + wm * 32 * TM;                       // first row of this wave
+                const int nw = max(0, min(32 * TM, p.M - wrow0));          // valid rows of this wave
                 float s[TN], q[TN];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    float ss = 0.f, qq = 0.f;
+                    float ss = 0.f;
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; ss += v; qq += v * v; }
-                    ss += __shfl_xor(ss, 32, 64); qq += __shfl_xor(qq, 32, 64);
+                        for (int r = 0; r < 16; ++r) ss += acc[i][j][r];    // rows >= M are exact zeros
+                    ss += __shfl_xor(ss, 32, 64);
+                    const float mean = nw > 0 ? ss / (float)nw : 0.f;
+                    float qq = 0.f;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = wrow0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            const float dv = acc[i][j][r] - mean;
+                            qq += (nw == 32 * TM || row < p.M) ? dv * dv : 0.f;
+                        }
+                    qq += __shfl_xor(qq, 32, 64);
                     s[j] = ss; q[j] = qq;
                 }
                 if constexpr (TM == 2) {   // a wave covers exactly one 64-row partial
@@ -318,7 +333,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p) {
                             }
                         }
                     }
-                } else {                   // two waves (wm = 0,1) share the 64-row partial: combine in LDS
+                } else {                   // two waves (wm = 0,1; 32 rows each) share the 64-row partial: Chan merge in LDS
                     float* red = smem;     // [2 wm][2][BN]; main loop ended with a barrier
                     if (h == 0) {
 #pragma unroll
@@ -329,10 +344,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p) {
                         }
                     }
                     __syncthreads();
-                    if (t < 2 * BN) {
-                        const int st = t / BN, c = t - st * BN, n = n0 + c;
-                        if (n < p.Nn)
-                            p.partials[((long long)tile_m * 2 + st) * p.Nn + n] = red[st * BN + c] + red[(2 + st) * BN + c];
+                    if (t < BN) {
+                        const int n = n0 + t;
+                        if (n < p.Nn) {
+                            const float na = (float)max(0, min(32, p.M - m0)), nb = (float)max(0, min(32, p.M - m0 - 32));
+                            const float sa = red[t], sb = red[2 * BN + t];
+                            float m2 = red[BN + t] + red[3 * BN + t];
+                            if (nb > 0.f) { const float dm = sa / na - sb / nb; m2 += dm * dm * na * nb / (na + nb); }
+                            p.partials[((long long)tile_m * 2 + 0) * p.Nn + n] = sa + sb;
+                            p.partials[((long long)tile_m * 2 + 1) * p.Nn + n] = m2;
+                        }
                     }
                 }
             }

@@ -12,6 +12,7 @@
 #define DW_CH 64           // channels per block (16 float4 lanes)
 
 extern "C" int sh_dw_partials(int N, int H, int W) { return (int)sh_cdiv((long long)N * H * W, DW_PIX); }
+extern "C" int sh_dw_tile_rows(void) { return DW_PIX; }
 
 // block: 256 threads = 16 channel-quads x 16 pixel lanes; each thread loops 4 pixels.
 template <int MODE>   // 0 fprop (+stats), 1 dgrad (flipped taps)
@@ -19,7 +20,8 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
                                                      float* __restrict__ y, long long ldy, float* __restrict__ partials,
                                                      int H, int W, int C, int dil, long long M, int accumulate) {
     __shared__ float ws[9][DW_CH];
-    __shared__ float red[2][16][DW_CH];
+    __shared__ float red[16][DW_CH];
+    __shared__ float colmean[DW_CH];
     const int t = threadIdx.x, cq = t & 15, pl = t >> 4;
     const int c0 = blockIdx.y * DW_CH;
     for (int i = t; i < 9 * DW_CH; i += 256) {
@@ -30,11 +32,15 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
     __syncthreads();
     const int c = c0 + cq * 4;
     const bool cok = c < C;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    f32x4 kept[DW_PIX / 16];
+    bool kept_ok[DW_PIX / 16];
     const bool tap_row_ok = dil < H, tap_col_ok = dil < W;   // off-centre taps can touch the image at all?
 #pragma unroll
     for (int it = 0; it < DW_PIX / 16; ++it) {
         const long long m = (long long)blockIdx.x * DW_PIX + it * 16 + pl;
+        kept_ok[it] = false;
+        kept[it] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (m < M && cok) {
             const int ow = (int)(m % W);
             const long long r = m / W;
@@ -58,19 +64,37 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
             }
             if (MODE == 1 && accumulate) acc += ld4(y + m * ldy + c);
             st4(y + m * ldy + c, acc);
-            s += acc; q += acc * acc;
+            s += acc; kept[it] = acc; kept_ok[it] = true;
         }
     }
     if (MODE == 0 && partials != nullptr) {
+        // per-block partial = (sum, M2 about the block's own mean) -- centred, see conv_gemm.hip
+        const long long left = M - (long long)blockIdx.x * DW_PIX;
+        const float nvalid = (float)(left < DW_PIX ? left : DW_PIX);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { red[0][pl][cq * 4 + j] = s[j]; red[1][pl][cq * 4 + j] = q[j]; }
+        for (int j = 0; j < 4; ++j) red[pl][cq * 4 + j] = s[j];
         __syncthreads();
-        if (t < 2 * DW_CH) {
-            const int st = t / DW_CH, cc = t % DW_CH;
-            float a = 0.f;
+        float colsum = 0.f;
+        if (t < DW_CH) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) a += red[st][k][cc];
-            if (c0 + cc < C) partials[((long long)blockIdx.x * 2 + st) * C + c0 + cc] = a;
+            for (int k = 0; k < 16; ++k) colsum += red[k][t];
+            colmean[t] = colsum / nvalid;
+        }
+        __syncthreads();
+        f32x4 q = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 mu = ld4(&colmean[cq * 4]);
+#pragma unroll
+        for (int it = 0; it < DW_PIX / 16; ++it)
+            if (kept_ok[it]) { const f32x4 dv = kept[it] - mu; q += dv * dv; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[pl][cq * 4 + j] = q[j];
+        __syncthreads();
+        if (t < DW_CH && c0 + t < C) {
+            float m2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) m2 += red[k][t];
+            partials[((long long)blockIdx.x * 2 + 0) * C + c0 + t] = colsum;
+            partials[((long long)blockIdx.x * 2 + 1) * C + c0 + t] = m2;
         }
     }
 }

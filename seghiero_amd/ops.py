@@ -180,13 +180,13 @@ def dwconv_wgrad(x, dy, dweight, dil):
 
 
 # ----------------------------------------------------------------------------- batch norm
-def bn_finalize(partials, count, gamma, beta, eps, momentum, running_mean, running_var, c, device):
+def bn_finalize(partials, count, gamma, beta, eps, momentum, running_mean, running_var, c, device, rows=64):
     coefs = torch.empty((4, c), device=device, dtype=torch.float32)      # mean, invstd, scale, shift
     _call("sh_bn_finalize", partials.data_ptr(), partials.shape[0], c, float(count),
           None if gamma is None else gamma.data_ptr(), None if beta is None else beta.data_ptr(), eps, momentum,
           None if running_mean is None else running_mean.data_ptr(),
           None if running_var is None else running_var.data_ptr(),
-          coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(), coefs[3].data_ptr(), _st())
+          coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(), coefs[3].data_ptr(), rows, _st())
     return coefs
 
 

@@ -67,9 +67,10 @@ def test_conv_fprop_dgrad_wgrad(ops, case):
     ops.conv_fprop(xg, wg, None, y2, part, s, p, d)
     ref_nb = F.conv2d(x, wt, None, s, p, d)
     close(y2, ref_nb, 2e-5, 2e-5, "fprop")
-    # BN statistic partials: sum and sum of squares per channel
-    close(part[:, 0].sum(0), ref_nb.sum((0, 2, 3)), 1e-4, 1e-3, "stat sum")
-    close(part[:, 1].sum(0), (ref_nb * ref_nb).sum((0, 2, 3)), 1e-4, 1e-3, "stat sumsq")
+    # BN statistics from the epilogue's centred (sum, M2) partials
+    coefs = ops.bn_finalize(part, n * ho * wo, None, None, 1e-5, 0.1, None, None, cout, DEV, rows=64)
+    close(coefs[0], ref_nb.mean((0, 2, 3)), 1e-4, 1e-5, "stat mean")
+    close(coefs[1], 1.0 / torch.sqrt(ref_nb.var((0, 2, 3), unbiased=False) + 1e-5), 1e-4, 1e-5, "stat invstd")
     # backward
     dy = torch.randn(ref.shape, generator=g)
     xr = x.clone().requires_grad_(True)
@@ -119,8 +120,9 @@ def test_dwconv(ops, shape, dil):
     part = torch.empty((ops.dw_partials_rows(n, h, w), 2, c), device=DEV)
     ops.dwconv_fprop(xg, wg, y, part, dil)
     close(y, ref, 1e-5, 1e-5)
-    close(part[:, 0].sum(0), ref.detach().sum((0, 2, 3)), 1e-4, 1e-3)
-    close(part[:, 1].sum(0), (ref.detach() ** 2).sum((0, 2, 3)), 1e-4, 1e-3)
+    coefs = ops.bn_finalize(part, n * h * w, None, None, 1e-5, 0.1, None, None, c, DEV, rows=64)
+    close(coefs[0], ref.detach().mean((0, 2, 3)), 1e-4, 1e-5)
+    close(coefs[1], 1.0 / torch.sqrt(ref.detach().var((0, 2, 3), unbiased=False) + 1e-5), 1e-4, 1e-5)
     dx = ops.new_act(n, c, h, w, DEV)
     ops.dwconv_dgrad(nhwc(dy), wg, dx, dil)
     close(dx, x.grad, 1e-5, 1e-5)
@@ -151,7 +153,7 @@ def test_batchnorm_train_fwd_bwd(ops, shape, relu, res):
     yg = nhwc(y.detach())
     part = ops.channel_stats(yg)
     rmg, rvg = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
-    coefs = ops.bn_finalize(part, n * h * w, gamma.detach().to(DEV), beta.detach().to(DEV), 1e-5, 0.1, rmg, rvg, c, DEV)
+    coefs = ops.bn_finalize(part, n * h * w, gamma.detach().to(DEV), beta.detach().to(DEV), 1e-5, 0.1, rmg, rvg, c, DEV, rows=256)
     out = ops.new_act(n, c, h, w, DEV)
     ops.bn_act(yg, coefs, out, relu, None if not res else nhwc(resid.detach()))
     close(out, ref, 1e-5, 2e-5, "bn fwd")
