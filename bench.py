@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the SegHiero training step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one synthetic batch resident in HBM: ResNet-50 trunk -> DS-ASPP contrast head
+-> fused resize + 2-level HieraTripletLoss (+ aux head + CE) -> backward -> (RCCL gradient all-reduce) -> fused SGD.
+Workload = BASELINE.json configs[1]: 512x512, batch 16 per GPU (weak scaling), 9 fine / 4 coarse classes, fp32.
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the launch stream over one extra
+instrumented step; `cpu_baseline` times the CPU oracle (oracle.step.OracleTrainer, kind "port") on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TF = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+HBM_PEAK_GBS = 8000.0
+CFG = dict(depth=50, n_fine=9, coarse_to_fine_map=[[0, 3], [4, 6], [7], [8]], size=512, batch=16)
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """Reference CPU train loop (the oracle) at the headline shape, bounded: batch 2 at 512x512, ResNet-50."""
+    from oracle.step import OracleTrainer
+    from seghiero_amd.synthetic import make_batch
+    threads = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    tr = OracleTrainer(depth=CFG["depth"], n_fine=CFG["n_fine"], coarse_to_fine_map=CFG["coarse_to_fine_map"])
+    tr.train()
+    b = 2
+    img, lab = make_batch(b, CFG["size"], CFG["n_fine"], seed=0)
+    t0 = time.perf_counter()
+    tr.train_step(img, lab, 0)                       # warm-up (allocator, thread pool)
+    warm = time.perf_counter() - t0
+    steps = 1 if warm > seconds_budget / 2 else max(1, min(3, int(seconds_budget / max(warm, 1e-3)) - 1))
+    t0 = time.perf_counter()
+    for s in range(steps):
+        tr.train_step(img, lab, 0)
+    dt = time.perf_counter() - t0
+    return {"value": round(b * steps / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"oracle.step.OracleTrainer (pure torch CPU restatement of train.py:260-320), ResNet-50 2-level, "
+                      f"512x512, batch {b}, {steps} timed step(s) after 1 warm-up, {threads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=CFG["batch"])
+    args = ap.parse_args()
+
+    from seghiero_amd import ddp, ops
+    from seghiero_amd.synthetic import make_batch
+    from seghiero_amd.train_step import SegHieroTrainer
+
+    rank, local, world = ddp.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(0)
+    tr = SegHieroTrainer(depth=CFG["depth"], n_fine=CFG["n_fine"], coarse_to_fine_map=CFG["coarse_to_fine_map"],
+                         lr=0.01, device=dev)
+    if world > 1:
+        ddp.broadcast_module_state(list(tr.modules().values()))
+        tr.grad_sync = ddp.GradSync(tr.params)
+    tr.train()
+    img, lab = make_batch(args.batch, CFG["size"], CFG["n_fine"], seed=rank, device=dev)
+    lab8 = ops.labels_u8(lab)                       # the loader contract is i64 labels; convert once, outside the loop
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.train_step(img, lab8, 0)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.train_step(img, lab8, 0)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    loss_val = float(loss)
+
+    if rank != 0:
+        return
+    # ---- roofline of the dominant kernel, measured live (HIP events on the launch stream), one instrumented step
+    with ops.profile() as prof:
+        tr.train_step(img, lab8, 0)
+    rows = prof.rows
+    dom = max(rows, key=lambda k: rows[k]["ms"])
+    r = rows[dom]
+    total_ms = sum(v["ms"] for v in rows.values())
+    roof = {"bound": "mfma", "kernel": dom, "achieved": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2),
+            "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(r["flops"] / (r["ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4),
+            "traffic": None, "launches": r["calls"], "avg_launch_us": round(1e3 * r["ms"] / r["calls"], 1),
+            "alg_bytes_per_step": r["bytes"], "alg_flops_per_step": r["flops"],
+            "share_of_step": round(r["ms"] / total_ms, 3)}
+    if r["flops"] == 0:
+        roof.update(bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None)
+    breakdown = {k: round(v["ms"], 2) for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])[:12]}
+    out = {
+        "metric": "images/sec at 512x512 (ResNet-50 2-level), full train step", "value": round(args.batch * world * args.steps / dt, 2),
+        "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: ResNet-50 + DepthwiseSeparableASPPContrastHead + 2-level HieraTripletLoss "
+                               "+ aux head, 9 fine / 4 coarse, 512x512 synthetic, fwd+loss+bwd+SGD",
+                   "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+        "loss": round(loss_val, 5), "roofline": roof, "kernel_ms_per_step": breakdown,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -10,7 +10,44 @@ import torch
 
 from ._lib import LIB, SegHieroHipError
 
-_call = LIB.call
+_PROF = None          # when set (see `profile()`), every C-ABI call is bracketed by HIP events on its launch stream
+
+
+def _call(name, *args, cost=None):
+    """Launch one C-ABI entry point on the current stream.  `cost` = (algorithmic flops, algorithmic bytes)."""
+    if _PROF is None:
+        return LIB.call(name, *args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = LIB.call(name, *args)
+    e1.record()
+    _PROF.append((name, cost, e0, e1))
+    return rc
+
+
+class profile:
+    """Context manager: per-kernel-family device time measured with HIP events recorded on the launch stream
+    (torch's current stream), plus the algorithmic flops / bytes the callers declare.  Used by bench.py for the
+    roofline line; adds event overhead, so never wrap the timed region with it."""
+
+    def __enter__(self):
+        global _PROF
+        _PROF = []
+        return self
+
+    def __exit__(self, *exc):
+        global _PROF
+        rec, _PROF = _PROF, None
+        torch.cuda.synchronize()
+        self.rows = {}
+        for name, cost, e0, e1 in rec:
+            r = self.rows.setdefault(name, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+            r["calls"] += 1
+            r["ms"] += e0.elapsed_time(e1)
+            if cost:
+                r["flops"] += cost[0]
+                r["bytes"] += cost[1]
+        return False
 
 
 def _st():
@@ -106,8 +143,11 @@ def conv_fprop(x, weight, bias, y, partials, stride, pad, dil):
     o, _, kh, kw = weight.shape
     xp, ldx = pm(x)
     yp, ldy = pm(y)
+    ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
+    m = n * ho * wo
     _call("sh_conv_fprop", xp, ldx, w_ohwi(weight).data_ptr(), None if bias is None else bias.data_ptr(), yp, ldy,
-          None if partials is None else partials.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, _st())
+          None if partials is None else partials.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, _st(),
+          cost=(2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin + m * o + o * cin * kh * kw)))
 
 
 def conv_dgrad(dy, weight, dx, stride, pad, dil, addend=None, mode=0):
@@ -116,8 +156,11 @@ def conv_dgrad(dy, weight, dx, stride, pad, dil, addend=None, mode=0):
     dyp, lddy = pm(dy)
     dxp, lddx = pm(dx)
     ap, lda = (None, 0) if addend is None else pm(addend)
+    ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
+    m = n * ho * wo
     _call("sh_conv_dgrad", dyp, lddy, w_ohwi(weight).data_ptr(), ap, lda, dxp, lddx, n, h, w, cin, o, kh, kw,
-          stride, pad, dil, mode, _st())
+          stride, pad, dil, mode, _st(),
+          cost=(2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin * (2 if addend is not None or mode else 1) + m * o + o * cin * kh * kw)))
 
 
 _WS = {}
@@ -142,8 +185,11 @@ def conv_wgrad(x, dy, dweight, stride, pad, dil):
     ws = workspace(need, x.device, "wgrad")
     xp, ldx = pm(x)
     dyp, lddy = pm(dy)
+    ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
+    m = n * ho * wo
     _call("sh_conv_wgrad", xp, ldx, dyp, lddy, dweight.data_ptr(), ws.data_ptr(), n, h, w, cin, o, kh, kw,
-          stride, pad, dil, _st())
+          stride, pad, dil, _st(),
+          cost=(2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin + m * o + o * cin * kh * kw)))
 
 
 def conv_partials(m, cout, device):
