@@ -233,13 +233,59 @@ extern "C" int sh_channel_stats(const float* y, int ldy, int64_t M, int C, float
     channel_partials_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(y, ldy, nullptr, 0, nullptr, 0, nullptr, nullptr, partials, M, C, 0);
     return sh_launch_status();
 }
+// float4 variant of the BN-backward partials: block = 256 rows x 64 channels, thread = (channel quad, row lane),
+// 16 rows per thread with 4 rows (12 x 16-byte loads) in flight.
+__global__ __launch_bounds__(256) void bn_bwd_partials_v4_kernel(const float* __restrict__ y, long long ldy,
+                                                                 const float* __restrict__ dout, long long lddo,
+                                                                 const float* __restrict__ out, long long ldo,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 float* __restrict__ partials, long long M, int C, int relu) {
+    __shared__ float red[2][16][64];
+    const int t = threadIdx.x, cq = t & 15, rl = t >> 4;
+    const int c = blockIdx.y * 64 + cq * 4;
+    const long long rbeg = (long long)blockIdx.x * STAT_ROWS;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        const f32x4 mu = ld4(mean + c), is = ld4(invstd + c);
+#pragma unroll 4
+        for (int k = 0; k < STAT_ROWS / 16; ++k) {
+            const long long r = rbeg + rl + 16 * k;
+            if (r < M) {
+                f32x4 g = ld4(dout + r * lddo + c);
+                const f32x4 yv = ld4(y + r * ldy + c);
+                if (relu) {
+                    const f32x4 o = ld4(out + r * ldo + c);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
+                }
+                s += g;
+                q += g * ((yv - mu) * is);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[0][rl][cq * 4 + j] = s[j]; red[1][rl][cq * 4 + j] = q[j]; }
+    __syncthreads();
+    if (t < 128) {
+        const int st = t >> 6, cc = t & 63, ch = blockIdx.y * 64 + cc;
+        if (ch < C) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a += red[st][k][cc];
+            partials[((long long)blockIdx.x * 2 + st) * C + ch] = a;
+        }
+    }
+}
 extern "C" int sh_bn_bwd_reduce(const float* dout, int lddo, const float* out, int ldo, const float* y, int ldy,
                                 const float* mean, const float* invstd, float* partials, int64_t M, int C, int relu,
                                 void* stream) {
     if (!dout || !y || !mean || !invstd || !partials || M <= 0 || C <= 0 || lddo < C || ldy < C) return SH_EINVAL;
     if (relu && (!out || ldo < C)) return SH_EINVAL;
     dim3 grid((unsigned)sh_cdiv(M, STAT_ROWS), (unsigned)sh_cdiv(C, 64));
-    channel_partials_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(y, ldy, dout, lddo, out, ldo, mean, invstd, partials, M, C, relu);
+    const bool v4 = (C & 3) == 0 && ((lddo | ldy | (relu ? ldo : 0)) & 3) == 0 && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
+                    (!relu || ((uintptr_t)out & 15) == 0) && ((uintptr_t)mean & 15) == 0 && ((uintptr_t)invstd & 15) == 0;
+    if (v4) bn_bwd_partials_v4_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(y, ldy, dout, lddo, out, ldo, mean, invstd, partials, M, C, relu);
+    else channel_partials_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(y, ldy, dout, lddo, out, ldo, mean, invstd, partials, M, C, relu);
     return sh_launch_status();
 }
 
@@ -260,16 +306,19 @@ extern "C" int sh_bn_bwd_finalize(const float* partials, int n_partials, int C, 
     return sh_launch_status();
 }
 
+#define EW_ROWS 16
 // ---------------------------------------------------------------------------------------------- BN apply (+residual, +ReLU)
 template <int V>
 __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y, long long ldy, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, const float* __restrict__ res, long long ldr,
                                                      float* __restrict__ out, long long ldo, long long M, int C, int relu) {
     const int cv = C / V;
-    const long long total = M * cv;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long m = i / cv;
-        const int c = (int)(i - m * cv) * V;
+    // chunks of EW_ROWS rows per block iteration; 32-bit (row, column) split inside a chunk
+    for (long long m0 = (long long)blockIdx.x * EW_ROWS; m0 < M; m0 += (long long)gridDim.x * EW_ROWS)
+    for (int e = threadIdx.x, tot = (int)((M - m0 < EW_ROWS ? M - m0 : EW_ROWS)) * cv; e < tot; e += 256) {
+        const int r = e / cv;
+        const long long m = m0 + r;
+        const int c = (e - r * cv) * V;
         if (V == 4) {
             f32x4 v = ld4(y + m * ldy + c) * ld4(scale + c) + ld4(shift + c);
             if (res) v += ld4(res + m * ldr + c);
@@ -283,6 +332,12 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y
         }
     }
 }
+static inline unsigned rows_grid(long long M, int cv) {
+    (void)cv;
+    long long g = sh_cdiv(M, EW_ROWS);
+    if (g > 8192) g = 8192;
+    return (unsigned)(g < 1 ? 1 : g);
+}
 static inline bool vec4_ok(int C, long long a, long long b = 0, long long c = 0, long long d = 0, long long e = 0) {
     return (C & 3) == 0 && ((a | b | c | d | e) & 3) == 0;
 }
@@ -293,8 +348,8 @@ extern "C" int sh_bn_act(const float* y, int ldy, const float* scale, const floa
     if (!y || !scale || !shift || !out || M <= 0 || C <= 0 || ldy < C || ldo < C) return SH_EINVAL;
     if (residual && ldr < C) return SH_EINVAL;
     const bool v4 = vec4_ok(C, ldy, ldo, residual ? ldr : 0) && ptr16(y) && ptr16(out) && ptr16(scale) && ptr16(shift) && (!residual || ptr16(residual));
-    if (v4) bn_act_kernel<4><<<grid_for(M * (C / 4)), 256, 0, (hipStream_t)stream>>>(y, ldy, scale, shift, residual, ldr, out, ldo, M, C, relu);
-    else bn_act_kernel<1><<<grid_for(M * C), 256, 0, (hipStream_t)stream>>>(y, ldy, scale, shift, residual, ldr, out, ldo, M, C, relu);
+    if (v4) bn_act_kernel<4><<<rows_grid(M, C / 4), 256, 0, (hipStream_t)stream>>>(y, ldy, scale, shift, residual, ldr, out, ldo, M, C, relu);
+    else bn_act_kernel<1><<<rows_grid(M, C), 256, 0, (hipStream_t)stream>>>(y, ldy, scale, shift, residual, ldr, out, ldo, M, C, relu);
     return sh_launch_status();
 }
 
@@ -306,10 +361,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ c2, float* __restrict__ dy, long long lddy,
                                                            float* __restrict__ dres, long long lddres, long long M, int C, int relu) {
     const int cv = C / V;
-    const long long total = M * cv;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long m = i / cv;
-        const int c = (int)(i - m * cv) * V;
+    // chunks of EW_ROWS rows per block iteration; 32-bit (row, column) split inside a chunk
+    for (long long m0 = (long long)blockIdx.x * EW_ROWS; m0 < M; m0 += (long long)gridDim.x * EW_ROWS)
+    for (int e = threadIdx.x, tot = (int)((M - m0 < EW_ROWS ? M - m0 : EW_ROWS)) * cv; e < tot; e += 256) {
+        const int r = e / cv;
+        const long long m = m0 + r;
+        const int c = (e - r * cv) * V;
         if (V == 4) {
             f32x4 g = ld4(dout + m * lddo + c);
             if (relu) {
@@ -342,7 +399,7 @@ extern "C" int sh_bn_bwd_apply(const float* dout, int lddo, const float* out, in
     if (dres && lddres < C) return SH_EINVAL;
     const bool v4 = vec4_ok(C, lddo, ldy, lddy, relu ? ldo : 0, dres ? lddres : 0) && ptr16(dout) && ptr16(y) && ptr16(dy) &&
                     ptr16(mean) && ptr16(invstd) && ptr16(c1) && ptr16(c2) && (!gamma || ptr16(gamma)) && (!relu || ptr16(out)) && (!dres || ptr16(dres));
-    if (v4) bn_bwd_apply_kernel<4><<<grid_for(M * (C / 4)), 256, 0, (hipStream_t)stream>>>(dout, lddo, out, ldo, y, ldy, mean, invstd, gamma, c1, c2, dy, lddy, dres, lddres, M, C, relu);
-    else bn_bwd_apply_kernel<1><<<grid_for(M * C), 256, 0, (hipStream_t)stream>>>(dout, lddo, out, ldo, y, ldy, mean, invstd, gamma, c1, c2, dy, lddy, dres, lddres, M, C, relu);
+    if (v4) bn_bwd_apply_kernel<4><<<rows_grid(M, C / 4), 256, 0, (hipStream_t)stream>>>(dout, lddo, out, ldo, y, ldy, mean, invstd, gamma, c1, c2, dy, lddy, dres, lddres, M, C, relu);
+    else bn_bwd_apply_kernel<1><<<rows_grid(M, C), 256, 0, (hipStream_t)stream>>>(dout, lddo, out, ldo, y, ldy, mean, invstd, gamma, c1, c2, dy, lddy, dres, lddres, M, C, relu);
     return sh_launch_status();
 }

@@ -361,14 +361,21 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvP p) {
     }
 }
 
-// slab reduce: dw[i] = sum_s slab[s][i]
+// slab reduce: dw[i] = sum_s slab[s][i].  Block = 64 float4 columns x 4 slab groups (f32 partial sums per group,
+// fixed combine order => deterministic).
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                           long long n4, long long n, int S) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    f32x4 s = ld4(slab + 4 * i);
-    for (int k = 1; k < S; ++k) s += ld4(slab + (long long)k * n + 4 * i);
-    st4(dw + 4 * i, s);
+    __shared__ f32x4 red[4][64];
+    const int t = threadIdx.x, cl = t & 63, g = t >> 6;
+    const long long i = (long long)blockIdx.x * 64 + cl;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4) {
+#pragma unroll 4
+        for (int k = g; k < S; k += 4) s += ld4(slab + (long long)k * n + 4 * i);
+    }
+    red[g][cl] = s;
+    __syncthreads();
+    if (t < 64 && i < n4) st4(dw + 4 * i, (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]));
 }
 
 // ---------------------------------------------------------------------------------------- host side
@@ -476,7 +483,7 @@ static WgradPlan wgrad_plan(int Cout, long long Nn, long long npix) {
     g.TN = Nn <= 64 ? 1 : 2;
     long long tiles = sh_cdiv(Cout, 64 * g.TM) * sh_cdiv(Nn, 64 * g.TN);
     if (tiles < 64 && g.TM == 2 && g.TN == 2) { /* keep the big tile: parallelism comes from the pixel split */ }
-    long long want = sh_cdiv(1024, tiles);
+    long long want = sh_cdiv(640, tiles);      // ~2.5 blocks per CU: enough to fill the chip, few slabs to reduce
     long long maxs = sh_cdiv(npix, 256);
     long long s = want < 1 ? 1 : want;
     if (s > maxs) s = maxs;
@@ -510,6 +517,6 @@ extern "C" int sh_conv_wgrad(const float* x, int ldx, const float* dy, int lddy,
     int rc = launch_conv<WGRAD>(p, g.TM, g.TN, g.splits, (hipStream_t)stream);
     if (rc != SH_OK) return rc;
     const long long n = (long long)Cout * p.Nn, n4 = n / 4;   // Nn % 4 == 0
-    slab_reduce_kernel<<<(unsigned)sh_cdiv(n4, 256), 256, 0, (hipStream_t)stream>>>(workspace, dw, n4, n, g.splits);
+    slab_reduce_kernel<<<(unsigned)sh_cdiv(n4, 64), 256, 0, (hipStream_t)stream>>>(workspace, dw, n4, n, g.splits);
     return sh_launch_status();
 }

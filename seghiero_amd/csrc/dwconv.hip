@@ -110,24 +110,27 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restri
     f32x4 acc[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const long long nchunks = (M + DW_PIX - 1) / DW_PIX;
+    for (long long chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {      // grid-stride: few, fat partials
 #pragma unroll
-    for (int it = 0; it < DW_PIX / 16; ++it) {
-        const long long m = (long long)blockIdx.x * DW_PIX + it * 16 + pl;
-        if (m < M && cok) {
-            const int ow = (int)(m % W);
-            const long long r = m / W;
-            const int oh = (int)(r % H);
-            const long long n = r / H;
-            const f32x4 g = ld4(dy + m * lddy + c);
+        for (int it = 0; it < DW_PIX / 16; ++it) {
+            const long long m = chunk * DW_PIX + it * 16 + pl;
+            if (m < M && cok) {
+                const int ow = (int)(m % W);
+                const long long r = m / W;
+                const int oh = (int)(r % H);
+                const long long n = r / H;
+                const f32x4 g = ld4(dy + m * lddy + c);
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const int ih = oh + (kh - 1) * dil;
-                if ((unsigned)ih >= (unsigned)H) continue;
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int ih = oh + (kh - 1) * dil;
+                    if ((unsigned)ih >= (unsigned)H) continue;
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int iw = ow + (kw - 1) * dil;
-                    if ((unsigned)iw >= (unsigned)W) continue;
-                    acc[kh * 3 + kw] += g * ld4(x + ((n * H + ih) * W + iw) * ldx + c);
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int iw = ow + (kw - 1) * dil;
+                        if ((unsigned)iw >= (unsigned)W) continue;
+                        acc[kh * 3 + kw] += g * ld4(x + ((n * H + ih) * W + iw) * ldx + c);
+                    }
                 }
             }
         }
@@ -185,7 +188,9 @@ extern "C" int sh_dwconv_wgrad(const float* x, int ldx, const float* dy, int ldd
                                int N, int H, int W, int C, int dil, void* stream) {
     if (!dw_args_ok(x, dy, dw, N, H, W, C, dil, ldx, lddy) || !dw_partials) return SH_EINVAL;
     const long long M = (long long)N * H * W;
-    const int P = (int)sh_cdiv(M, DW_PIX);
+    int P = (int)sh_cdiv(M, DW_PIX);
+    const int cap = (int)sh_cdiv(1024, sh_cdiv(C, DW_CH));          // ~4 blocks per CU over all channel chunks
+    if (P > cap) P = cap < 1 ? 1 : cap;
     dim3 grid((unsigned)P, (unsigned)sh_cdiv(C, DW_CH));
     dwconv_wgrad_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, dy, lddy, dw_partials, H, W, C, dil, M);
     int rc = sh_launch_status();

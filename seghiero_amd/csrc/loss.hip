@@ -34,8 +34,11 @@ __device__ __forceinline__ Lerp lerp_src(int dst, float scale, int in) {
     return L;
 }
 __device__ __forceinline__ void contrib_range(int i, float inv_scale, int out, int& lo, int& hi) {
-    lo = (int)floorf(((float)i - 0.5f) * inv_scale - 0.5f) - 1;
-    hi = (int)ceilf(((float)i + 1.5f) * inv_scale - 0.5f) + 1;
+    // outputs whose source lies in (i-1, i+1): dst in ((i-0.5)/scale-0.5, (i+1.5)/scale-0.5).  floor / ceil of the open
+    // ends is a superset even under f32 rounding (an end that rounds across an integer only drops/keeps a candidate whose
+    // weight is ~1 ulp); every candidate re-derives the exact forward weights.
+    lo = (int)floorf(((float)i - 0.5f) * inv_scale - 0.5f);
+    hi = (int)ceilf(((float)i + 1.5f) * inv_scale - 0.5f);
     if (i == 0) lo = 0;
     lo = lo < 0 ? 0 : lo;
     hi = hi > out - 1 ? out - 1 : hi;
@@ -289,6 +292,121 @@ __global__ __launch_bounds__(256) void hiera2_bwd_kernel(const float* __restrict
     for (int j = 0; j < MAXC; ++j) if (j < lddl) dst[j] = j < C ? acc[j] : 0.f;   // padding lanes are zeroed (dgrad reads them)
 }
 
+// ------------------------------------------------------------------------------------------ tiled backward (both losses)
+// One block = TL x TL low-resolution pixels of one image.  Phase A: every full-resolution pixel that can reference the
+// tile (its bilinear footprint) gets its loss gradient computed ONCE into an LDS tile.  Phase B: each (low-res pixel,
+// channel) gathers its footprint from LDS with the forward's exact weights, in a fixed order (deterministic, no atomics).
+// Halo recompute is (TL*s+s+2)^2/(TL*s)^2 instead of the ~4x of a per-pixel gather, and the logits are read once.
+template <int MAXC, int MODE>   // MODE 0: 2-level hiera loss, 1: CE (valid-pixel mean)
+__global__ __launch_bounds__(256) void loss_bwd_tile_kernel(const float* __restrict__ logits, long long ldl, const uint8_t* __restrict__ labels,
+                                                            const H2Tab T, int C, const double* __restrict__ sums,
+                                                            const float* __restrict__ gscale_dev, float gscale, float* __restrict__ dlogits,
+                                                            long long lddl, int h, int w, int H, int W, float sy, float sx, int TL,
+                                                            int tiles_x, int tiles_y, int lds_cap) {
+    extern __shared__ __attribute__((aligned(16))) float gt[];
+    const int t = threadIdx.x;
+    const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y;
+    const long long n = blockIdx.x / (tiles_x * tiles_y);
+    const int i0 = ty * TL, i1 = min(i0 + TL, h) - 1, j0 = tx * TL, j1 = min(j0 + TL, w) - 1;
+    const bool identity = (h == H && w == W);
+    int ylo, yhi, xlo, xhi, tmp;
+    if (identity) { ylo = i0; yhi = i1; xlo = j0; xhi = j1; }
+    else {
+        contrib_range(i0, 1.f / sy, H, ylo, tmp); contrib_range(i1, 1.f / sy, H, tmp, yhi);
+        contrib_range(j0, 1.f / sx, W, xlo, tmp); contrib_range(j1, 1.f / sx, W, tmp, xhi);
+    }
+    const int RH = yhi - ylo + 1, RW = xhi - xlo + 1;
+    if (RH * RW * C > lds_cap) return;                       // cannot happen (host sizes lds_cap from the same bound)
+    const float gs = gscale * (gscale_dev ? gscale_dev[0] : 1.f);
+    float af = 0.f, ac = 0.f, b;
+    if (MODE == 0) {
+        const double nvf = sums[4] < 1.0 ? 1.0 : sums[4], nvc = sums[5] < 1.0 ? 1.0 : sums[5];
+        af = gs * (float)(5.0 / (nvf * T.nf));
+        ac = T.nc > 0 ? gs * (float)(5.0 / (nvc * T.nc)) : 0.f;
+        b = gs * (float)(1.0 / sums[6]);
+    } else {
+        b = gs * (float)(1.0 / sums[1]);
+    }
+    const float* base = logits + n * h * w * ldl;
+    // ---- phase A
+    for (int idx = t; idx < RH * RW; idx += 256) {
+        const int ry = idx / RW, rx = idx - ry * RW, oy = ylo + ry, ox = xlo + rx;
+        float g[MAXC];
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j) g[j] = 0.f;
+        const int f = labels[(n * H + oy) * W + ox];
+        if (f != IGN) {
+            const Lerp ly = lerp_src(oy, sy, h), lx = lerp_src(ox, sx, w);
+            float z[MAXC];
+            fetch_logits<MAXC>(base, ldl, w, ly, lx, identity, C, z);
+            if (MODE == 0) {
+                float o[4];
+                hiera2_pixel<MAXC, true>(z, f, coarse_of(f, T), T, af, ac, b, o, g);
+            } else {
+                softmax_ce<MAXC, true>(z, 0, C, f, b, g);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j) if (j < C) gt[idx * C + j] = g[j];
+    }
+    __syncthreads();
+    // ---- phase B
+    const int nrows = i1 - i0 + 1, ncols = j1 - j0 + 1, L = (int)lddl;
+    for (int item = t; item < nrows * ncols * L; item += 256) {
+        const int ch = item % L, pq = item / L;
+        const int iy = i0 + pq / ncols, ix = j0 + pq % ncols;
+        float acc = 0.f;
+        if (ch < C) {
+            int cylo, cyhi, cxlo, cxhi;
+            if (identity) { cylo = cyhi = iy; cxlo = cxhi = ix; }
+            else { contrib_range(iy, 1.f / sy, H, cylo, cyhi); contrib_range(ix, 1.f / sx, W, cxlo, cxhi); }
+            for (int oy = cylo; oy <= cyhi; ++oy) {
+                const Lerp ly = lerp_src(oy, sy, h);
+                const float wy = identity ? 1.f : (ly.i0 == iy ? ly.w0 : 0.f) + (ly.i1 == iy ? ly.w1 : 0.f);
+                if (wy == 0.f) continue;
+                const float* row = gt + ((oy - ylo) * RW - xlo) * C + ch;
+                for (int ox = cxlo; ox <= cxhi; ++ox) {
+                    const Lerp lx = lerp_src(ox, sx, w);
+                    const float wx = identity ? 1.f : (lx.i0 == ix ? lx.w0 : 0.f) + (lx.i1 == ix ? lx.w1 : 0.f);
+                    if (wx != 0.f) acc += (wy * wx) * row[ox * C];
+                }
+            }
+        }
+        dlogits[((n * h + iy) * w + ix) * lddl + ch] = acc;          // padding lanes (ch >= C) are written as zeros
+    }
+}
+
+// host: pick TL (low-res tile side) so the LDS gradient tile stays <= budget; returns 0 if even TL = 1 does not fit
+static int pick_tile(int h, int w, int H, int W, int C, int budget_bytes, int& region_elems) {
+    const float sy = (float)H / (float)h, sx = (float)W / (float)w;
+    const float s = sy > sx ? sy : sx;
+    int best = 0;
+    for (int TL = 1; TL <= 32; ++TL) {
+        const int side = (h == H && w == W) ? TL : (int)ceilf(TL * s + s) + 3;
+        const long long bytes = (long long)side * side * C * 4;
+        if (bytes > budget_bytes) break;
+        best = TL; region_elems = side * side * C;
+    }
+    return best;
+}
+template <int MAXC, int MODE>
+static int launch_loss_bwd_tile(const float* logits, int ldl, const uint8_t* labels, const H2Tab& T, int C, const double* sums,
+                                const float* gscale_dev, float gscale, float* dlogits, int lddl, int N, int h, int w, int H, int W,
+                                int TL, int region_elems, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&loss_bwd_tile_kernel<MAXC, MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_done = true;
+    }
+    const int tiles_x = (int)sh_cdiv(w, TL), tiles_y = (int)sh_cdiv(h, TL);
+    const unsigned nblk = (unsigned)((long long)N * tiles_x * tiles_y);
+    loss_bwd_tile_kernel<MAXC, MODE><<<nblk, 256, (size_t)region_elems * 4, st>>>(
+        logits, ldl, labels, T, C, sums, gscale_dev, gscale, dlogits, lddl, h, w, H, W, (float)h / (float)H, (float)w / (float)W, TL,
+        tiles_x, tiles_y, region_elems);
+    return sh_launch_status();
+}
+
 extern "C" int sh_hiera2_partials(int N, int H, int W) { return (int)sh_cdiv((long long)N * H * W, LOSS_PIX_PER_BLOCK); }
 
 static bool make_tab(H2Tab& T, const int* buckets, int nf, int nc) {
@@ -333,7 +451,17 @@ extern "C" int sh_hiera2_loss_bwd(const float* logits, int ldl, const uint8_t* l
     const unsigned nblk = (unsigned)sh_cdiv(total, 256);
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
     hipStream_t st = (hipStream_t)stream;
-    const int C = lddl;   // kernel writes lddl lanes (padding zeroed), so size the register arrays for it
+    {
+        const int Cr = n_fine + n_coarse;
+        int region = 0;
+        const int TL = (h <= H && w <= W) ? pick_tile(h, w, H, W, Cr, 80 * 1024, region) : 0;
+        if (TL > 0 && TL * TL * lddl >= 256) {
+            if (Cr <= 8) return launch_loss_bwd_tile<8, 0>(logits, ldl, labels, T, Cr, sums, gscale_dev, gscale, dlogits, lddl, N, h, w, H, W, TL, region, st);
+            if (Cr <= 16) return launch_loss_bwd_tile<16, 0>(logits, ldl, labels, T, Cr, sums, gscale_dev, gscale, dlogits, lddl, N, h, w, H, W, TL, region, st);
+            return launch_loss_bwd_tile<32, 0>(logits, ldl, labels, T, Cr, sums, gscale_dev, gscale, dlogits, lddl, N, h, w, H, W, TL, region, st);
+        }
+    }
+    const int C = lddl;   // fallback gather kernel writes lddl lanes (padding zeroed), so size the register arrays for it
     if (C <= 8) hiera2_bwd_kernel<8><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, sums, gscale_dev, gscale, dlogits, lddl, h, w, H, W, sy, sx, total);
     else if (C <= 16) hiera2_bwd_kernel<16><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, sums, gscale_dev, gscale, dlogits, lddl, h, w, H, W, sy, sx, total);
     else hiera2_bwd_kernel<32><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, sums, gscale_dev, gscale, dlogits, lddl, h, w, H, W, sy, sx, total);
@@ -449,6 +577,18 @@ extern "C" int sh_ce_loss_bwd(const float* logits, int ldl, const uint8_t* label
     const unsigned nblk = (unsigned)sh_cdiv(total, 4);
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
     hipStream_t st = (hipStream_t)stream;
+    {
+        H2Tab T{};
+        int region = 0;
+        const int TL = (h <= H && w <= W) ? pick_tile(h, w, H, W, C, 80 * 1024, region) : 0;
+        // the tiled form needs enough (pixel, channel) items for its gather phase; at large resize factors (x16 aux head:
+        // TL = 1) the wave-per-pixel gather below is the faster one
+        if (TL > 0 && TL * TL * lddl >= 256) {
+            if (C <= 8) return launch_loss_bwd_tile<8, 1>(logits, ldl, labels, T, C, sums, gscale_dev, gscale, dlogits, lddl, N, h, w, H, W, TL, region, st);
+            if (C <= 16) return launch_loss_bwd_tile<16, 1>(logits, ldl, labels, T, C, sums, gscale_dev, gscale, dlogits, lddl, N, h, w, H, W, TL, region, st);
+            return launch_loss_bwd_tile<32, 1>(logits, ldl, labels, T, C, sums, gscale_dev, gscale, dlogits, lddl, N, h, w, H, W, TL, region, st);
+        }
+    }
     if (lddl <= 8) ce_bwd_kernel<8><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, sums, gscale_dev, gscale, dlogits, lddl, h, w, H, W, sy, sx, total);
     else if (lddl <= 16) ce_bwd_kernel<16><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, sums, gscale_dev, gscale, dlogits, lddl, h, w, H, W, sy, sx, total);
     else ce_bwd_kernel<32><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, sums, gscale_dev, gscale, dlogits, lddl, h, w, H, W, sy, sx, total);
