@@ -211,4 +211,5 @@ class ResNetBackbone(nn.Module):
     def forward(self, x: torch.Tensor):
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError("expected input of shape [B, 3, H, W]")
+        ops._require_gpu(x)
         return _BackboneFn.apply(self, x, *self.parameters())

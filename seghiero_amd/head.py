@@ -232,6 +232,7 @@ class DepthwiseSeparableASPPContrastHead(nn.Module):
     def forward(self, inputs: list):
         """inputs: [C1, C2, C3, C4] (only inputs[0] and inputs[-1] are read, as in the reference).
         Returns (logits [B,num_classes,H/4,W/4], embedding [B,proj_dim,H/32,W/32])."""
+        ops._require_gpu(inputs[-1])
         self.step += 1
         c1 = inputs[0] if self.c1_bottleneck is not None else None
         return _HeadFn.apply(self, c1, inputs[-1], *self.parameters())
@@ -270,4 +271,5 @@ class AuxHead(nn.Sequential):
                          nn.ReLU(inplace=True))
 
     def forward(self, c3):
+        ops._require_gpu(c3)
         return _AuxFn.apply(self, c3, *self.parameters())

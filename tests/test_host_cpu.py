@@ -1,0 +1,166 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every symbol the header declares, the host-side
+helpers are bit-exact against the reference goldens, module surfaces (names, state_dict keys, error behaviour) match,
+and the compute entry points fail loudly instead of falling back when there is no GPU."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from seghiero_amd._lib import LIBPATH
+    if not os.path.exists(LIBPATH):
+        subprocess.check_call(["bash", os.path.join(ROOT, "seghiero_amd", "csrc", "build.sh")])
+    return LIBPATH
+
+
+def test_abi_exports_every_declared_symbol(built):
+    from seghiero_amd._lib import HEADER, LIB
+    declared = set(re.findall(r"\b(sh_\w+)\s*\(", re.sub(r"/\*.*?\*/", " ", open(HEADER).read(), flags=re.S)))
+    assert len(declared) >= 45
+    assert declared == set(LIB.protos), declared ^ set(LIB.protos)
+    assert set(LIB.exported_symbols()) == declared          # dlsym succeeded for each of them
+    assert LIB.raw("sh_abi_version")() == 1                  # host-only calls work without a GPU
+    assert LIB.raw("sh_conv_tile_rows")() == 64
+    assert LIB.raw("sh_conv_wgrad_workspace")(16, 128, 128, 64, 64, 3, 3, 1, 1, 1) > 0
+    assert LIB.raw("sh_conv_wgrad_workspace")(16, 128, 128, 3, 64, 3, 3, 1, 1, 1) == -1     # Cin % 4 != 0 rejected
+
+
+def test_abi_rejects_bad_arguments_without_launching(built):
+    from seghiero_amd._lib import LIB
+    assert LIB.raw("sh_conv_fprop")(None, 4, None, None, None, 4, None, 1, 8, 8, 4, 4, 1, 1, 1, 0, 1, None) == -1
+    assert LIB.raw("sh_sgd_step")(0, None, None, None, None, 0.1, 0.9, 0.0, 1, 1.0, None) == -1
+    assert LIB.raw("sh_fill")(None, 0.0, 10, None) == -1
+
+
+def test_hierarchy_helpers_bit_exact_vs_reference_golden(golden):
+    import seghiero_amd as sa
+    g = golden("g1_maps")
+    cfgs = {"a": ([[0, 3], [4, 6], [7], [8]], 9), "b": ([[0, 1], [2, 3]], 4), "c": ([[0], [1, 4], [5, 6]], 7)}
+    for k, (cfg, nf) in cfgs.items():
+        assert np.array_equal(sa.build_fine_to_coarse_map(cfg, nf).numpy(), g[f"{k}_f2c"])
+        assert sa.build_fine_to_coarse_map(cfg, nf).dtype == torch.long
+        assert np.array_equal(np.asarray(sa.build_hiera_index(cfg)), g[f"{k}_hidx"])
+    assert np.array_equal(sa.build_fine_to_super_map([[0], [1, 6]], 7).numpy(), g["c_f2s"])
+    with pytest.raises(ValueError):
+        sa.build_fine_to_super_map([[0, 1], [2, 3]], 9)
+
+
+def test_module_surface_matches_reference(golden):
+    from seghiero_amd.backbone import ResNetBackbone
+    from seghiero_amd.head import AuxHead, DepthwiseSeparableASPPContrastHead
+    from oracle import nets
+    g = golden("g3_head")
+    kw = dict(in_channels=64, c1_in_channels=16, c1_channels=8, aspp_channels=16, dilations=(1, 12, 24, 36),
+              num_classes=6, proj_dim=8, proj_type="convmlp")
+    head = DepthwiseSeparableASPPContrastHead(**kw)
+    ref_keys = {k[4:]: v.shape for k, v in g.items() if k.startswith("sd__")}     # keys/shapes of the REFERENCE head
+    assert {k: tuple(v.shape) for k, v in head.state_dict().items()} == {k: tuple(s) for k, s in ref_keys.items()}
+    full = DepthwiseSeparableASPPContrastHead(2048, 256, 48, 512, (1, 12, 24, 36), 13)
+    assert len(full.state_dict()) == 94 and sum(p.numel() for p in full.parameters()) == 11925104 + 513 * 13
+    with pytest.raises(ValueError):
+        DepthwiseSeparableASPPContrastHead(**{**kw, "proj_type": "mlp"})
+    torch.manual_seed(3)                      # seed-for-seed default init == the reference's (incl. discarded draws)
+    h2 = DepthwiseSeparableASPPContrastHead(**kw)
+    for k, v in h2.state_dict().items():
+        if v.dim() == 4 or k == "cls_seg.bias":
+            np.testing.assert_array_equal(v.numpy(), g["sd__" + k], err_msg=k)
+    for depth, n in ((18, 11176512), (50, 23508032), (101, 42500160)):
+        with pytest.warns(UserWarning):
+            bb = ResNetBackbone(depth)            # pretrained=True default: warns, never fetches
+        assert sum(p.numel() for p in bb.parameters()) == n
+        ob = nets.ResNetBackbone(depth, pretrained=False)
+        assert {k: tuple(v.shape) for k, v in bb.state_dict().items()} == {k: tuple(v.shape) for k, v in ob.state_dict().items()}
+    with pytest.raises(ValueError):
+        ResNetBackbone(77, pretrained=False)
+    assert list(AuxHead(1024, 9).state_dict()) == list(nets.make_aux_head(1024, 9).state_dict())
+
+
+def test_state_dict_roundtrip_keeps_native_layout():
+    from seghiero_amd.backbone import ResNetBackbone
+    from oracle import nets
+    ob = nets.ResNetBackbone(18, pretrained=False)
+    bb = ResNetBackbone(18, pretrained=False)
+    bb.load_state_dict(ob.state_dict())
+    w = bb.layer1[0].conv1.weight
+    assert torch.equal(w, ob.layer1[0].conv1.weight)                       # same logical values
+    assert w.is_contiguous(memory_format=torch.channels_last)             # OHWI memory for the kernels
+    assert bb.stem_conv.weight.is_contiguous()
+
+
+def test_no_cpu_fallback():
+    """The product must raise on CPU tensors -- there is no eager / oracle fallback behind it."""
+    import seghiero_amd as sa
+    from seghiero_amd.backbone import ResNetBackbone
+    from seghiero_amd.loss import HieraTripletLoss
+    bb = ResNetBackbone(18, pretrained=False)
+    with pytest.raises(sa.SegHieroHipError, match="MI355X"):
+        bb(torch.randn(1, 3, 32, 32))
+    loss = HieraTripletLoss(4, [0, 0, 1, 1], [[0, 2], [2, 4]])
+    with pytest.raises(sa.SegHieroHipError):
+        loss(0, torch.randn(1, 8, 2, 2), None, torch.randn(1, 6, 8, 8), torch.zeros(1, 8, 8, dtype=torch.long))
+    src = "".join(open(os.path.join(ROOT, "seghiero_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "seghiero_amd")) if f.endswith(".py"))
+    assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_triplet_tables_and_factor():
+    from seghiero_amd.loss import triplet_factor, two_level_triplet_tables
+    masks, ok = two_level_triplet_tables([0, 0, 1, 1], [[0, 2], [2, 4]])
+    def members(words):
+        return {v for v in range(256) if (int(words[v >> 6]) >> (v & 63)) & 1}
+    assert members(masks[0, 0]) == {1} and members(masks[3, 0]) == {2}
+    assert members(masks[0, 1]) == set(range(2, 256))                      # negatives include 255 (reference :36)
+    assert members(ok) == {0, 1, 2, 3}
+    assert triplet_factor(0, 80000) == 0.0 and triplet_factor(80000, 80000) == 0.5
+    assert abs(triplet_factor(40000, 80000) - 0.25) < 1e-12
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from seghiero_amd import ddp
+    ddp.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(s)) for s in [(7,), (64, 16, 3, 3), (13, 32, 1, 1), (300,)]]
+    params[1].data = params[1].data.contiguous(memory_format=torch.channels_last)
+    sync = ddp.GradSync(params, bucket_mb=0.01)
+    assert len(sync.buckets) >= 2
+    g = torch.Generator().manual_seed(100 + rank)
+    for p in params:
+        p.grad = torch.empty_like(p).copy_(torch.randn(p.shape, generator=g))
+    scale = sync.reduce(params)
+    m = torch.nn.Linear(3, 2)
+    with torch.no_grad():
+        m.weight.fill_(float(rank))
+    ddp.broadcast_module_state([m])
+    q.put((rank, scale, [p.grad.detach().numpy().copy() for p in params], float(m.weight.detach().sum())))
+    dist.destroy_process_group()
+
+
+def test_gradsync_two_ranks_gloo():
+    """N>1 path on CPU: bucketed all-reduce over gloo == sum of the per-rank gradients; broadcast from rank 0."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 200
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+    expect = []
+    for r in range(2):
+        g = torch.Generator().manual_seed(100 + r)
+        expect.append([torch.randn(s, generator=g) for s in [(7,), (64, 16, 3, 3), (13, 32, 1, 1), (300,)]])
+    for rank, scale, grads, wsum in res:
+        assert scale == 0.5 and wsum == 0.0
+        for gi, g in enumerate(grads):
+            np.testing.assert_allclose(g, (expect[0][gi] + expect[1][gi]).numpy(), rtol=1e-6, atol=1e-6)

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the implicit-GEMM conv kernels on the layer shapes of the ResNet-50 / 512x512 / B=16 step.
+Times fprop / dgrad / wgrad with HIP events (torch current stream) and prints TFLOP/s (fp32 MFMA peak 157.3)."""
+import sys
+import torch
+sys.path.insert(0, ".")
+from seghiero_amd import ops
+
+DEV = "cuda:0"
+SHAPES = [  # name, N, H, W, Cin, Cout, k, stride, pad
+    ("stem7x7", 16, 512, 512, 4, 64, 7, 2, 3),
+    ("l1.conv1 256>64", 16, 128, 128, 256, 64, 1, 1, 0),
+    ("l1.conv2 3x3 64", 16, 128, 128, 64, 64, 3, 1, 1),
+    ("l1.conv3 64>256", 16, 128, 128, 64, 256, 1, 1, 0),
+    ("l2.conv2 3x3 128", 16, 64, 64, 128, 128, 3, 1, 1),
+    ("l2.conv3 128>512", 16, 64, 64, 128, 512, 1, 1, 0),
+    ("l2.0.conv2 3x3/2", 16, 128, 128, 128, 128, 3, 2, 1),
+    ("l3.conv2 3x3 256", 16, 32, 32, 256, 256, 3, 1, 1),
+    ("l3.conv3 256>1024", 16, 32, 32, 256, 1024, 1, 1, 0),
+    ("l3.conv1 1024>256", 16, 32, 32, 1024, 256, 1, 1, 0),
+    ("l4.conv2 3x3 512", 16, 16, 16, 512, 512, 3, 1, 1),
+    ("l4.conv3 512>2048", 16, 16, 16, 512, 2048, 1, 1, 0),
+    ("aspp.pw 2048>512", 16, 16, 16, 2048, 512, 1, 1, 0),
+    ("proj 2048>2048", 16, 16, 16, 2048, 2048, 1, 1, 0),
+    ("sep0.pw 560>512", 16, 128, 128, 560, 512, 1, 1, 0),
+    ("sep1.pw 512>512", 16, 128, 128, 512, 512, 1, 1, 0),
+]
+
+
+def timeit(fn, iters=10):
+    fn(); fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+    tot = {"fprop": [0, 0], "dgrad": [0, 0], "wgrad": [0, 0]}
+    for name, n, h, w, cin, cout, k, s, p in SHAPES:
+        if only and only not in name:
+            continue
+        ho, wo = ops.conv_out_hw(h, w, k, k, s, p, 1)
+        x = ops.new_act(n, cin, h, w, DEV); x.normal_()
+        wt = torch.randn(cout, cin, k, k, device=DEV).contiguous(memory_format=torch.channels_last) * 0.05
+        y = ops.new_act(n, cout, ho, wo, DEV)
+        part = ops.conv_partials(n * ho * wo, cout, DEV)
+        dy = ops.new_act(n, cout, ho, wo, DEV); dy.normal_()
+        dx = ops.new_act(n, cin, h, w, DEV)
+        dw = torch.empty_like(wt)
+        fl = 2.0 * n * ho * wo * cout * cin * k * k
+        tf = timeit(lambda: ops.conv_fprop(x, wt, None, y, part, s, p, 1))
+        td = timeit(lambda: ops.conv_dgrad(dy, wt, dx, s, p, 1))
+        tw = timeit(lambda: ops.conv_wgrad(x, dy, dw, s, p, 1))
+        for key, t in (("fprop", tf), ("dgrad", td), ("wgrad", tw)):
+            tot[key][0] += fl; tot[key][1] += t
+        print(f"{name:20s} GF={fl/1e9:7.1f}  fprop {tf*1e3:7.1f}us {fl/tf/1e9:6.1f}TF | dgrad {td*1e3:7.1f}us {fl/td/1e9:6.1f}TF | "
+              f"wgrad {tw*1e3:7.1f}us {fl/tw/1e9:6.1f}TF", flush=True)
+    for key, (fl, t) in tot.items():
+        if t:
+            print(f"TOTAL {key}: {fl/t/1e9:.1f} TF")
+
+
+if __name__ == "__main__":
+    main()
