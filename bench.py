@@ -64,9 +64,12 @@ def main():
     from seghiero_amd.synthetic import make_batch
     from seghiero_amd.train_step import SegHieroTrainer
 
-    rank, local, world = ddp.init_from_env()
+    # SEGHIERO_BENCH_BACKEND=gloo + SEGHIERO_BENCH_ONE_DEVICE=1 rehearse the N>1 code path on a single-GPU box
+    rank, local, world = ddp.init_from_env(backend=os.environ.get("SEGHIERO_BENCH_BACKEND"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("SEGHIERO_BENCH_ONE_DEVICE"):
+        local = 0
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     torch.manual_seed(0)
@@ -79,6 +82,9 @@ def main():
     img, lab = make_batch(args.batch, CFG["size"], CFG["n_fine"], seed=rank, device=dev)
     lab8 = ops.labels_u8(lab)                       # the loader contract is i64 labels; convert once, outside the loop
 
+    trace = (lambda m: print(f"[rank {rank}] {m}", file=sys.stderr, flush=True)) if os.environ.get("SEGHIERO_TRACE") else (lambda m: None)
+    trace("setup done")
+
     def barrier():
         if world > 1:
             torch.distributed.barrier()
@@ -86,7 +92,9 @@ def main():
 
     for _ in range(args.warmup):
         tr.train_step(img, lab8, 0)
+        trace("warmup step done")
     barrier()
+    trace("barrier passed")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = tr.train_step(img, lab8, 0)
@@ -94,15 +102,19 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        ddp.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
     loss_val = float(loss)
 
+    # ---- roofline of the dominant kernel, measured live (HIP events on the launch stream), one instrumented step.
+    # Every rank runs it (the step contains collectives); only rank 0 instruments and reports.
     if rank != 0:
+        tr.train_step(img, lab8, 0)
+        barrier()
         return
-    # ---- roofline of the dominant kernel, measured live (HIP events on the launch stream), one instrumented step
     with ops.profile() as prof:
         tr.train_step(img, lab8, 0)
+    barrier()
     rows = prof.rows
     dom = max(rows, key=lambda k: rows[k]["ms"])
     r = rows[dom]

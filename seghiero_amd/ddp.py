@@ -34,13 +34,34 @@ def init_from_env(backend=None):
     return rank, local, world
 
 
+def _via_host(group=None):
+    """gloo has no device collectives in this build: stage through host memory (rehearsal / CPU tests only;
+    the production backend is "nccl" = RCCL, which works on device buffers directly)."""
+    return dist.get_backend(group) == "gloo"
+
+
+def all_reduce(t, op=None, group=None, async_op=False):
+    op = dist.ReduceOp.SUM if op is None else op
+    if t.is_cuda and _via_host(group):
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+        return None
+    return dist.all_reduce(t, op=op, group=group, async_op=async_op)
+
+
 def broadcast_module_state(modules, src=0):
     """Make every rank start from rank `src`'s parameters and buffers (weights, BN running stats, `step`)."""
     if not (dist.is_available() and dist.is_initialized()):
         return
     for m in modules:
         for t in list(m.parameters()) + list(m.buffers()):
-            dist.broadcast(t.data, src=src)
+            if t.is_cuda and _via_host():
+                h = t.detach().cpu()
+                dist.broadcast(h, src=src)
+                t.data.copy_(h)
+            else:
+                dist.broadcast(t.data, src=src)
 
 
 class GradSync:
@@ -92,11 +113,12 @@ class GradSync:
                 ev.record(cur)
                 with torch.cuda.stream(self.stream):
                     self.stream.wait_event(ev)
-                    works.append(dist.all_reduce(buf, group=self.group, async_op=True))
+                    works.append(all_reduce(buf, group=self.group, async_op=True))
             else:
-                works.append(dist.all_reduce(buf, group=self.group, async_op=True))
+                works.append(all_reduce(buf, group=self.group, async_op=True))
         for w in works:
-            w.wait()
+            if w is not None:
+                w.wait()
         if self.stream is not None:
             cur.wait_stream(self.stream)
         for start, end, plist in self.buckets:          # point the grads at the reduced arena (no copy back)

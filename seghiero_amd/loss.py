@@ -149,8 +149,9 @@ class _Hiera2Fn(torch.autograd.Function):
         ready = None
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             # hiera_triplet_loss.py:193-198: the term counts only if EVERY rank produced triplets
+            from . import ddp
             ready = trip[1:2].clone()
-            torch.distributed.all_reduce(ready, op=torch.distributed.ReduceOp.MIN)
+            ddp.all_reduce(ready, op=torch.distributed.ReduceOp.MIN)
         factor = triplet_factor(step, 80000)
         total = ops.combine_loss(main, trip, ready, factor, mod.loss_weight)
         ctx.save_for_backward(logits, emb, label8, sums, trip, ws)
