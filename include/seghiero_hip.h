@@ -166,6 +166,29 @@ int sh_triplet_bwd(const float* emb, const void* workspace, const float* out, co
  * (hiera_triplet_loss.py:193-211). */
 int sh_combine_loss(const float* main_loss, const float* trip_out, const float* ready_count, float factor,
                     float loss_weight, float* out, void* stream);
+/* ---- 3-level loss with the RMI lower bound: RMIHieraTripletLoss (models/loss/rmi_hiera_triplet_loss.py:323-546) ---- */
+/* Fused resize + mid/high targets by gather (:21-63) + 3-level sigmoid BCE (eps 1e-6, :352-470) + three all-pixel-mean CE
+ * terms (:523-526).  f2m_host / f2h_host: HOST int32[n_fine] fine->mid / fine->high maps.
+ *   sums (device double[8]) <- {bce_f, bce_m, bce_h, ce_f, ce_m, ce_h, n_valid, n_pixels}
+ *   loss_out (device float[1]) <- 0.5*5*(bce_f/(nv*nf)+bce_m/(nv*nm)+bce_h/(nv*nh)) + (ce_f+ce_m+ce_h)/npix
+ *   probs (optional): planar f32 [N][C][H][W] <- sigmoid(z)*valid + 1e-6 (the RMI input, :496). */
+int sh_hiera3_loss_fwd(const float* logits, int ldl, const uint8_t* labels, const int* f2m_host, const int* f2h_host,
+                       int n_fine, int n_mid, int n_high, double* sums, float* loss_out, float* partials, float* probs,
+                       int N, int h, int w, int H, int W, void* stream);
+/* RMI lower bound (:292-317, :479-517): per (image, channel) f64 9x9 Gram matrices over the 3x3 windows, inverse, Schur
+ * complement, Cholesky log-det; rmi_out (device float[1]) <- sum_c mean_b(0.5*logdet)/9.  dprob (optional, planar like
+ * probs) <- d(0.5*logdet_{b,c})/dP (the 1/(9N) and lambda factors are applied by sh_hiera3_loss_bwd's rmi_coef). */
+int64_t sh_rmi_workspace(int N, int C, int H, int W);
+int sh_rmi_loss(const float* probs, const uint8_t* labels, const int* f2m_host, const int* f2h_host, int n_fine, int n_mid,
+                int n_high, void* workspace, float* rmi_out, float* dprob, int N, int H, int W, void* stream);
+/* dlogits [N,h,w,lddl] <- gscale*gscale_dev[0] * d(loss_out + rmi_coef * <dprob, P>)/d(logits)  (tiled gather form). */
+int sh_hiera3_loss_bwd(const float* logits, int ldl, const uint8_t* labels, const int* f2m_host, const int* f2h_host,
+                       int n_fine, int n_mid, int n_high, const double* sums, const float* dprob, float rmi_coef,
+                       const float* gscale_dev, float gscale, float* dlogits, int lddl, int N, int h, int w, int H, int W,
+                       void* stream);
+/* out = (a + alpha*b[0]) -- device scalar combine used for lambda*rmi + rest. */
+int sh_scalar_axpy(const float* a, const float* b, float alpha, float* out, void* stream);
+
 /* fine argmax + pixel accuracy + confusion matrix (train.py:37-49, 381-385; mIoU is build-defined).
  * counts: int64 [2 + n_fine*n_fine] = {correct, valid, confusion[gt][pred]...} (accumulated; zero it first). */
 int sh_pixel_metrics(const float* logits, int ldl, const uint8_t* labels, int n_fine, long long* counts,

@@ -15,18 +15,27 @@ from . import hierarchy, losses, nets
 
 class OracleTrainer:
     def __init__(self, depth=50, n_fine=9, coarse_to_fine_map=((0, 3), (4, 6), (7,), (8,)), lr=0.01, fine_weight=1.0,
-                 head_kw=None):
+                 head_kw=None, super_coarse_to_coarse_map=None, rmi_radius=3):
         cfg_map = [list(x) for x in coarse_to_fine_map]
+        sup_map = None if super_coarse_to_coarse_map is None else [list(x) for x in super_coarse_to_coarse_map]
         self.n_fine, self.n_coarse = n_fine, len(cfg_map)
+        self.n_super = 0 if sup_map is None else len(sup_map)
         self.backbone = nets.ResNetBackbone(depth, pretrained=False)
         ch = self.backbone.out_channels
         kw = dict(in_channels=ch[3], c1_in_channels=ch[0], c1_channels=48, aspp_channels=512,
-                  dilations=(1, 12, 24, 36), num_classes=n_fine + self.n_coarse, proj_dim=256, proj_type="convmlp")
+                  dilations=(1, 12, 24, 36), num_classes=n_fine + self.n_coarse + self.n_super, proj_dim=256,
+                  proj_type="convmlp")
         kw.update(head_kw or {})
         self.aspp_head = nets.DepthwiseSeparableASPPContrastHead(**kw)
         self.aux_head = nets.make_aux_head(ch[2], n_fine)
-        self.hiera_loss_fn = losses.HieraTripletLoss(n_fine, hierarchy.build_fine_to_coarse_map(cfg_map, n_fine).tolist(),
-                                                     hierarchy.build_hiera_index(cfg_map), loss_weight=fine_weight)
+        if sup_map is None:
+            self.hiera_loss_fn = losses.HieraTripletLoss(n_fine, hierarchy.build_fine_to_coarse_map(cfg_map, n_fine).tolist(),
+                                                         hierarchy.build_hiera_index(cfg_map), loss_weight=fine_weight)
+        else:
+            self.hiera_loss_fn = losses.RMIHieraTripletLoss(n_fine, self.n_coarse, self.n_super,
+                                                            hierarchy.build_fine_to_coarse_map(cfg_map, n_fine),
+                                                            hierarchy.build_fine_to_super_map(sup_map, n_fine), rmi_radius=rmi_radius,
+                                                            loss_weight_lambda=fine_weight, loss_weight=1.0)
         self.aux_criterion = nn.CrossEntropyLoss(ignore_index=255)
         self.params = list(self.backbone.parameters()) + list(self.aspp_head.parameters()) + list(self.aux_head.parameters())
         self.optimizer = torch.optim.SGD(self.params, lr=lr, momentum=0.9, weight_decay=1e-4)

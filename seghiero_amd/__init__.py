@@ -16,6 +16,7 @@ def __getattr__(name):
     table = {
         "ResNetBackbone": "backbone", "DepthwiseSeparableASPPContrastHead": "head", "AuxHead": "head",
         "HieraTripletLoss": "loss", "TreeTripletLoss": "loss", "CrossEntropyLoss": "loss",
+        "RMIHieraTripletLoss": "loss", "RMITreeTripletLoss": "loss",
         "SegHieroTrainer": "train_step", "FusedSGD": "sgd",
     }
     if name in table:

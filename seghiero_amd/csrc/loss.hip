@@ -9,9 +9,8 @@
 //  * sh_triplet_*    : tree-triplet (tree_triplet_loss.py:15-65 / rmi_tree_triplet_loss.py:14-70).
 //  * sh_pixel_metrics: fine argmax, pixel accuracy counts (train.py:37-49, 381-385) and a confusion matrix.
 // All are HBM/latency-bound reductions: wave shuffles -> LDS -> one partial per block -> f64 finalize.
-#include "common.h"
+#include "loss_common.h"
 
-#define IGN 255
 #define MAXB 32       // max coarse buckets
 #define MAXF 64       // max fine classes
 
@@ -21,75 +20,11 @@ struct H2Tab {
     signed char bucket_of[MAXF];
 };
 
-struct Lerp { int i0, i1; float w0, w1; };
-__device__ __forceinline__ Lerp lerp_src(int dst, float scale, int in) {
-    float s = scale * ((float)dst + 0.5f) - 0.5f;
-    s = s < 0.f ? 0.f : s;
-    Lerp L;
-    L.i0 = (int)s;
-    if (L.i0 > in - 1) L.i0 = in - 1;
-    L.i1 = L.i0 + (L.i0 < in - 1 ? 1 : 0);
-    L.w1 = s - (float)L.i0;
-    L.w0 = 1.f - L.w1;
-    return L;
-}
-__device__ __forceinline__ void contrib_range(int i, float inv_scale, int out, int& lo, int& hi) {
-    // outputs whose source lies in (i-1, i+1): dst in ((i-0.5)/scale-0.5, (i+1.5)/scale-0.5).  floor / ceil of the open
-    // ends is a superset even under f32 rounding (an end that rounds across an integer only drops/keeps a candidate whose
-    // weight is ~1 ulp); every candidate re-derives the exact forward weights.
-    lo = (int)floorf(((float)i - 0.5f) * inv_scale - 0.5f);
-    hi = (int)ceilf(((float)i + 1.5f) * inv_scale - 0.5f);
-    if (i == 0) lo = 0;
-    lo = lo < 0 ? 0 : lo;
-    hi = hi > out - 1 ? out - 1 : hi;
-}
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
-
-// interpolate C channels of pixel (oy,ox) from the low-res logits of image n
-template <int MAXC>
-__device__ __forceinline__ void fetch_logits(const float* __restrict__ base, long long ldl, int w, const Lerp& ly, const Lerp& lx,
-                                             bool identity, int C, float (&z)[MAXC]) {
-    if (identity) {
-        const float* p = base + ((long long)ly.i0 * w + lx.i0) * ldl;
-#pragma unroll
-        for (int j = 0; j < MAXC; ++j) z[j] = j < C ? p[j] : 0.f;
-    } else {
-        const float* p00 = base + ((long long)ly.i0 * w + lx.i0) * ldl;
-        const float* p01 = base + ((long long)ly.i0 * w + lx.i1) * ldl;
-        const float* p10 = base + ((long long)ly.i1 * w + lx.i0) * ldl;
-        const float* p11 = base + ((long long)ly.i1 * w + lx.i1) * ldl;
-#pragma unroll
-        for (int j = 0; j < MAXC; ++j)
-            z[j] = j < C ? ly.w0 * (lx.w0 * p00[j] + lx.w1 * p01[j]) + ly.w1 * (lx.w0 * p10[j] + lx.w1 * p11[j]) : 0.f;
-    }
-}
-
 __device__ __forceinline__ int coarse_of(int f, const H2Tab& T) {
     int c = IGN;
     for (int i = 0; i < T.nc; ++i)
         if (f >= T.bs[i] && f < T.be[i]) c = i;     // later buckets overwrite, like the reference's sequential masked writes
     return c;
-}
-
-// log-softmax CE of z[off..off+n) against target tgt: returns -log p_tgt; optionally adds coef*(softmax - onehot) to g
-template <int MAXC, bool GRAD>
-__device__ __forceinline__ float softmax_ce(const float (&z)[MAXC], int off, int n, int tgt, float coef, float (&g)[MAXC]) {
-    float mx = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < MAXC; ++j) if (j >= off && j < off + n) mx = fmaxf(mx, z[j]);
-    float se = 0.f;
-#pragma unroll
-    for (int j = 0; j < MAXC; ++j) if (j >= off && j < off + n) se += expf(z[j] - mx);
-    const float lse = mx + logf(se);
-    float zt = 0.f;
-#pragma unroll
-    for (int j = 0; j < MAXC; ++j) {
-        if (j >= off && j < off + n) {
-            if (j - off == tgt) zt = z[j];
-            if (GRAD) g[j] += coef * (expf(z[j] - lse) - (j - off == tgt ? 1.f : 0.f));
-        }
-    }
-    return lse - zt;
 }
 
 // Per-pixel 2-level terms.  out[0..3] = bce_fine, bce_coarse, ce_fine, ce_coarse.  With GRAD: g[j] += d/dz_j of
@@ -167,23 +102,7 @@ __device__ __forceinline__ void hiera2_pixel(const float (&z)[MAXC], int f, int 
     }
 }
 
-// block reduce NV floats -> partials[blockIdx.x][8]
-template <int NV>
-__device__ __forceinline__ void block_reduce_store(float (&v)[NV], float* __restrict__ partials) {
-    __shared__ float red[NV][4];
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] = wave_sum(v[j]);
-    if ((t & 63) == 0) {
-#pragma unroll
-        for (int j = 0; j < NV; ++j) red[j][t >> 6] = v[j];
-    }
-    __syncthreads();
-    if (t < 8) partials[(long long)blockIdx.x * 8 + t] = t < NV ? (red[t][0] + red[t][1]) + (red[t][2] + red[t][3]) : 0.f;
-}
-
 // ------------------------------------------------------------------------------------------ 2-level forward
-#define LOSS_PIX_PER_BLOCK 1024
 template <int MAXC>
 __global__ __launch_bounds__(256) void hiera2_fwd_kernel(const float* __restrict__ logits, long long ldl, const uint8_t* __restrict__ labels,
                                                          const H2Tab T, float* __restrict__ partials, uint8_t* __restrict__ coarse_out,

@@ -196,3 +196,133 @@ class HieraTripletLoss(nn.Module):
         if cls_score.shape[1] != self.num_classes + len(self.hiera_index):
             raise ValueError("cls_score must have n_fine + n_coarse channels")
         return _Hiera2Fn.apply(cls_score, embedding, ops.labels_u8(label), self, _step_value(step))
+
+
+# ----------------------------------------------------------------------------- 3-level RMI loss
+def three_level_triplet_tables(upper_ids, lower_ids):
+    """Per anchor class ii (rmi_tree_triplet_loss.py:28-47): positives = the other ids of ii's hard-coded group,
+    negatives = the other group; classes 0 and 255 are never anchors.  Deviation: a label outside both groups makes
+    the reference raise ValueError from ``list.remove`` (:39); here such a class is simply not an anchor."""
+    masks = torch.zeros((256, 2, 4), dtype=torch.int64)
+    ok = []
+    for group, other in ((upper_ids, lower_ids), (lower_ids, upper_ids)):
+        for ii in group:
+            if ii == 0 or ii == 255:
+                continue
+            masks[ii, 0] = torch.tensor(_bitset([v for v in group if v != ii]))
+            masks[ii, 1] = torch.tensor(_bitset(list(other)))
+            ok.append(ii)
+    return masks, torch.tensor(_bitset(ok), dtype=torch.int64)
+
+
+class _RMITripletFn(_TripletFn):
+    pass
+
+
+class RMITreeTripletLoss(nn.Module):
+    """``TreeTripletLoss`` of reference ``models/loss/rmi_tree_triplet_loss.py:5-70`` (3-level variant)."""
+
+    def __init__(self, num_classes, upper_ids, lower_ids, ignore_index=IGNORE):
+        super().__init__()
+        self.ignore_label = ignore_index
+        self.num_classes = num_classes
+        self.upper_ids = upper_ids
+        self.lower_ids = lower_ids
+        masks, ok = three_level_triplet_tables(upper_ids, lower_ids)
+        self.register_buffer("_masks", masks, persistent=False)
+        self.register_buffer("_anchor_ok", ok, persistent=False)
+
+    tables = TreeTripletLoss.tables
+
+    def forward(self, feats, labels=None, max_triplet=200):
+        masks, ok = self.tables(feats.device)
+        loss, count = _TripletFn.apply(feats, ops.labels_u8(labels), masks, ok, max_triplet)
+        n = int(count.item())
+        cnt = torch.tensor([n], device=feats.device)
+        return (None, cnt) if n == 0 else (loss, cnt)
+
+
+class _Hiera3Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cls_score, embedding, label8, mod, step):
+        logits = ops.to_nhwc(cls_score)
+        emb = _dense_nhwc(embedding)
+        nf, nm, nh = mod.n_fine, mod.n_mid, mod.n_high
+        f2m, f2h = mod._f2m, mod._f2h
+        lam, lw = mod.loss_weight_lambda, mod.loss_weight
+        need_grad = ctx.needs_input_grad[0]
+        rest, sums, probs = ops.hiera3_fwd(logits, label8, nf, nm, nh, f2m, f2h, want_probs=True)
+        rmi, dprob = ops.rmi_loss(probs, label8, nf, nm, nh, f2m, f2h, want_grad=need_grad)
+        main = ops.scalar_axpy(rest, rmi, lam)
+        masks, ok = mod.triplet_loss.tables(logits.device)
+        trip, ws = ops.triplet_fwd(emb, label8, masks, ok, 200, 0.6)
+        ready = None
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            from . import ddp
+            ready = trip[1:2].clone()
+            ddp.all_reduce(ready, op=torch.distributed.ReduceOp.MIN)
+        factor = triplet_factor(step, 160000 if nf > 15 else 60000)
+        total = ops.combine_loss(main, trip, ready, factor, lw)
+        ctx.save_for_backward(logits, emb, label8, sums, trip, ws, dprob if dprob is not None else sums)
+        ctx.has_dprob = dprob is not None
+        ctx.ready = ready
+        ctx.cfg = (nf, nm, nh, f2m, f2h, lam, lw, factor, logits.shape[0])
+        mod.last_terms = (rest, rmi, trip)
+        return total.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, emb, label8, sums, trip, ws, dprob = ctx.saved_tensors
+        nf, nm, nh, f2m, f2h, lam, lw, factor, batch = ctx.cfg
+        g = g.reshape(1).float()
+        dlogits = None
+        if ctx.needs_input_grad[0]:
+            dlogits = ops.hiera3_bwd(logits, label8, nf, nm, nh, f2m, f2h, sums, dprob if ctx.has_dprob else None,
+                                     lam / (9.0 * batch), g, lw)
+        demb = None
+        if ctx.needs_input_grad[1]:
+            gt = g if ctx.ready is None else g * (ctx.ready > 0).float()
+            demb = ops.triplet_bwd(emb, ws, trip, gt, factor * lw)
+        return dlogits, demb, None, None, None
+
+
+class RMIHieraTripletLoss(nn.Module):
+    """Drop-in for reference ``models/loss/rmi_hiera_triplet_loss.py:180-546`` (same constructor, same forward).
+    ``rmi_pool_way / rmi_pool_size / rmi_pool_stride`` are accepted, asserted equal and never applied -- exactly like
+    the reference; ``rmi_radius`` must be 3 (the only value the kernels implement)."""
+
+    def __init__(self, n_fine: int, n_mid: int, n_high: int, fine_to_mid: torch.Tensor, fine_to_high: torch.Tensor,
+                 rmi_radius: int = 3, rmi_pool_way: int = 0, rmi_pool_size: int = 3, rmi_pool_stride: int = 3,
+                 loss_weight_lambda: float = 0.5, loss_weight: float = 1.0, ignore_index: int = IGNORE):
+        super().__init__()
+        assert fine_to_mid.dtype == torch.long
+        assert fine_to_high.dtype == torch.long
+        assert fine_to_mid.numel() == n_fine
+        assert fine_to_high.numel() == n_fine
+        assert rmi_pool_size == rmi_pool_stride
+        if rmi_radius != 3 or ignore_index != IGNORE:
+            raise SegHieroHipError("the RMI kernels implement rmi_radius == 3 and ignore_index == 255")
+        self.n_fine, self.n_mid, self.n_high = n_fine, n_mid, n_high
+        self.fine_to_mid, self.fine_to_high = fine_to_mid.clone(), fine_to_high.clone()
+        self._f2m, self._f2h = fine_to_mid.tolist(), fine_to_high.tolist()
+        self.ignore_index = ignore_index
+        self.rmi_radius, self.rmi_pool_way = rmi_radius, rmi_pool_way
+        self.rmi_pool_size, self.rmi_pool_stride = rmi_pool_size, rmi_pool_stride
+        if n_fine > 15:
+            self.upper_ids = [1, 2, 3, 4, 5, 6, 7, 10, 11, 13, 14, 15]
+            self.lower_ids = [8, 9, 12, 16, 17, 18, 19]
+        else:
+            self.upper_ids, self.lower_ids = [1, 2, 3, 4], [5, 6]
+        self.loss_weight_lambda, self.loss_weight = loss_weight_lambda, loss_weight
+        self.half_d = rmi_radius * rmi_radius
+        self.d = 2 * self.half_d
+        self.kernel_padding = rmi_pool_size // 2
+        self.ce = CrossEntropyLoss()
+        self.triplet_loss = RMITreeTripletLoss(num_classes=n_fine, upper_ids=self.upper_ids, lower_ids=self.lower_ids,
+                                               ignore_index=ignore_index)
+        self.last_terms = None
+
+    def forward(self, step, embedding, cls_score_before, cls_score, label, weight=None, **kwargs):
+        if cls_score.shape[1] != self.n_fine + self.n_mid + self.n_high:
+            raise ValueError("cls_score must have n_fine + n_mid + n_high channels")
+        return _Hiera3Fn.apply(cls_score, embedding, ops.labels_u8(label), self, _step_value(step))

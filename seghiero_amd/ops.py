@@ -520,3 +520,55 @@ def sgd_step(params, grads, bufs, lr, momentum, weight_decay, first_step, gscale
         na = (ctypes.c_longlong * k)(*[p.numel() for p in ps])
         _call("sh_sgd_step", k, wa, ga, va, na, float(lr), float(momentum), float(weight_decay), int(first_step),
               float(gscale), st)
+
+
+# ----------------------------------------------------------------------------- 3-level loss + RMI
+def _ints(values):
+    vals = [int(v) for v in values]
+    return (ctypes.c_int * max(len(vals), 1))(*vals)
+
+
+def hiera3_fwd(logits, labels8, n_fine, n_mid, n_high, f2m, f2h, want_probs):
+    """-> (loss_rest[1] f32, sums[8] f64, probs planar [N,C,H,W] or None)."""
+    n, c, h, w = logits.shape
+    _, H, W = labels8.shape
+    lp, ldl = pm(logits)
+    dev = logits.device
+    nblk = LIB.raw("sh_hiera2_partials")(n, H, W)
+    partials = torch.empty((nblk, 8), device=dev, dtype=torch.float32)
+    sums = torch.empty((8,), device=dev, dtype=torch.float64)
+    loss = torch.empty((1,), device=dev, dtype=torch.float32)
+    probs = torch.empty((n, c, H, W), device=dev, dtype=torch.float32) if want_probs else None
+    _call("sh_hiera3_loss_fwd", lp, ldl, labels8.data_ptr(), _ints(f2m), _ints(f2h), n_fine, n_mid, n_high, sums.data_ptr(),
+          loss.data_ptr(), partials.data_ptr(), None if probs is None else probs.data_ptr(), n, h, w, H, W, _st())
+    return loss, sums, probs
+
+
+def rmi_loss(probs, labels8, n_fine, n_mid, n_high, f2m, f2h, want_grad):
+    """-> (rmi[1] f32, dprob planar or None)."""
+    n, c, H, W = probs.shape
+    need = LIB.raw("sh_rmi_workspace")(n, c, H, W)
+    ws = workspace(need, probs.device, "rmi")
+    out = torch.empty((1,), device=probs.device, dtype=torch.float32)
+    dprob = torch.empty_like(probs) if want_grad else None
+    _call("sh_rmi_loss", probs.data_ptr(), labels8.data_ptr(), _ints(f2m), _ints(f2h), n_fine, n_mid, n_high, ws.data_ptr(),
+          out.data_ptr(), None if dprob is None else dprob.data_ptr(), n, H, W, _st())
+    return out, dprob
+
+
+def hiera3_bwd(logits, labels8, n_fine, n_mid, n_high, f2m, f2h, sums, dprob, rmi_coef, gscale_dev, gscale):
+    n, c, h, w = logits.shape
+    _, H, W = labels8.shape
+    lp, ldl = pm(logits)
+    d = new_act(n, c, h, w, logits.device, ld=pad4(c))
+    dp, ldd = pm(d)
+    _call("sh_hiera3_loss_bwd", lp, ldl, labels8.data_ptr(), _ints(f2m), _ints(f2h), n_fine, n_mid, n_high, sums.data_ptr(),
+          None if dprob is None else dprob.data_ptr(), float(rmi_coef), None if gscale_dev is None else gscale_dev.data_ptr(),
+          float(gscale), dp, ldd, n, h, w, H, W, _st())
+    return d
+
+
+def scalar_axpy(a, b, alpha):
+    out = torch.empty((1,), device=a.device, dtype=torch.float32)
+    _call("sh_scalar_axpy", a.data_ptr(), b.data_ptr(), float(alpha), out.data_ptr(), _st())
+    return out

@@ -18,8 +18,8 @@ import torch.nn as nn
 from . import ops
 from .backbone import ResNetBackbone
 from .head import AuxHead, DepthwiseSeparableASPPContrastHead
-from .hierarchy import build_fine_to_coarse_map, build_hiera_index
-from .loss import HieraTripletLoss
+from .hierarchy import build_fine_to_coarse_map, build_fine_to_super_map, build_hiera_index
+from .loss import HieraTripletLoss, RMIHieraTripletLoss
 from .sgd import FusedSGD
 
 
@@ -45,19 +45,29 @@ def aux_ce_loss(aux_logits, label):
 
 class SegHieroTrainer:
     def __init__(self, depth=50, n_fine=9, coarse_to_fine_map=((0, 3), (4, 6), (7,), (8,)), lr=0.01, fine_weight=1.0,
-                 device="cuda:0", head_kw=None, grad_sync=None):
+                 device="cuda:0", head_kw=None, grad_sync=None, super_coarse_to_coarse_map=None, rmi_radius=3):
+        """``super_coarse_to_coarse_map`` given -> 3-level model + RMIHieraTripletLoss (train.py:202-233), else the
+        2-level HieraTripletLoss (train.py:176-200)."""
         cfg_map = [list(x) for x in coarse_to_fine_map]
+        sup_map = None if super_coarse_to_coarse_map is None else [list(x) for x in super_coarse_to_coarse_map]
         self.n_fine, self.n_coarse = n_fine, len(cfg_map)
+        self.n_super = 0 if sup_map is None else len(sup_map)
         self.device = torch.device(device)
         self.backbone = ResNetBackbone(depth=depth, pretrained=False)
         ch = self.backbone.out_channels
         kw = dict(in_channels=ch[3], c1_in_channels=ch[0], c1_channels=48, aspp_channels=512,
-                  dilations=(1, 12, 24, 36), num_classes=n_fine + self.n_coarse, proj_dim=256, proj_type="convmlp")
+                  dilations=(1, 12, 24, 36), num_classes=n_fine + self.n_coarse + self.n_super, proj_dim=256,
+                  proj_type="convmlp")
         kw.update(head_kw or {})
         self.aspp_head = DepthwiseSeparableASPPContrastHead(**kw)
         self.aux_head = AuxHead(ch[2], n_fine)
-        self.hiera_loss_fn = HieraTripletLoss(num_classes=n_fine, hiera_map=build_fine_to_coarse_map(cfg_map, n_fine).tolist(),
-                                              hiera_index=build_hiera_index(cfg_map), loss_weight=fine_weight)
+        if sup_map is None:
+            self.hiera_loss_fn = HieraTripletLoss(num_classes=n_fine, hiera_map=build_fine_to_coarse_map(cfg_map, n_fine).tolist(),
+                                                  hiera_index=build_hiera_index(cfg_map), loss_weight=fine_weight)
+        else:   # train.py:226-233: loss_weight_lambda = training.fine_weight, loss_weight = 1.0
+            self.hiera_loss_fn = RMIHieraTripletLoss(n_fine, self.n_coarse, self.n_super, build_fine_to_coarse_map(cfg_map, n_fine),
+                                                     build_fine_to_super_map(sup_map, n_fine), rmi_radius=rmi_radius,
+                                                     loss_weight_lambda=fine_weight, loss_weight=1.0)
         for m in (self.backbone, self.aspp_head, self.aux_head, self.hiera_loss_fn):
             m.to(self.device)
         self.params = list(self.backbone.parameters()) + list(self.aspp_head.parameters()) + list(self.aux_head.parameters())

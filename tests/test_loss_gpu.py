@@ -174,3 +174,60 @@ def test_pixel_metrics(sa):
     # argmax over interpolated logits can flip on exact ties only; counts must agree exactly on this seeded input
     assert int(counts[0]) == c
     assert torch.equal(counts[2:].reshape(9, 9), cm)
+
+
+# ---------------------------------------------------------------- 3-level RMI loss vs the reference goldens (G6, G7)
+F2M, F2H = [0, 1, 1, 1, 1, 2, 2], [0, 1, 1, 1, 1, 1, 1]
+
+
+@pytest.mark.parametrize("tag", ["even", "odd"])
+@pytest.mark.parametrize("lam", [0.0, 0.5])
+@pytest.mark.parametrize("step", [0, 30000])
+def test_rmi_hiera_triplet_loss_g6(sa, tag, lam, step):
+    """Loss rtol 1e-5; gradient w.r.t. the logits rtol 2e-3 of the tensor's max (f64 Gram matrices are near-singular and
+    the reference differentiates through log(diag(chol)+1e-8) while the kernel uses the closed form)."""
+    _, loss, ops = sa
+    g = load_golden("g6_rmi_hiera_triplet_loss")
+    fn = loss.RMIHieraTripletLoss(7, 3, 2, torch.tensor(F2M), torch.tensor(F2H), loss_weight_lambda=lam).to(DEV)
+    z = T(g[f"{tag}_z"]).to(DEV).requires_grad_(True)
+    e = T(g[f"{tag}_emb"]).to(DEV).requires_grad_(True)
+    val = fn(torch.tensor([step]), e, None, z, lab(g[f"{tag}_lab"]).to(DEV))
+    val.backward()
+    key = f"{tag}_lam{lam}_s{step}"
+    close(val, g[f"{key}_loss"], 1e-5, 0)
+    ref = g[f"{key}_dz"]
+    np.testing.assert_allclose(z.grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * float(np.abs(ref).max()))
+    close(e.grad, g[f"{key}_demb"], 1e-4, 1e-8)
+
+
+def test_rmi_triplet_g7(sa):
+    _, loss, ops = sa
+    g = load_golden("g7_rmi_triplet")
+    trip = loss.RMITreeTripletLoss(7, [1, 2, 3, 4], [5, 6])
+    emb = T(g["emb"]).to(DEV).requires_grad_(True)
+    val, cnt = trip(emb, lab(g["lab"]).to(DEV))
+    assert np.array_equal(cnt.cpu().numpy(), g["cnt"])
+    val.backward()
+    close(val, g["val"], 1e-5, 0)
+    close(emb.grad, g["demb"], 1e-4, 1e-8)
+
+
+def test_rmi_loss_fused_resize_matches_oracle(sa):
+    """Low-resolution logits + fused x4 resize (the train-step path) vs oracle(F.interpolate(...))."""
+    _, loss, ops = sa
+    from oracle import losses as ol
+    g = torch.Generator().manual_seed(77)
+    z = 1.5 * torch.randn(2, 12, 16, 16, generator=g)
+    e = F.normalize(torch.randn(2, 16, 4, 4, generator=g), dim=1)
+    label = _blocky(g, 2, 64, 64, 7, cell=8)
+    zr, er = z.clone().requires_grad_(True), e.clone().requires_grad_(True)
+    ref = ol.RMIHieraTripletLoss(7, 3, 2, torch.tensor(F2M), torch.tensor(F2H))(
+        torch.tensor([20000]), er, None, F.interpolate(zr, size=(64, 64), mode="bilinear", align_corners=False), label)
+    ref.backward()
+    zg, eg = z.to(DEV).requires_grad_(True), e.to(DEV).requires_grad_(True)
+    val = loss.RMIHieraTripletLoss(7, 3, 2, torch.tensor(F2M), torch.tensor(F2H)).to(DEV)(20000, eg, None, zg, label.to(DEV))
+    val.backward()
+    close(val, ref, 1e-5, 0)
+    r = zr.grad.numpy()
+    np.testing.assert_allclose(zg.grad.cpu().numpy(), r, rtol=2e-3, atol=2e-3 * float(np.abs(r).max()))
+    close(eg.grad, er.grad, 1e-4, 1e-8)

@@ -195,3 +195,28 @@ def test_train_steps_match_oracle_config1(sa):
     counts = counts.cpu()
     assert int(counts[1]) == valid
     assert abs(int(counts[0]) - correct) <= max(2, valid // 10000)     # argmax may flip on near-ties only
+
+
+def test_three_level_rmi_train_step_config4_family(sa):
+    """BASELINE config 4 family (7 fine / 3 mid / 2 high, RMIHieraTripletLoss) on ResNet-18 at 96x96, B=4: step-0 loss
+    within 1e-4 of the oracle; two SGD steps stay within 4x the fp32 oracle's own distance from its fp64 trajectory."""
+    from oracle.step import OracleTrainer
+    from seghiero_amd.synthetic import make_batch
+    from seghiero_amd.train_step import SegHieroTrainer
+    torch.manual_seed(1)
+    kw = dict(depth=18, n_fine=7, coarse_to_fine_map=[[0], [1, 4], [5, 6]], super_coarse_to_coarse_map=[[0], [1, 6]], lr=0.01,
+              fine_weight=0.5)
+    ref = OracleTrainer(**kw)
+    ref64 = _oracle64(ref, kw)
+    mine = SegHieroTrainer(device=DEV, **kw)
+    assert mine.aspp_head.cls_seg.out_channels == 12
+    mine.load_state_dicts(ref.state_dicts())
+    ref.train(); mine.train(); ref64.train()
+    for step in range(2):
+        img, lab = make_batch(4, 96, 7, seed=40 + step)
+        l32 = float(ref.train_step(img, lab, epoch=step))
+        l64 = float(ref64.train_step(img.double(), lab, epoch=step))
+        lm = float(mine.train_step(img.to(DEV), lab.to(DEV), epoch=step))
+        if step == 0:
+            assert abs(lm - l32) < 1e-4 * max(1.0, abs(l32)), (lm, l32)
+        assert abs(lm - l64) < 4 * abs(l32 - l64) + 1e-4 * max(1.0, abs(l64)), (step, lm, l32, l64)
