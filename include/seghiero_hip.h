@@ -61,6 +61,28 @@ int sh_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw,
                   int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                   int dil, void* stream);
 
+/* The same three GEMMs on the bf16 matrix cores with an exact 3-way bf16 split of every fp32 operand and six
+ * v_mfma_f32_32x32x16_bf16 products per term (fp32-class accuracy, 2.7x fewer MFMA cycles than the f32 MFMA; see
+ * csrc/conv_bf16x6.hip).  Same arguments, except that `w` / `wt` are the pre-split bf16 weight planes made by
+ * sh_weight_split (mode 0 for fprop, mode 1 for dgrad); dgrad needs lddy >= pad4(Cout) with zeroed padding lanes. */
+int sh_conv_fprop_x6(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
+                     float* stat_partials, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                     int stride, int pad, int dil, void* stream);
+int sh_weight_transpose(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream);
+/* Pre-split weights into three bf16 planes (exact 3-way split), rows zero-padded to a multiple of 32:
+ * mode 0: [3][Cout][round32(KH*KW*Cin)] for sh_conv_fprop_x6; mode 1: [3][KH*KW*Cin][round32(pad4(Cout))] for
+ * sh_conv_dgrad_x6.  Buffer size: sh_weight_split_bytes. */
+int64_t sh_weight_split_bytes(int Cout, int KH, int KW, int Cin, int mode);
+int sh_weight_split(const float* w, void* planes, int Cout, int KH, int KW, int Cin, int mode, void* stream);
+int sh_conv_dgrad_x6(const float* dy, int lddy, const float* wt, const float* addend, int ldadd,
+                     float* dx, int lddx, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                     int stride, int pad, int dil, int mode, void* stream);
+int64_t sh_conv_wgrad_x6_workspace(int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                   int stride, int pad, int dil);
+int sh_conv_wgrad_x6(const float* x, int ldx, const float* dy, int lddy, float* dw, float* workspace,
+                     int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                     int dil, void* stream);
+
 /* depthwise 3x3 (groups = C), stride 1, padding = dilation ---------------------------------- */
 /* Replaces DepthwiseSeparableConv.depthwise (models/head/sep_aspp_contrast_head.py:43-46, :56).
  * w is [C][3][3].  stat_partials: [sh_dw_partials(N,H,W)][2][C]. */

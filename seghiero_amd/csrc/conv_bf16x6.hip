@@ -1,0 +1,657 @@
+// fp32-accurate convolution GEMMs on the bf16 matrix cores ("6 x bf16 split").
+//
+// gfx950's f32 MFMA runs at the vector rate (157 TF); its bf16 MFMA is 16x faster.  Every fp32 operand x is split
+// exactly into three bf16 terms x = x1 + x2 + x3 (8 significand bits each, by truncation: x1 = hi16(x), x2 = hi16(x-x1),
+// x3 = hi16(x-x1-x2); the subtractions are exact in fp32), and a product is evaluated as
+//     a*b ~= a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1          (dropped terms <= 3 * 2^-24 |ab|)
+// with six v_mfma_f32_32x32x16_bf16 accumulating in fp32: 192 MFMA cycles per K=16 instead of 512 for the f32 MFMA,
+// at fp32-class accuracy (validated by the same parity tests as the f32 kernels, tests/test_ops_gpu.py).
+//
+// Structure: same implicit-GEMM tiling / loaders / epilogues as conv_gemm.hip.  Global fp32 -> registers -> split ->
+// three bf16 LDS planes per operand ([row][32 k] with 80-byte rows: conflict-free 16-byte fragment reads).  FPROP and
+// DGRAD have K-contiguous operands (DGRAD reads a per-step transposed weight copy [tap][ci][co]); WGRAD's operands are
+// pixel-major, so its planes are stored [k][m] and the fragments are read with ds_read_b64_tr_b16 (hardware transpose).
+#include "common.h"
+
+enum { FPROP = 0, DGRAD = 1 };
+
+struct ConvQ {
+    const float* a;
+    const float* b;
+    float* c;
+    const float* extra;     // fprop: bias[Cout] ; dgrad: addend[M][ldadd]
+    float* partials;
+    long long lda, ldb, ldc, ldadd;
+    int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, dil;
+    int M, Nn, K, Kc;       // Kc = channels per tap along K (Cin for fprop, padded Cout for dgrad)
+    int Kp;                 // row length (in k) of the pre-split B planes (multiple of 32)
+    int Kreal;              // channels actually present per tap in the A rows (dgrad: pad4(Cout); fprop: Cin)
+    long long bplane;       // elements per B plane
+    int scatter, sH, sW, sstride;
+    int kchunk;
+    int tiles_m, tiles_n, n_partials;
+};
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// exact 3-way split of 4 floats -> three packed bf16x4 (8 bytes each)
+__device__ __forceinline__ void split4(const f32x4 v, u32x2& p1, u32x2& p2, u32x2& p3) {
+    unsigned h1[4], h2[4], h3[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned u = __float_as_uint(v[j]);
+        const float r1 = v[j] - __uint_as_float(u & 0xffff0000u);
+        const unsigned u2 = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(u2 & 0xffff0000u);
+        h1[j] = u; h2[j] = u2; h3[j] = __float_as_uint(r2);
+    }
+    // perm(S0, S1, 0x07060302) = (S0 & 0xffff0000) | (S1 >> 16): element j in the low half, j+1 in the high half
+    p1[0] = __builtin_amdgcn_perm(h1[1], h1[0], 0x07060302u); p1[1] = __builtin_amdgcn_perm(h1[3], h1[2], 0x07060302u);
+    p2[0] = __builtin_amdgcn_perm(h2[1], h2[0], 0x07060302u); p2[1] = __builtin_amdgcn_perm(h2[3], h2[2], 0x07060302u);
+    p3[0] = __builtin_amdgcn_perm(h3[1], h3[0], 0x07060302u); p3[1] = __builtin_amdgcn_perm(h3[3], h3[2], 0x07060302u);
+}
+
+#define ROWB 80            // bytes per LDS row of a K-contiguous plane (64 data + 16 pad)
+
+// six-product accumulate of one 32x32 tile over K=16
+__device__ __forceinline__ f32x16 mma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c) {
+    c = mfma_bf16(a[2], b[0], c);      // smallest terms first
+    c = mfma_bf16(a[0], b[2], c);
+    c = mfma_bf16(a[1], b[1], c);
+    c = mfma_bf16(a[1], b[0], c);
+    c = mfma_bf16(a[0], b[1], c);
+    c = mfma_bf16(a[0], b[0], c);
+    return c;
+}
+
+// ============================================================================================ FPROP / DGRAD
+template <int MODE, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvQ p) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32;
+    constexpr int A_PLANE = BM * ROWB, B_PLANE = BN * ROWB;      // bytes
+    constexpr int NA = 2 * TM;                                   // A float4 per thread per tile
+    constexpr int NBV = BN / 64;                                 // B 16-byte chunks per thread per plane per tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* As = smem;                       // [3][BM][80]
+    unsigned char* Bs = smem + 3 * A_PLANE;         // [3][BN][80]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const unsigned nblk = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+    const unsigned bid = xcd_remap(blockIdx.x, nblk);
+    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nkt = (p.K + BK - 1) / BK;
+    const bool tap_uniform = (p.Kc & 31) == 0;      // a K tile never straddles taps: tap arithmetic stays on the scalar unit
+    const bool single_tap = p.KH * p.KW == 1;
+
+    const int kc = t & 7, r0 = t >> 3;
+    int a_y[NA], a_x[NA], a_nb[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        if (m < p.M) {
+            if constexpr (MODE == FPROP) {
+                const int ow = m % p.Wo, q = m / p.Wo, oh = q % p.Ho, n = q / p.Ho;
+                a_y[i] = oh * p.stride - p.pad; a_x[i] = ow * p.stride - p.pad; a_nb[i] = n * p.H * p.W;
+            } else {
+                const int iw = m % p.W, q = m / p.W, ih = q % p.H, n = q / p.H;
+                a_y[i] = ih + p.pad; a_x[i] = iw + p.pad; a_nb[i] = n * p.Ho * p.Wo;
+            }
+        } else { a_y[i] = -(1 << 28); a_x[i] = 0; a_nb[i] = 0; }
+    }
+    // per-row element offsets of the current tap (recomputed only when the tap changes; never for 1x1 convs)
+    long long a_off[NA];
+    bool a_ok[NA];
+    int cur_tap = -1;
+    auto set_tap = [&](int tap) {
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        const int dh = kh * p.dil, dw = kw * p.dil;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if constexpr (MODE == FPROP) {
+                const int ih = a_y[i] + dh, iw = a_x[i] + dw;
+                a_ok[i] = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                a_off[i] = (long long)(a_nb[i] + ih * p.W + iw) * p.lda;
+            } else {
+                int th = a_y[i] - dh, tw = a_x[i] - dw;
+                bool ok = th >= 0 && tw >= 0;
+                if (p.stride > 1) {
+                    ok = ok && (th % p.stride == 0) && (tw % p.stride == 0);
+                    th /= p.stride; tw /= p.stride;
+                }
+                a_ok[i] = ok && th < p.Ho && tw < p.Wo;
+                a_off[i] = (long long)(a_nb[i] + th * p.Wo + tw) * p.lda;
+            }
+        }
+    };
+    // B: pre-split bf16 planes [3][rows][Kp]; thread -> (row = idx>>2, 16-byte chunk = idx&3), idx = t + 256*i
+    const unsigned short* bq = reinterpret_cast<const unsigned short*>(p.b);
+
+    struct Stage { f32x4 ra[NA]; u32x4 rbq[3][NBV]; };
+    Stage S0, S1;                                    // two tiles in flight (global-load latency > one tile's MFMA time)
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const u32x4 zq = {0u, 0u, 0u, 0u};
+
+    auto load_tile = [&](int kt, Stage& S) {
+        const int kbase = kt * BK;
+        int tap, cc;
+        if (single_tap) { tap = 0; cc = kbase + 4 * kc; }
+        else if (tap_uniform) { tap = kbase / p.Kc; cc = kbase - tap * p.Kc + 4 * kc; }
+        else { const int k = kbase + 4 * kc; tap = k / p.Kc; cc = k - tap * p.Kc; }
+        const bool kok = (kbase + 4 * kc) < p.K && cc < p.Kreal;
+        if (!(single_tap || tap_uniform) || tap != cur_tap) { set_tap(tap); cur_tap = tap; }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) S.ra[i] = (kok && a_ok[i]) ? ld4(p.a + a_off[i] + cc) : zero4;
+        // B rows: fprop W planes [Cout][Kp] (k linear over taps); dgrad Wt planes [tap*Cin + ci][Kp] (k within the tap)
+        const int btap = single_tap ? 0 : kbase / p.Kc;     // block-uniform (dgrad always has Kc % 32 == 0)
+#pragma unroll
+        for (int i = 0; i < NBV; ++i) {
+            const int idx = t + 256 * i, row = idx >> 2, c16 = idx & 3;
+            const int j = n0 + row;
+            long long off;
+            if constexpr (MODE == FPROP) off = (long long)j * p.Kp + kbase + 8 * c16;
+            else off = ((long long)btap * p.Cin + j) * p.Kp + (kbase - btap * p.Kc) + 8 * c16;
+            const bool ok = j < p.Nn;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                S.rbq[pl][i] = ok ? *reinterpret_cast<const u32x4*>(bq + pl * p.bplane + off) : zq;
+        }
+    };
+    auto store_tile = [&](const Stage& S) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            u32x2 q1, q2, q3;
+            split4(S.ra[i], q1, q2, q3);
+            const int off = (r0 + 32 * i) * ROWB + kc * 8;
+            *reinterpret_cast<u32x2*>(As + off) = q1;
+            *reinterpret_cast<u32x2*>(As + A_PLANE + off) = q2;
+            *reinterpret_cast<u32x2*>(As + 2 * A_PLANE + off) = q3;
+        }
+#pragma unroll
+        for (int i = 0; i < NBV; ++i) {
+            const int idx = t + 256 * i, row = idx >> 2, c16 = idx & 3;
+            const int off = row * ROWB + c16 * 16;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(Bs + pl * B_PLANE + off) = S.rbq[pl][i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int arow = wm * 32 * TM + l31, brow = wn * 32 * TN + l31;
+    auto compute = [&]() {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[TM][3], bfr[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    af[i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + pl * A_PLANE + (arow + 32 * i) * ROWB + (2 * s + h) * 16));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    bfr[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + pl * B_PLANE + (brow + 32 * j) * ROWB + (2 * s + h) * 16));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mma6(af[i], bfr[j], acc[i][j]);
+        }
+    };
+    load_tile(0, S0);
+    if (nkt > 1) load_tile(1, S1);
+    store_tile(S0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt += 2) {
+        // LDS holds tile kt, S1 holds tile kt+1 (in flight), S0 is free
+        if (kt + 2 < nkt) load_tile(kt + 2, S0);
+        compute();
+        __syncthreads();                      // every wave is done reading the LDS planes
+        if (kt + 1 < nkt) {
+            store_tile(S1);
+            __syncthreads();
+            if (kt + 3 < nkt) load_tile(kt + 3, S1);
+            compute();
+            __syncthreads();
+            if (kt + 2 < nkt) { store_tile(S0); __syncthreads(); }
+        }
+    }
+
+    // ------------------------------------------------------------------ epilogue (same as conv_gemm.hip)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * 32 * TN + 32 * j + l31;
+        const bool nok = n < p.Nn;
+        float bias = 0.f;
+        if constexpr (MODE == FPROP) bias = (p.extra != nullptr && nok) ? p.extra[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 32 * TM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < p.M && nok) {
+                    if constexpr (MODE == FPROP) {
+                        p.c[(long long)m * p.ldc + n] = acc[i][j][r] + bias;
+                    } else {
+                        float v = acc[i][j][r];
+                        if (p.extra != nullptr) v += p.extra[(long long)m * p.ldadd + n];
+                        if (p.scatter) {
+                            const int ow = m % p.W, q = m / p.W, oh = q % p.H, nb = q / p.H;
+                            float* dst = p.c + ((long long)(nb * p.sH + oh * p.sstride) * p.sW + ow * p.sstride) * p.ldc + n;
+                            *dst += v;
+                        } else {
+                            p.c[(long long)m * p.ldc + n] = v;
+                        }
+                    }
+                }
+            }
+    }
+    if constexpr (MODE == FPROP) {
+        if (p.partials != nullptr) {
+            const int wrow0 = m0 + wm * 32 * TM;
+            const int nw = max(0, min(32 * TM, p.M - wrow0));
+            float s[TN], q[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float ss = 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ss += acc[i][j][r];
+                ss += __shfl_xor(ss, 32, 64);
+                const float mean = nw > 0 ? ss / (float)nw : 0.f;
+                float qq = 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = wrow0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const float dv = acc[i][j][r] - mean;
+                        qq += (nw == 32 * TM || row < p.M) ? dv * dv : 0.f;
+                    }
+                qq += __shfl_xor(qq, 32, 64);
+                s[j] = ss; q[j] = qq;
+            }
+            if constexpr (TM == 2) {
+                const int pidx = tile_m * 2 + wm;
+                if (h == 0 && pidx < p.n_partials) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int n = n0 + wn * 32 * TN + 32 * j + l31;
+                        if (n < p.Nn) {
+                            p.partials[((long long)pidx * 2 + 0) * p.Nn + n] = s[j];
+                            p.partials[((long long)pidx * 2 + 1) * p.Nn + n] = q[j];
+                        }
+                    }
+                }
+            } else {
+                float* red = reinterpret_cast<float*>(smem);      // main loop ended with a barrier
+                if (h == 0) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int c = wn * 32 * TN + 32 * j + l31;
+                        red[(wm * 2 + 0) * BN + c] = s[j];
+                        red[(wm * 2 + 1) * BN + c] = q[j];
+                    }
+                }
+                __syncthreads();
+                if (t < BN) {
+                    const int n = n0 + t;
+                    if (n < p.Nn) {
+                        const float na = (float)max(0, min(32, p.M - m0)), nb = (float)max(0, min(32, p.M - m0 - 32));
+                        const float sa = red[t], sb = red[2 * BN + t];
+                        float m2 = red[BN + t] + red[3 * BN + t];
+                        if (nb > 0.f) { const float dm = sa / na - sb / nb; m2 += dm * dm * na * nb / (na + nb); }
+                        p.partials[((long long)tile_m * 2 + 0) * p.Nn + n] = sa + sb;
+                        p.partials[((long long)tile_m * 2 + 1) * p.Nn + n] = m2;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ============================================================================================ WGRAD (transposing LDS reads)
+// dW[co][n'] = sum_pix dY[pix][co] * im2col(X)[pix][n'];  planes stored [k = pixel][row], 320-byte rows
+// (256 data + 64 pad => the four k-rows of a ds_read_b64_tr_b16 block land on disjoint banks).
+#define TROWB 320
+__global__ __launch_bounds__(256, 2) void conv_wgrad_x6_kernel(const ConvQ p) {
+    constexpr int BM = 128, BN = 128, BK = 32;
+    constexpr int PLANE = BK * TROWB;                // 10240 bytes
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* As = smem;                        // [3][32][320]
+    unsigned char* Bs = smem + 3 * PLANE;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const unsigned nblk = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+    const unsigned bid = xcd_remap(blockIdx.x, nblk);
+    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = blockIdx.y * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
+    const int nkt = (kend - kbeg + BK - 1) / BK;
+
+    const int rc = t & 31, k0 = t >> 5;              // float4 column chunk, k-row (8 rows per pass, 4 passes)
+    const int nn = n0 + 4 * rc;
+    const bool wg_ok = nn < p.Nn;
+    const int tap = nn / p.Cin, wg_ci = nn - tap * p.Cin;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int wg_dh = kh * p.dil - p.pad, wg_dw = kw * p.dil - p.pad;
+    const int co = m0 + 4 * rc;
+
+    struct Stage { f32x4 ra[4], rb[4]; };
+    Stage S0, S1;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // pixel coordinates of this thread's 4 k-rows, advanced by 32 pixels per K tile (no divisions in the loop)
+    int px_ow[4], px_oh[4], px_n[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pix = kbeg + k0 + 8 * i;
+        px_ow[i] = pix % p.Wo; const int q2 = pix / p.Wo; px_oh[i] = q2 % p.Ho; px_n[i] = q2 / p.Ho;
+    }
+    auto load_tile = [&](int kt, Stage& S) {
+        const int kbase = kbeg + kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pix = kbase + k0 + 8 * i;
+            const bool pok = pix < kend;
+            S.ra[i] = (pok && co < p.M) ? ld4(p.a + (long long)pix * p.lda + co) : zero4;
+            const int ih = px_oh[i] * p.stride + wg_dh, iw = px_ow[i] * p.stride + wg_dw;
+            const bool ok = pok && wg_ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            S.rb[i] = ok ? ld4(p.b + ((long long)(px_n[i] * p.H + ih) * p.W + iw) * p.ldb + wg_ci) : zero4;
+            px_ow[i] += BK;
+            while (px_ow[i] >= p.Wo) { px_ow[i] -= p.Wo; ++px_oh[i]; }
+            while (px_oh[i] >= p.Ho) { px_oh[i] -= p.Ho; ++px_n[i]; }
+        }
+    };
+    auto store_tile = [&](const Stage& S) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int off = (k0 + 8 * i) * TROWB + rc * 8;
+            u32x2 q1, q2, q3;
+            split4(S.ra[i], q1, q2, q3);
+            *reinterpret_cast<u32x2*>(As + off) = q1;
+            *reinterpret_cast<u32x2*>(As + PLANE + off) = q2;
+            *reinterpret_cast<u32x2*>(As + 2 * PLANE + off) = q3;
+            split4(S.rb[i], q1, q2, q3);
+            *reinterpret_cast<u32x2*>(Bs + off) = q1;
+            *reinterpret_cast<u32x2*>(Bs + PLANE + off) = q2;
+            *reinterpret_cast<u32x2*>(Bs + 2 * PLANE + off) = q3;
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transpose-read addressing: 16-lane group g -> (row half g&1, k half g>>1); lane 4q+pp supplies row q, columns 4pp..4pp+3
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const int tr_off = ((g >> 1) * 8 + q) * TROWB + (16 * (g & 1) + 4 * pp) * 2;   // + s*16*TROWB (+4*TROWB for k+4) + row base*2
+    auto frag = [&](const unsigned char* plane, int s, int rowbase) -> bf16x8 {
+        const unsigned char* a0 = plane + tr_off + s * 16 * TROWB + rowbase * 2;
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0 + 4 * TROWB));
+        s16x8 r;
+        r[0] = v0[0]; r[1] = v0[1]; r[2] = v0[2]; r[3] = v0[3]; r[4] = v1[0]; r[5] = v1[1]; r[6] = v1[2]; r[7] = v1[3];
+        return __builtin_bit_cast(bf16x8, r);
+    };
+
+    auto compute = [&]() {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[2][3], bfr[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    af[i][pl] = frag(As + pl * PLANE, s, wm * 64 + 32 * i);
+                    bfr[i][pl] = frag(Bs + pl * PLANE, s, wn * 64 + 32 * i);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mma6(af[i], bfr[j], acc[i][j]);
+        }
+    };
+    if (nkt > 0) {
+        load_tile(0, S0);
+        if (nkt > 1) load_tile(1, S1);
+        store_tile(S0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt += 2) {
+        if (kt + 2 < nkt) load_tile(kt + 2, S0);
+        compute();
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            store_tile(S1);
+            __syncthreads();
+            if (kt + 3 < nkt) load_tile(kt + 3, S1);
+            compute();
+            __syncthreads();
+            if (kt + 2 < nkt) { store_tile(S0); __syncthreads(); }
+        }
+    }
+    float* slab = p.c + (long long)blockIdx.y * p.M * p.Nn;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + 32 * j + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < p.M && n < p.Nn) slab[(long long)m * p.Nn + n] = acc[i][j][r];
+            }
+        }
+}
+
+// slab reduce (same as conv_gemm.hip)
+__global__ __launch_bounds__(256) void slab_reduce_x6_kernel(const float* __restrict__ slab, float* __restrict__ dw, long long n4, long long n, int S) {
+    __shared__ f32x4 red[4][64];
+    const int t = threadIdx.x, cl = t & 63, g = t >> 6;
+    const long long i = (long long)blockIdx.x * 64 + cl;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4) {
+#pragma unroll 4
+        for (int k = g; k < S; k += 4) s += ld4(slab + (long long)k * n + 4 * i);
+    }
+    red[g][cl] = s;
+    __syncthreads();
+    if (t < 64 && i < n4) st4(dw + 4 * i, (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]));
+}
+
+// Wt[tap][ci][CoutP] <- W[co][tap][ci]   (zero padded to CoutP = pad4(Cout))
+__global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int T, int Cin, int CoutP) {
+    const long long total = (long long)T * Cin * CoutP;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int co = (int)(i % CoutP);
+        const long long q = i / CoutP;
+        const int ci = (int)(q % Cin), tap = (int)(q / Cin);
+        wt[i] = co < Cout ? w[((long long)co * T + tap) * Cin + ci] : 0.f;
+    }
+}
+// Pre-split weights into three bf16 planes, K-contiguous rows of length Kp (multiple of 32, zero padded):
+//   mode 0 (fprop): planes[pl][co][Kp]            from W[co][K]           (rows = Cout, K = T*Cin)
+//   mode 1 (dgrad): planes[pl][tap*Cin + ci][Kp]  from W[co][tap][ci]     (rows = T*Cin, per-tap K = Cout)
+__global__ __launch_bounds__(256) void weight_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes, int Cout, int T,
+                                                          int Cin, int Kp, int mode, long long rows) {
+    const long long total = rows * Kp, plane = total;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int k = (int)(i % Kp);
+        const long long row = i / Kp;
+        float v = 0.f;
+        if (mode == 0) { if (k < T * Cin) v = w[row * (long long)(T * Cin) + k]; }
+        else { const int ci = (int)(row % Cin), tap = (int)(row / Cin); if (k < Cout) v = w[((long long)k * T + tap) * Cin + ci]; }
+        const unsigned u = __float_as_uint(v);
+        const float r1 = v - __uint_as_float(u & 0xffff0000u);
+        const unsigned u2 = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(u2 & 0xffff0000u);
+        planes[i] = (unsigned short)(u >> 16);
+        planes[plane + i] = (unsigned short)(u2 >> 16);
+        planes[2 * plane + i] = (unsigned short)(__float_as_uint(r2) >> 16);
+    }
+}
+static inline int round32(int v) { return (v + 31) & ~31; }
+// bytes of the plane buffer for sh_weight_split
+extern "C" int64_t sh_weight_split_bytes(int Cout, int KH, int KW, int Cin, int mode) {
+    if (Cout <= 0 || KH <= 0 || KW <= 0 || Cin <= 0) return SH_EINVAL;
+    const long long rows = mode == 0 ? Cout : (long long)KH * KW * Cin;
+    const int Kp = mode == 0 ? round32(KH * KW * Cin) : round32((Cout + 3) & ~3);
+    return 3 * rows * Kp * 2;
+}
+extern "C" int sh_weight_split(const float* w, void* planes, int Cout, int KH, int KW, int Cin, int mode, void* stream) {
+    if (!w || !planes || Cout <= 0 || KH <= 0 || KW <= 0 || Cin <= 0 || (mode != 0 && mode != 1)) return SH_EINVAL;
+    const long long rows = mode == 0 ? Cout : (long long)KH * KW * Cin;
+    const int Kp = mode == 0 ? round32(KH * KW * Cin) : round32((Cout + 3) & ~3);
+    long long g = sh_cdiv(rows * Kp, 256);
+    if (g > 4096) g = 4096;
+    weight_split_kernel<<<(unsigned)g, 256, 0, (hipStream_t)stream>>>(w, (unsigned short*)planes, Cout, KH * KW, Cin, Kp, mode, rows);
+    return sh_launch_status();
+}
+extern "C" int sh_weight_transpose(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream) {
+    if (!w || !wt || Cout <= 0 || KH <= 0 || KW <= 0 || Cin <= 0) return SH_EINVAL;
+    const int CoutP = (Cout + 3) & ~3;
+    long long total = (long long)KH * KW * Cin * CoutP, g = sh_cdiv(total, 256);
+    if (g > 4096) g = 4096;
+    weight_transpose_kernel<<<(unsigned)g, 256, 0, (hipStream_t)stream>>>(w, wt, Cout, KH * KW, Cin, CoutP);
+    return sh_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------- host side
+template <int MODE, int TM, int TN>
+static int launch_x6(const ConvQ& p, hipStream_t st) {
+    constexpr size_t lds = 3 * (size_t)(64 * TM + 64 * TN) * ROWB;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6_kernel<MODE, TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    conv_x6_kernel<MODE, TM, TN><<<(unsigned)(p.tiles_m * p.tiles_n), 256, lds, st>>>(p);
+    return sh_launch_status();
+}
+static void pick_tiles(long long M, long long Nn, int& TM, int& TN) {
+    TN = Nn <= 64 ? 1 : 2;
+    TM = 2;
+    if (sh_cdiv(M, 128) * sh_cdiv(Nn, 64 * TN) < 256) {
+        TM = 1;
+        if (TN == 2 && sh_cdiv(M, 64) * sh_cdiv(Nn, 128) < 256) TN = 1;
+    }
+    if (M <= 64) TM = 1;
+}
+template <int MODE>
+static int launch_conv_x6(ConvQ& p, hipStream_t st) {
+    int TM, TN;
+    pick_tiles(p.M, p.Nn, TM, TN);
+    p.tiles_m = (int)sh_cdiv(p.M, 64 * TM);
+    p.tiles_n = (int)sh_cdiv(p.Nn, 64 * TN);
+    if (TM == 2 && TN == 2) return launch_x6<MODE, 2, 2>(p, st);
+    if (TM == 2 && TN == 1) return launch_x6<MODE, 2, 1>(p, st);
+    if (TM == 1 && TN == 2) return launch_x6<MODE, 1, 2>(p, st);
+    return launch_x6<MODE, 1, 1>(p, st);
+}
+static bool geom(ConvQ& p, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || dil <= 0 || pad < 0) return false;
+    if (Cin % 4 != 0) return false;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
+    p.Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+    p.Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+    if (p.Ho <= 0 || p.Wo <= 0) return false;
+    if ((long long)N * H * W >= (1ll << 31) || (long long)N * p.Ho * p.Wo >= (1ll << 31)) return false;
+    if ((long long)KH * KW * (long long)(Cin > Cout ? Cin : Cout + 3) >= (1ll << 30)) return false;
+    return true;
+}
+
+// wq = sh_weight_split(w, mode 0)
+extern "C" int sh_conv_fprop_x6(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, float* stat_partials,
+                                int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, void* stream) {
+    ConvQ p{};
+    if (!x || !w || !y || !geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil)) return SH_EINVAL;
+    if (ldx < Cin || ldy < Cout || (ldx & 3)) return SH_EINVAL;
+    p.a = x; p.b = w; p.c = y; p.extra = bias; p.partials = stat_partials; p.lda = ldx; p.ldc = ldy;
+    p.M = N * p.Ho * p.Wo; p.Nn = Cout; p.K = KH * KW * Cin; p.Kc = Cin; p.Kreal = Cin;
+    p.Kp = round32(p.K); p.bplane = (long long)Cout * p.Kp;
+    p.n_partials = (int)sh_cdiv(p.M, 64);
+    return launch_conv_x6<FPROP>(p, (hipStream_t)stream);
+}
+// wt = sh_weight_split(w, mode 1): bf16 planes [3][KH*KW*Cin][round32(pad4(Cout))]
+extern "C" int sh_conv_dgrad_x6(const float* dy, int lddy, const float* wt, const float* addend, int ldadd, float* dx, int lddx,
+                                int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, int mode, void* stream) {
+    ConvQ p{};
+    if (!dy || !wt || !dx || !geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil)) return SH_EINVAL;
+    const int CoutP = (Cout + 3) & ~3;
+    if (lddy < CoutP || (lddy & 3) || lddx < Cin) return SH_EINVAL;
+    if (addend && ldadd < Cin) return SH_EINVAL;
+    p.a = dy; p.b = wt; p.c = dx; p.extra = addend; p.ldadd = ldadd; p.lda = lddy; p.ldc = lddx;
+    p.Nn = Cin; p.Kreal = CoutP; p.Kc = round32(CoutP); p.Kp = p.Kc; p.K = KH * KW * p.Kc;
+    p.bplane = (long long)KH * KW * Cin * p.Kp;
+    if (mode == 1) {
+        if (KH != 1 || KW != 1 || pad != 0) return SH_EINVAL;
+        p.scatter = 1; p.sH = H; p.sW = W; p.sstride = stride;
+        p.H = p.Ho; p.W = p.Wo; p.stride = 1;
+        p.M = N * p.Ho * p.Wo;
+    } else if (mode == 0) {
+        p.M = N * H * W;
+    } else return SH_EINVAL;
+    return launch_conv_x6<DGRAD>(p, (hipStream_t)stream);
+}
+
+static void wgrad_plan_x6(int Cout, long long Nn, long long npix, int& splits, int& kchunk) {
+    const long long tiles = sh_cdiv(Cout, 128) * sh_cdiv(Nn, 128);
+    long long s = sh_cdiv(640, tiles), maxs = sh_cdiv(npix, 256);
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    const long long chunk = sh_cdiv(sh_cdiv(npix, s), 32) * 32;
+    kchunk = (int)chunk;
+    splits = (int)sh_cdiv(npix, chunk);
+}
+extern "C" int64_t sh_conv_wgrad_x6_workspace(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil) {
+    ConvQ p{};
+    if (!geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil)) return SH_EINVAL;
+    int splits, kchunk;
+    wgrad_plan_x6(Cout, (long long)KH * KW * Cin, (long long)N * p.Ho * p.Wo, splits, kchunk);
+    return (int64_t)splits * Cout * KH * KW * Cin * (int64_t)sizeof(float);
+}
+extern "C" int sh_conv_wgrad_x6(const float* x, int ldx, const float* dy, int lddy, float* dw, float* workspace, int N, int H, int W,
+                                int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, void* stream) {
+    ConvQ p{};
+    if (!x || !dy || !dw || !workspace || !geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil)) return SH_EINVAL;
+    if (lddy < ((Cout + 3) & ~3) || (lddy & 3) || ldx < Cin || (ldx & 3)) return SH_EINVAL;
+    p.a = dy; p.b = x; p.c = workspace; p.lda = lddy; p.ldb = ldx;
+    p.M = Cout; p.Nn = KH * KW * Cin; p.K = N * p.Ho * p.Wo;
+    int splits;
+    wgrad_plan_x6(Cout, p.Nn, p.K, splits, p.kchunk);
+    p.tiles_m = (int)sh_cdiv(p.M, 128); p.tiles_n = (int)sh_cdiv(p.Nn, 128);
+    constexpr size_t lds = 6 * 32 * TROWB;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits);
+    conv_wgrad_x6_kernel<<<grid, 256, lds, st>>>(p);
+    int rc = sh_launch_status();
+    if (rc != SH_OK) return rc;
+    const long long n = (long long)Cout * p.Nn, n4 = n / 4;
+    slab_reduce_x6_kernel<<<(unsigned)sh_cdiv(n4, 64), 256, 0, st>>>(workspace, dw, n4, n, splits);
+    return sh_launch_status();
+}

@@ -10,6 +10,11 @@ import torch
 
 from ._lib import LIB, SegHieroHipError
 
+import os
+
+# "x6": fp32-accurate 6 x bf16-split MFMA path (default); "f32": v_mfma_f32_32x32x2_f32 path.
+CONV_IMPL = os.environ.get("SEGHIERO_CONV", "x6")
+
 _PROF = None          # when set (see `profile()`), every C-ABI call is bracketed by HIP events on its launch stream
 
 
@@ -145,9 +150,29 @@ def conv_fprop(x, weight, bias, y, partials, stride, pad, dil):
     yp, ldy = pm(y)
     ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
     m = n * ho * wo
-    _call("sh_conv_fprop", xp, ldx, w_ohwi(weight).data_ptr(), None if bias is None else bias.data_ptr(), yp, ldy,
+    x6 = CONV_IMPL == "x6"
+    wptr = weight_split(weight, 0).data_ptr() if x6 else w_ohwi(weight).data_ptr()
+    _call("sh_conv_fprop_x6" if x6 else "sh_conv_fprop", xp, ldx, wptr,
+          None if bias is None else bias.data_ptr(), yp, ldy,
           None if partials is None else partials.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, _st(),
           cost=(2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin + m * o + o * cin * kh * kw)))
+
+
+def weight_split(weight, mode):
+    """Exact 3-way bf16 split of an [O,I,KH,KW] (OHWI memory) weight into planes for the x6 fprop (mode 0) / dgrad (1)."""
+    o, i, kh, kw = weight.shape
+    nbytes = LIB.raw("sh_weight_split_bytes")(o, kh, kw, i, mode)
+    planes = torch.empty((nbytes,), device=weight.device, dtype=torch.uint8)
+    _call("sh_weight_split", w_ohwi(weight).data_ptr(), planes.data_ptr(), o, kh, kw, i, mode, _st())
+    return planes
+
+
+def weight_transpose(weight):
+    """[O,I,KH,KW] (OHWI memory) -> [KH*KW, I, pad4(O)] buffer: the K-contiguous B operand of the x6 dgrad."""
+    o, i, kh, kw = weight.shape
+    wt = torch.empty((kh * kw, i, pad4(o)), device=weight.device, dtype=torch.float32)
+    _call("sh_weight_transpose", w_ohwi(weight).data_ptr(), wt.data_ptr(), o, kh, kw, i, _st())
+    return wt
 
 
 def conv_dgrad(dy, weight, dx, stride, pad, dil, addend=None, mode=0):
@@ -158,7 +183,9 @@ def conv_dgrad(dy, weight, dx, stride, pad, dil, addend=None, mode=0):
     ap, lda = (None, 0) if addend is None else pm(addend)
     ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
     m = n * ho * wo
-    _call("sh_conv_dgrad", dyp, lddy, w_ohwi(weight).data_ptr(), ap, lda, dxp, lddx, n, h, w, cin, o, kh, kw,
+    x6 = CONV_IMPL == "x6" and lddy >= pad4(o)
+    wptr = weight_split(weight, 1).data_ptr() if x6 else w_ohwi(weight).data_ptr()
+    _call("sh_conv_dgrad_x6" if x6 else "sh_conv_dgrad", dyp, lddy, wptr, ap, lda, dxp, lddx, n, h, w, cin, o, kh, kw,
           stride, pad, dil, mode, _st(),
           cost=(2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin * (2 if addend is not None or mode else 1) + m * o + o * cin * kh * kw)))
 
@@ -179,7 +206,9 @@ def workspace(nbytes, device, tag="ws"):
 def conv_wgrad(x, dy, dweight, stride, pad, dil):
     n, cin, h, w = x.shape
     o, _, kh, kw = dweight.shape
-    need = LIB.raw("sh_conv_wgrad_workspace")(n, h, w, cin, o, kh, kw, stride, pad, dil)
+    # the x6 wgrad kernel has one tile shape (128x128): narrow outputs stay on the f32-MFMA kernel (64-wide tiles)
+    x6 = CONV_IMPL == "x6" and o >= 128 and cin * kh * kw >= 128
+    need = LIB.raw("sh_conv_wgrad_x6_workspace" if x6 else "sh_conv_wgrad_workspace")(n, h, w, cin, o, kh, kw, stride, pad, dil)
     if need < 0:
         raise SegHieroHipError("sh_conv_wgrad_workspace rejected the geometry")
     ws = workspace(need, x.device, "wgrad")
@@ -187,7 +216,7 @@ def conv_wgrad(x, dy, dweight, stride, pad, dil):
     dyp, lddy = pm(dy)
     ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
     m = n * ho * wo
-    _call("sh_conv_wgrad", xp, ldx, dyp, lddy, dweight.data_ptr(), ws.data_ptr(), n, h, w, cin, o, kh, kw,
+    _call("sh_conv_wgrad_x6" if x6 else "sh_conv_wgrad", xp, ldx, dyp, lddy, dweight.data_ptr(), ws.data_ptr(), n, h, w, cin, o, kh, kw,
           stride, pad, dil, _st(),
           cost=(2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin + m * o + o * cin * kh * kw)))
 
