@@ -63,8 +63,8 @@ int sh_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw,
 
 /* The same three GEMMs on the bf16 matrix cores with an exact 3-way bf16 split of every fp32 operand and six
  * v_mfma_f32_32x32x16_bf16 products per term (fp32-class accuracy, 2.7x fewer MFMA cycles than the f32 MFMA; see
- * csrc/conv_bf16x6.hip).  Same arguments, except that `w` / `wt` are the pre-split bf16 weight planes made by
- * sh_weight_split (mode 0 for fprop, mode 1 for dgrad); dgrad needs lddy >= pad4(Cout) with zeroed padding lanes. */
+ * csrc/conv_bf16x6.hip).  Same arguments, except that dgrad takes the transposed weight copy made by
+ * sh_weight_transpose ([KH*KW][Cin][pad4(Cout)], zero padded) and needs lddy >= pad4(Cout) with zeroed padding lanes. */
 int sh_conv_fprop_x6(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
                      float* stat_partials, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                      int stride, int pad, int dil, void* stream);

@@ -73,31 +73,38 @@ __device__ __forceinline__ f32x16 mma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3
 }
 
 // ============================================================================================ FPROP / DGRAD
-template <int MODE, int TM, int TN>
-__global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvQ p) {
-    constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32;
+// Block = WGM x WGN waves, each wave TM x TN MFMA tiles of 32x32: block tile (32*TM*WGM) x (32*TN*WGN).
+// Measured (tools/bench_conv.py + PMC): with 128x128 tiles these kernels are bound by the CU's L1 line-access rate
+// (every K tile re-reads (BM+BN)*128 B through the vector L1), not by MFMA or VALU issue -- so the big shapes use
+// 256x256 tiles on 1024 threads (half the L1 lines per flop), with both operands kept fp32 in memory (4 B/element) and
+// split to bf16 in registers on their way to LDS.
+template <int MODE, int TM, int TN, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4 < 2 ? 2 : (WGM * WGN) / 4) void conv_x6_kernel(const ConvQ p) {
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, BK = 32;
     constexpr int A_PLANE = BM * ROWB, B_PLANE = BN * ROWB;      // bytes
-    constexpr int NA = 2 * TM;                                   // A float4 per thread per tile
-    constexpr int NBV = BN / 64;                                 // B 16-byte chunks per thread per plane per tile
+    constexpr int RPP = NT / 8;                                  // rows covered per loader pass (8 lanes x 16 B per row)
+    constexpr int NA = BM / RPP, NB = BN / RPP;
+    static_assert(NA >= 1 && NB >= 1, "tile too small for the thread count");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem;                       // [3][BM][80]
     unsigned char* Bs = smem + 3 * A_PLANE;         // [3][BN][80]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WGN, wn = wave % WGN, l31 = lane & 31, h = lane >> 5;
     const unsigned nblk = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
     const unsigned bid = xcd_remap(blockIdx.x, nblk);
     const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int nkt = (p.K + BK - 1) / BK;
-    const bool tap_uniform = (p.Kc & 31) == 0;      // a K tile never straddles taps: tap arithmetic stays on the scalar unit
     const bool single_tap = p.KH * p.KW == 1;
+    const bool tap_uniform = single_tap || (p.Kc & 31) == 0;     // a K tile never straddles taps => tap math is scalar
 
     const int kc = t & 7, r0 = t >> 3;
     int a_y[NA], a_x[NA], a_nb[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int m = m0 + r0 + 32 * i;
+        const int m = m0 + r0 + RPP * i;
         if (m < p.M) {
             if constexpr (MODE == FPROP) {
                 const int ow = m % p.Wo, q = m / p.Wo, oh = q % p.Ho, n = q / p.Ho;
@@ -108,8 +115,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvQ p) {
             }
         } else { a_y[i] = -(1 << 28); a_x[i] = 0; a_nb[i] = 0; }
     }
-    // per-row element offsets of the current tap (recomputed only when the tap changes; never for 1x1 convs)
-    long long a_off[NA];
+    long long a_off[NA];             // element offset of each A row for the current tap (never recomputed for 1x1 convs)
     bool a_ok[NA];
     int cur_tap = -1;
     auto set_tap = [&](int tap) {
@@ -133,55 +139,55 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvQ p) {
             }
         }
     };
-    // B: pre-split bf16 planes [3][rows][Kp]; thread -> (row = idx>>2, 16-byte chunk = idx&3), idx = t + 256*i
-    const unsigned short* bq = reinterpret_cast<const unsigned short*>(p.b);
+    // B rows: fprop W[co][K] (k linear over taps); dgrad Wt[tap][ci][Kc] (per-tap rows of Kc = pad4(Cout) floats)
+    long long b_row[NB];
+    bool b_ok[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int j = n0 + r0 + RPP * i;
+        b_ok[i] = j < p.Nn;
+        b_row[i] = (long long)j * (MODE == FPROP ? p.K : p.Kc);
+    }
 
-    struct Stage { f32x4 ra[NA]; u32x4 rbq[3][NBV]; };
-    Stage S0, S1;                                    // two tiles in flight (global-load latency > one tile's MFMA time)
+    f32x4 ra[NA], rb[NB];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const u32x4 zq = {0u, 0u, 0u, 0u};
 
-    auto load_tile = [&](int kt, Stage& S) {
+    auto load_tile = [&](int kt) {
         const int kbase = kt * BK;
         int tap, cc;
         if (single_tap) { tap = 0; cc = kbase + 4 * kc; }
         else if (tap_uniform) { tap = kbase / p.Kc; cc = kbase - tap * p.Kc + 4 * kc; }
         else { const int k = kbase + 4 * kc; tap = k / p.Kc; cc = k - tap * p.Kc; }
-        const bool kok = (kbase + 4 * kc) < p.K && cc < p.Kreal;
-        if (!(single_tap || tap_uniform) || tap != cur_tap) { set_tap(tap); cur_tap = tap; }
+        const bool kok = (kbase + 4 * kc) < p.K;
+        if (!tap_uniform || tap != cur_tap) { set_tap(tap); cur_tap = tap; }
 #pragma unroll
-        for (int i = 0; i < NA; ++i) S.ra[i] = (kok && a_ok[i]) ? ld4(p.a + a_off[i] + cc) : zero4;
-        // B rows: fprop W planes [Cout][Kp] (k linear over taps); dgrad Wt planes [tap*Cin + ci][Kp] (k within the tap)
-        const int btap = single_tap ? 0 : kbase / p.Kc;     // block-uniform (dgrad always has Kc % 32 == 0)
+        for (int i = 0; i < NA; ++i) ra[i] = (kok && a_ok[i]) ? ld4(p.a + a_off[i] + cc) : zero4;
 #pragma unroll
-        for (int i = 0; i < NBV; ++i) {
-            const int idx = t + 256 * i, row = idx >> 2, c16 = idx & 3;
-            const int j = n0 + row;
+        for (int i = 0; i < NB; ++i) {
             long long off;
-            if constexpr (MODE == FPROP) off = (long long)j * p.Kp + kbase + 8 * c16;
-            else off = ((long long)btap * p.Cin + j) * p.Kp + (kbase - btap * p.Kc) + 8 * c16;
-            const bool ok = j < p.Nn;
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                S.rbq[pl][i] = ok ? *reinterpret_cast<const u32x4*>(bq + pl * p.bplane + off) : zq;
+            if constexpr (MODE == FPROP) off = b_row[i] + kbase + 4 * kc;
+            else off = (long long)tap * p.Cin * p.Kc + b_row[i] + cc;
+            rb[i] = (kok && b_ok[i]) ? ld4(p.b + off) : zero4;
         }
     };
-    auto store_tile = [&](const Stage& S) {
+    auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             u32x2 q1, q2, q3;
-            split4(S.ra[i], q1, q2, q3);
-            const int off = (r0 + 32 * i) * ROWB + kc * 8;
+            split4(ra[i], q1, q2, q3);
+            const int off = (r0 + RPP * i) * ROWB + kc * 8;
             *reinterpret_cast<u32x2*>(As + off) = q1;
             *reinterpret_cast<u32x2*>(As + A_PLANE + off) = q2;
             *reinterpret_cast<u32x2*>(As + 2 * A_PLANE + off) = q3;
         }
 #pragma unroll
-        for (int i = 0; i < NBV; ++i) {
-            const int idx = t + 256 * i, row = idx >> 2, c16 = idx & 3;
-            const int off = row * ROWB + c16 * 16;
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(Bs + pl * B_PLANE + off) = S.rbq[pl][i];
+        for (int i = 0; i < NB; ++i) {
+            u32x2 q1, q2, q3;
+            split4(rb[i], q1, q2, q3);
+            const int off = (r0 + RPP * i) * ROWB + kc * 8;
+            *reinterpret_cast<u32x2*>(Bs + off) = q1;
+            *reinterpret_cast<u32x2*>(Bs + B_PLANE + off) = q2;
+            *reinterpret_cast<u32x2*>(Bs + 2 * B_PLANE + off) = q3;
         }
     };
 
@@ -193,8 +199,12 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvQ p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    load_tile(0);
+    store_tile();
+    __syncthreads();
     const int arow = wm * 32 * TM + l31, brow = wn * 32 * TN + l31;
-    auto compute = [&]() {
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) load_tile(kt + 1);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 af[TM][3], bfr[TN][3];
@@ -213,23 +223,10 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvQ p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = mma6(af[i], bfr[j], acc[i][j]);
         }
-    };
-    load_tile(0, S0);
-    if (nkt > 1) load_tile(1, S1);
-    store_tile(S0);
-    __syncthreads();
-    for (int kt = 0; kt < nkt; kt += 2) {
-        // LDS holds tile kt, S1 holds tile kt+1 (in flight), S0 is free
-        if (kt + 2 < nkt) load_tile(kt + 2, S0);
-        compute();
         __syncthreads();                      // every wave is done reading the LDS planes
         if (kt + 1 < nkt) {
-            store_tile(S1);
+            store_tile();
             __syncthreads();
-            if (kt + 3 < nkt) load_tile(kt + 3, S1);
-            compute();
-            __syncthreads();
-            if (kt + 2 < nkt) { store_tile(S0); __syncthreads(); }
         }
     }
 
@@ -288,8 +285,8 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvQ p) {
                 qq += __shfl_xor(qq, 32, 64);
                 s[j] = ss; q[j] = qq;
             }
-            if constexpr (TM == 2) {
-                const int pidx = tile_m * 2 + wm;
+            if constexpr (TM == 2) {          // a wave covers exactly one 64-row partial
+                const int pidx = tile_m * (BM / 64) + wm;
                 if (h == 0 && pidx < p.n_partials) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
@@ -300,7 +297,8 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvQ p) {
                         }
                     }
                 }
-            } else {
+            } else {                          // TM == 1 (only instantiated with WGM == 2): two waves share the 64-row partial
+                static_assert(TM == 2 || WGM == 2, "TM == 1 variants use a 2-wave M grid");
                 float* red = reinterpret_cast<float*>(smem);      // main loop ended with a barrier
                 if (h == 0) {
 #pragma unroll
@@ -537,36 +535,36 @@ extern "C" int sh_weight_transpose(const float* w, float* wt, int Cout, int KH, 
 }
 
 // ---------------------------------------------------------------------------------------- host side
-template <int MODE, int TM, int TN>
-static int launch_x6(const ConvQ& p, hipStream_t st) {
-    constexpr size_t lds = 3 * (size_t)(64 * TM + 64 * TN) * ROWB;
+template <int MODE, int TM, int TN, int WGM, int WGN>
+static int launch_x6(ConvQ& p, hipStream_t st) {
+    constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
+    constexpr size_t lds = 3 * (size_t)(BM + BN) * ROWB;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6_kernel<MODE, TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6_kernel<MODE, TM, TN, WGM, WGN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    conv_x6_kernel<MODE, TM, TN><<<(unsigned)(p.tiles_m * p.tiles_n), 256, lds, st>>>(p);
+    p.tiles_m = (int)sh_cdiv(p.M, BM);
+    p.tiles_n = (int)sh_cdiv(p.Nn, BN);
+    conv_x6_kernel<MODE, TM, TN, WGM, WGN><<<(unsigned)(p.tiles_m * p.tiles_n), 64 * WGM * WGN, lds, st>>>(p);
     return sh_launch_status();
-}
-static void pick_tiles(long long M, long long Nn, int& TM, int& TN) {
-    TN = Nn <= 64 ? 1 : 2;
-    TM = 2;
-    if (sh_cdiv(M, 128) * sh_cdiv(Nn, 64 * TN) < 256) {
-        TM = 1;
-        if (TN == 2 && sh_cdiv(M, 64) * sh_cdiv(Nn, 128) < 256) TN = 1;
-    }
-    if (M <= 64) TM = 1;
 }
 template <int MODE>
 static int launch_conv_x6(ConvQ& p, hipStream_t st) {
-    int TM, TN;
-    pick_tiles(p.M, p.Nn, TM, TN);
-    p.tiles_m = (int)sh_cdiv(p.M, 64 * TM);
-    p.tiles_n = (int)sh_cdiv(p.Nn, 64 * TN);
-    if (TM == 2 && TN == 2) return launch_x6<MODE, 2, 2>(p, st);
-    if (TM == 2 && TN == 1) return launch_x6<MODE, 2, 1>(p, st);
-    if (TM == 1 && TN == 2) return launch_x6<MODE, 1, 2>(p, st);
-    return launch_x6<MODE, 1, 1>(p, st);
+    const long long M = p.M, N = p.Nn;
+    // big tiles while they still give >= 2 blocks per CU (they halve the L1 traffic per flop), then the 128/64 family
+    if (N > 128 && sh_cdiv(M, 256) * sh_cdiv(N, 256) >= 512) return launch_x6<MODE, 2, 2, 4, 4>(p, st);
+    if (N > 64 && sh_cdiv(M, 256) * sh_cdiv(N, 128) >= 512) return launch_x6<MODE, 2, 2, 4, 2>(p, st);
+    int TN = N <= 64 ? 1 : 2, TM = 2;
+    if (sh_cdiv(M, 128) * sh_cdiv(N, 64 * TN) < 256) {
+        TM = 1;
+        if (TN == 2 && sh_cdiv(M, 64) * sh_cdiv(N, 128) < 256) TN = 1;
+    }
+    if (M <= 64) TM = 1;
+    if (TM == 2 && TN == 2) return launch_x6<MODE, 2, 2, 2, 2>(p, st);
+    if (TM == 2 && TN == 1) return launch_x6<MODE, 2, 1, 2, 2>(p, st);
+    if (TM == 1 && TN == 2) return launch_x6<MODE, 1, 2, 2, 2>(p, st);
+    return launch_x6<MODE, 1, 1, 2, 2>(p, st);
 }
 static bool geom(ConvQ& p, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || dil <= 0 || pad < 0) return false;
@@ -580,19 +578,17 @@ static bool geom(ConvQ& p, int N, int H, int W, int Cin, int Cout, int KH, int K
     return true;
 }
 
-// wq = sh_weight_split(w, mode 0)
 extern "C" int sh_conv_fprop_x6(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, float* stat_partials,
                                 int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, void* stream) {
     ConvQ p{};
     if (!x || !w || !y || !geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil)) return SH_EINVAL;
     if (ldx < Cin || ldy < Cout || (ldx & 3)) return SH_EINVAL;
     p.a = x; p.b = w; p.c = y; p.extra = bias; p.partials = stat_partials; p.lda = ldx; p.ldc = ldy;
-    p.M = N * p.Ho * p.Wo; p.Nn = Cout; p.K = KH * KW * Cin; p.Kc = Cin; p.Kreal = Cin;
-    p.Kp = round32(p.K); p.bplane = (long long)Cout * p.Kp;
+    p.M = N * p.Ho * p.Wo; p.Nn = Cout; p.K = KH * KW * Cin; p.Kc = Cin;
     p.n_partials = (int)sh_cdiv(p.M, 64);
     return launch_conv_x6<FPROP>(p, (hipStream_t)stream);
 }
-// wt = sh_weight_split(w, mode 1): bf16 planes [3][KH*KW*Cin][round32(pad4(Cout))]
+// wt = sh_weight_transpose(w): fp32 [KH*KW][Cin][pad4(Cout)]
 extern "C" int sh_conv_dgrad_x6(const float* dy, int lddy, const float* wt, const float* addend, int ldadd, float* dx, int lddx,
                                 int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, int mode, void* stream) {
     ConvQ p{};
@@ -601,8 +597,7 @@ extern "C" int sh_conv_dgrad_x6(const float* dy, int lddy, const float* wt, cons
     if (lddy < CoutP || (lddy & 3) || lddx < Cin) return SH_EINVAL;
     if (addend && ldadd < Cin) return SH_EINVAL;
     p.a = dy; p.b = wt; p.c = dx; p.extra = addend; p.ldadd = ldadd; p.lda = lddy; p.ldc = lddx;
-    p.Nn = Cin; p.Kreal = CoutP; p.Kc = round32(CoutP); p.Kp = p.Kc; p.K = KH * KW * p.Kc;
-    p.bplane = (long long)KH * KW * Cin * p.Kp;
+    p.Nn = Cin; p.Kc = CoutP; p.K = KH * KW * CoutP;
     if (mode == 1) {
         if (KH != 1 || KW != 1 || pad != 0) return SH_EINVAL;
         p.scatter = 1; p.sH = H; p.sW = W; p.sstride = stride;

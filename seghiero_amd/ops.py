@@ -151,7 +151,7 @@ def conv_fprop(x, weight, bias, y, partials, stride, pad, dil):
     ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
     m = n * ho * wo
     x6 = CONV_IMPL == "x6"
-    wptr = weight_split(weight, 0).data_ptr() if x6 else w_ohwi(weight).data_ptr()
+    wptr = w_ohwi(weight).data_ptr()
     _call("sh_conv_fprop_x6" if x6 else "sh_conv_fprop", xp, ldx, wptr,
           None if bias is None else bias.data_ptr(), yp, ldy,
           None if partials is None else partials.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, _st(),
@@ -184,7 +184,7 @@ def conv_dgrad(dy, weight, dx, stride, pad, dil, addend=None, mode=0):
     ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
     m = n * ho * wo
     x6 = CONV_IMPL == "x6" and lddy >= pad4(o)
-    wptr = weight_split(weight, 1).data_ptr() if x6 else w_ohwi(weight).data_ptr()
+    wptr = weight_transpose(weight).data_ptr() if x6 else w_ohwi(weight).data_ptr()
     _call("sh_conv_dgrad_x6" if x6 else "sh_conv_dgrad", dyp, lddy, wptr, ap, lda, dxp, lddx, n, h, w, cin, o, kh, kw,
           stride, pad, dil, mode, _st(),
           cost=(2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin * (2 if addend is not None or mode else 1) + m * o + o * cin * kh * kw)))
