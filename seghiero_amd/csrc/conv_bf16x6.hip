@@ -326,17 +326,22 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4 < 2 ? 2 : (WGM * WG
 }
 
 // ============================================================================================ WGRAD (transposing LDS reads)
-// dW[co][n'] = sum_pix dY[pix][co] * im2col(X)[pix][n'];  planes stored [k = pixel][row], 320-byte rows
-// (256 data + 64 pad => the four k-rows of a ds_read_b64_tr_b16 block land on disjoint banks).
-#define TROWB 320
-__global__ __launch_bounds__(256, 2) void conv_wgrad_x6_kernel(const ConvQ p) {
-    constexpr int BM = 128, BN = 128, BK = 32;
-    constexpr int PLANE = BK * TROWB;                // 10240 bytes
+// dW[co][n'] = sum_pix dY[pix][co] * im2col(X)[pix][n'];  planes stored [k = pixel][row] with (2*rows + 64)-byte rows
+// (=> the four k-rows of a ds_read_b64_tr_b16 block land on disjoint banks).  Block = WGM x WGN waves of 64x64.
+template <int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4 < 2 ? 2 : (WGM * WGN) / 4) void conv_wgrad_x6_kernel(const ConvQ p) {
+    constexpr int NT = 64 * WGM * WGN, BM = 64 * WGM, BN = 64 * WGN, BK = 32;
+    constexpr int AROWB = 2 * BM + 64, BROWB = 2 * BN + 64;
+    constexpr int APLANE = BK * AROWB, BPLANE = BK * BROWB;
+    constexpr int ACPR = BM / 4, BCPR = BN / 4;              // float4 chunks per k-row
+    constexpr int AKPP = NT / ACPR, BKPP = NT / BCPR;        // k-rows per loader pass
+    constexpr int NA = BK / AKPP, NB = BK / BKPP;
+    static_assert(NA >= 1 && NB >= 1, "tile too narrow for the thread count");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* As = smem;                        // [3][32][320]
-    unsigned char* Bs = smem + 3 * PLANE;
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + 3 * APLANE;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WGN, wn = wave % WGN, l31 = lane & 31, h = lane >> 5;
     const unsigned nblk = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
     const unsigned bid = xcd_remap(blockIdx.x, nblk);
     const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
@@ -344,52 +349,60 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x6_kernel(const ConvQ p) {
     const int kbeg = blockIdx.y * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
     const int nkt = (kend - kbeg + BK - 1) / BK;
 
-    const int rc = t & 31, k0 = t >> 5;              // float4 column chunk, k-row (8 rows per pass, 4 passes)
-    const int nn = n0 + 4 * rc;
+    const int arc = t % ACPR, ak0 = t / ACPR;        // A: float4 column chunk, first k-row
+    const int brc = t % BCPR, bk0 = t / BCPR;
+    const int co = m0 + 4 * arc;
+    const int nn = n0 + 4 * brc;
     const bool wg_ok = nn < p.Nn;
     const int tap = nn / p.Cin, wg_ci = nn - tap * p.Cin;
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
     const int wg_dh = kh * p.dil - p.pad, wg_dw = kw * p.dil - p.pad;
-    const int co = m0 + 4 * rc;
 
-    struct Stage { f32x4 ra[4], rb[4]; };
-    Stage S0, S1;
+    f32x4 ra[NA], rb[NB];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    // pixel coordinates of this thread's 4 k-rows, advanced by 32 pixels per K tile (no divisions in the loop)
-    int px_ow[4], px_oh[4], px_n[4];
+    // pixel coordinates of this thread's B k-rows, advanced by 32 pixels per K tile (no divisions in the loop)
+    int px_ow[NB], px_oh[NB], px_n[NB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int pix = kbeg + k0 + 8 * i;
+    for (int i = 0; i < NB; ++i) {
+        const int pix = kbeg + bk0 + BKPP * i;
         px_ow[i] = pix % p.Wo; const int q2 = pix / p.Wo; px_oh[i] = q2 % p.Ho; px_n[i] = q2 / p.Ho;
     }
-    auto load_tile = [&](int kt, Stage& S) {
+    auto load_tile = [&](int kt) {
         const int kbase = kbeg + kt * BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int pix = kbase + k0 + 8 * i;
-            const bool pok = pix < kend;
-            S.ra[i] = (pok && co < p.M) ? ld4(p.a + (long long)pix * p.lda + co) : zero4;
+        for (int i = 0; i < NA; ++i) {
+            const int pix = kbase + ak0 + AKPP * i;
+            ra[i] = (pix < kend && co < p.M) ? ld4(p.a + (long long)pix * p.lda + co) : zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int pix = kbase + bk0 + BKPP * i;
             const int ih = px_oh[i] * p.stride + wg_dh, iw = px_ow[i] * p.stride + wg_dw;
-            const bool ok = pok && wg_ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            S.rb[i] = ok ? ld4(p.b + ((long long)(px_n[i] * p.H + ih) * p.W + iw) * p.ldb + wg_ci) : zero4;
+            const bool ok = pix < kend && wg_ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            rb[i] = ok ? ld4(p.b + ((long long)(px_n[i] * p.H + ih) * p.W + iw) * p.ldb + wg_ci) : zero4;
             px_ow[i] += BK;
             while (px_ow[i] >= p.Wo) { px_ow[i] -= p.Wo; ++px_oh[i]; }
             while (px_oh[i] >= p.Ho) { px_oh[i] -= p.Ho; ++px_n[i]; }
         }
     };
-    auto store_tile = [&](const Stage& S) {
+    auto store_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int off = (k0 + 8 * i) * TROWB + rc * 8;
+        for (int i = 0; i < NA; ++i) {
+            const int off = (ak0 + AKPP * i) * AROWB + arc * 8;
             u32x2 q1, q2, q3;
-            split4(S.ra[i], q1, q2, q3);
+            split4(ra[i], q1, q2, q3);
             *reinterpret_cast<u32x2*>(As + off) = q1;
-            *reinterpret_cast<u32x2*>(As + PLANE + off) = q2;
-            *reinterpret_cast<u32x2*>(As + 2 * PLANE + off) = q3;
-            split4(S.rb[i], q1, q2, q3);
+            *reinterpret_cast<u32x2*>(As + APLANE + off) = q2;
+            *reinterpret_cast<u32x2*>(As + 2 * APLANE + off) = q3;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int off = (bk0 + BKPP * i) * BROWB + brc * 8;
+            u32x2 q1, q2, q3;
+            split4(rb[i], q1, q2, q3);
             *reinterpret_cast<u32x2*>(Bs + off) = q1;
-            *reinterpret_cast<u32x2*>(Bs + PLANE + off) = q2;
-            *reinterpret_cast<u32x2*>(Bs + 2 * PLANE + off) = q3;
+            *reinterpret_cast<u32x2*>(Bs + BPLANE + off) = q2;
+            *reinterpret_cast<u32x2*>(Bs + 2 * BPLANE + off) = q3;
         }
     };
     f32x16 acc[2][2];
@@ -402,17 +415,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x6_kernel(const ConvQ p) {
 
     // transpose-read addressing: 16-lane group g -> (row half g&1, k half g>>1); lane 4q+pp supplies row q, columns 4pp..4pp+3
     const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
-    const int tr_off = ((g >> 1) * 8 + q) * TROWB + (16 * (g & 1) + 4 * pp) * 2;   // + s*16*TROWB (+4*TROWB for k+4) + row base*2
-    auto frag = [&](const unsigned char* plane, int s, int rowbase) -> bf16x8 {
-        const unsigned char* a0 = plane + tr_off + s * 16 * TROWB + rowbase * 2;
+    const int krow = (g >> 1) * 8 + q, coff = (16 * (g & 1) + 4 * pp) * 2;
+    auto frag = [&](const unsigned char* plane, int rowb, int s, int rowbase) -> bf16x8 {
+        const unsigned char* a0 = plane + (krow + s * 16) * rowb + coff + rowbase * 2;
         const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
-        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0 + 4 * TROWB));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0 + 4 * rowb));
         s16x8 r;
         r[0] = v0[0]; r[1] = v0[1]; r[2] = v0[2]; r[3] = v0[3]; r[4] = v1[0]; r[5] = v1[1]; r[6] = v1[2]; r[7] = v1[3];
         return __builtin_bit_cast(bf16x8, r);
     };
 
-    auto compute = [&]() {
+    if (nkt > 0) { load_tile(0); store_tile(); }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) load_tile(kt + 1);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 af[2][3], bfr[2][3];
@@ -420,33 +436,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x6_kernel(const ConvQ p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
-                    af[i][pl] = frag(As + pl * PLANE, s, wm * 64 + 32 * i);
-                    bfr[i][pl] = frag(Bs + pl * PLANE, s, wn * 64 + 32 * i);
+                    af[i][pl] = frag(As + pl * APLANE, AROWB, s, wm * 64 + 32 * i);
+                    bfr[i][pl] = frag(Bs + pl * BPLANE, BROWB, s, wn * 64 + 32 * i);
                 }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = mma6(af[i], bfr[j], acc[i][j]);
         }
-    };
-    if (nkt > 0) {
-        load_tile(0, S0);
-        if (nkt > 1) load_tile(1, S1);
-        store_tile(S0);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nkt; kt += 2) {
-        if (kt + 2 < nkt) load_tile(kt + 2, S0);
-        compute();
         __syncthreads();
-        if (kt + 1 < nkt) {
-            store_tile(S1);
-            __syncthreads();
-            if (kt + 3 < nkt) load_tile(kt + 3, S1);
-            compute();
-            __syncthreads();
-            if (kt + 2 < nkt) { store_tile(S0); __syncthreads(); }
-        }
+        if (kt + 1 < nkt) { store_tile(); __syncthreads(); }
     }
     float* slab = p.c + (long long)blockIdx.y * p.M * p.Nn;
 #pragma unroll
@@ -609,21 +608,39 @@ extern "C" int sh_conv_dgrad_x6(const float* dy, int lddy, const float* wt, cons
     return launch_conv_x6<DGRAD>(p, (hipStream_t)stream);
 }
 
-static void wgrad_plan_x6(int Cout, long long Nn, long long npix, int& splits, int& kchunk) {
-    const long long tiles = sh_cdiv(Cout, 128) * sh_cdiv(Nn, 128);
-    long long s = sh_cdiv(640, tiles), maxs = sh_cdiv(npix, 256);
+struct WgX6Plan { int wgm, wgn, splits, kchunk; };
+static WgX6Plan wgrad_plan_x6(int Cout, long long Nn, long long npix) {
+    WgX6Plan g;
+    // measured (tools/bench_conv.py): 128x256 helps the narrow-Cout shapes, 256x256 on 1024 threads does not help wgrad
+    g.wgm = 2;
+    g.wgn = (Nn >= 256 && Cout <= 128) ? 4 : 2;
+    const long long tiles = sh_cdiv(Cout, 64 * g.wgm) * sh_cdiv(Nn, 64 * g.wgn);
+    long long s = sh_cdiv(g.wgm * g.wgn >= 16 ? 512 : 640, tiles), maxs = sh_cdiv(npix, 256);
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
     const long long chunk = sh_cdiv(sh_cdiv(npix, s), 32) * 32;
-    kchunk = (int)chunk;
-    splits = (int)sh_cdiv(npix, chunk);
+    g.kchunk = (int)chunk;
+    g.splits = (int)sh_cdiv(npix, chunk);
+    return g;
 }
 extern "C" int64_t sh_conv_wgrad_x6_workspace(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil) {
     ConvQ p{};
     if (!geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil)) return SH_EINVAL;
-    int splits, kchunk;
-    wgrad_plan_x6(Cout, (long long)KH * KW * Cin, (long long)N * p.Ho * p.Wo, splits, kchunk);
-    return (int64_t)splits * Cout * KH * KW * Cin * (int64_t)sizeof(float);
+    const WgX6Plan g = wgrad_plan_x6(Cout, (long long)KH * KW * Cin, (long long)N * p.Ho * p.Wo);
+    return (int64_t)g.splits * Cout * KH * KW * Cin * (int64_t)sizeof(float);
+}
+template <int WGM, int WGN>
+static int launch_wgrad_x6(ConvQ& p, int splits, hipStream_t st) {
+    constexpr size_t lds = 3 * 32 * (size_t)((2 * 64 * WGM + 64) + (2 * 64 * WGN + 64));
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x6_kernel<WGM, WGN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    p.tiles_m = (int)sh_cdiv(p.M, 64 * WGM); p.tiles_n = (int)sh_cdiv(p.Nn, 64 * WGN);
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits);
+    conv_wgrad_x6_kernel<WGM, WGN><<<grid, 64 * WGM * WGN, lds, st>>>(p);
+    return sh_launch_status();
 }
 extern "C" int sh_conv_wgrad_x6(const float* x, int ldx, const float* dy, int lddy, float* dw, float* workspace, int N, int H, int W,
                                 int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, void* stream) {
@@ -632,21 +649,16 @@ extern "C" int sh_conv_wgrad_x6(const float* x, int ldx, const float* dy, int ld
     if (lddy < ((Cout + 3) & ~3) || (lddy & 3) || ldx < Cin || (ldx & 3)) return SH_EINVAL;
     p.a = dy; p.b = x; p.c = workspace; p.lda = lddy; p.ldb = ldx;
     p.M = Cout; p.Nn = KH * KW * Cin; p.K = N * p.Ho * p.Wo;
-    int splits;
-    wgrad_plan_x6(Cout, p.Nn, p.K, splits, p.kchunk);
-    p.tiles_m = (int)sh_cdiv(p.M, 128); p.tiles_n = (int)sh_cdiv(p.Nn, 128);
-    constexpr size_t lds = 6 * 32 * TROWB;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    const WgX6Plan g = wgrad_plan_x6(Cout, p.Nn, p.K);
+    p.kchunk = g.kchunk;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits);
-    conv_wgrad_x6_kernel<<<grid, 256, lds, st>>>(p);
-    int rc = sh_launch_status();
+    int rc;
+    if (g.wgm == 4 && g.wgn == 4) rc = launch_wgrad_x6<4, 4>(p, g.splits, st);
+    else if (g.wgm == 2 && g.wgn == 4) rc = launch_wgrad_x6<2, 4>(p, g.splits, st);
+    else if (g.wgm == 4 && g.wgn == 2) rc = launch_wgrad_x6<4, 2>(p, g.splits, st);
+    else rc = launch_wgrad_x6<2, 2>(p, g.splits, st);
     if (rc != SH_OK) return rc;
     const long long n = (long long)Cout * p.Nn, n4 = n / 4;
-    slab_reduce_x6_kernel<<<(unsigned)sh_cdiv(n4, 64), 256, 0, st>>>(workspace, dw, n4, n, splits);
+    slab_reduce_x6_kernel<<<(unsigned)sh_cdiv(n4, 64), 256, 0, st>>>(workspace, dw, n4, n, g.splits);
     return sh_launch_status();
 }
