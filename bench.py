@@ -129,6 +129,21 @@ def main():
             "traffic": None, "launches": r["calls"], "avg_launch_us": round(1e3 * r["ms"] / r["calls"], 1),
             "alg_bytes_per_step": r["bytes"], "alg_flops_per_step": r["flops"],
             "share_of_step": round(r["ms"] / total_ms, 3)}
+    # HBM traffic of the same kernel family from the committed PMC passes (tools/profile_bench.sh ->
+    # tools/summarize_profile.py): rocprofv3 cannot wrap this process from the inside, so the number is read from
+    # profiles/ and labelled with its source.
+    fam = {"sh_conv_fprop_x6": "conv_fprop_x6", "sh_conv_dgrad_x6": "conv_dgrad_x6", "sh_conv_wgrad_x6": "conv_wgrad_x6",
+           "sh_conv_fprop": "conv_fprop_f32", "sh_conv_dgrad": "conv_dgrad_f32", "sh_conv_wgrad": "conv_wgrad_f32"}.get(dom)
+    try:
+        import glob
+        tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))[-1]
+        tj = json.load(open(tf))["per_kernel_family"].get(fam)
+        if tj:
+            roof["traffic"] = round(tj["hbm_bytes_per_launch"])
+            roof["traffic_source"] = os.path.relpath(tf, ROOT) + " (PMC FETCH_SIZE x2 + WRITE_SIZE, per launch)"
+            roof["alg_bytes_per_launch"] = round(r["bytes"] / r["calls"])
+    except Exception:
+        pass
     if r["flops"] == 0:
         roof.update(bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None)
     breakdown = {k: round(v["ms"], 2) for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])[:12]}

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Summarise a tools/profile_bench.sh run into profiles/<tag>_*.{csv,json}.
+
+HBM traffic per kernel family from the PMC passes: FETCH_SIZE / WRITE_SIZE are reported in KiB (x1024 -> bytes) and, on
+gfx950, FETCH_SIZE counts a wide coalesced streaming read at exactly half its bytes (MI355X_MICROARCH.md, HBM section),
+so the read side is doubled before comparing with algorithmic bytes; WRITE_SIZE is taken as is."""
+import collections
+import csv
+import glob
+import json
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01b"
+src = f"gpurun_out/prof_{tag}"
+stats = glob.glob(f"{src}/trace/runc/*_kernel_stats.csv")[0]
+shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
+
+
+def family(name):
+    for key, fam in (("conv_x6_kernel<0", "conv_fprop_x6"), ("conv_x6_kernel<1", "conv_dgrad_x6"), ("conv_wgrad_x6", "conv_wgrad_x6"),
+                     ("conv_gemm_kernel<0", "conv_fprop_f32"), ("conv_gemm_kernel<1", "conv_dgrad_f32"),
+                     ("conv_gemm_kernel<2", "conv_wgrad_f32")):
+        if key in name:
+            return fam
+    return name.split("(")[0].replace("void ", "")[:48]
+
+
+out = collections.defaultdict(lambda: dict(launches=0, fetch_kib=0.0, write_kib=0.0))
+for which, col in (("fetch", "fetch_kib"), ("write", "write_kib")):
+    f = glob.glob(f"{src}/{which}/runc/*_counter_collection.csv")[0]
+    rows = list(csv.DictReader(open(f)))
+    # bench ran warmup 1 + steps 1 + instrumented 1 = 3 identical steps: average per step
+    for r in rows:
+        fam = family(r["Kernel_Name"])
+        out[fam][col] += float(r["Counter_Value"]) / 3.0
+        if which == "fetch":
+            out[fam]["launches"] += 1.0 / 3.0
+res = {}
+for fam, d in out.items():
+    rd, wr = 2.0 * d["fetch_kib"] * 1024, d["write_kib"] * 1024
+    res[fam] = dict(launches_per_step=round(d["launches"], 1), hbm_read_bytes_per_step=rd, hbm_write_bytes_per_step=wr,
+                    hbm_bytes_per_launch=(rd + wr) / max(d["launches"], 1e-9))
+top = dict(sorted(res.items(), key=lambda kv: -(kv[1]["hbm_read_bytes_per_step"] + kv[1]["hbm_write_bytes_per_step"]))[:25])
+json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over `python bench.py --steps 1 --warmup 1` ({tag}); FETCH_SIZE doubled "
+                     "(gfx950 wide-read correction), KiB -> bytes", "per_kernel_family": top}, open(f"profiles/{tag}_hbm_traffic.json", "w"), indent=1)
+for fam, d in list(top.items())[:14]:
+    print(f"{fam:28s} launches/step {d['launches_per_step']:6.1f}  read {d['hbm_read_bytes_per_step']/1e9:7.2f} GB  write {d['hbm_write_bytes_per_step']/1e9:7.2f} GB")
