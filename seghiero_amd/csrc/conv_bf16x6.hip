@@ -12,6 +12,7 @@
 // DGRAD have K-contiguous operands (DGRAD reads a per-step transposed weight copy [tap][ci][co]); WGRAD's operands are
 // pixel-major, so its planes are stored [k][m] and the fragments are read with ds_read_b64_tr_b16 (hardware transpose).
 #include "common.h"
+#include <stdlib.h>
 
 enum { FPROP = 0, DGRAD = 1 };
 
@@ -78,8 +79,8 @@ __device__ __forceinline__ f32x16 mma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3
 // (every K tile re-reads (BM+BN)*128 B through the vector L1), not by MFMA or VALU issue -- so the big shapes use
 // 256x256 tiles on 1024 threads (half the L1 lines per flop), with both operands kept fp32 in memory (4 B/element) and
 // split to bf16 in registers on their way to LDS.
-template <int MODE, int TM, int TN, int WGM, int WGN>
-__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4 < 2 ? 2 : (WGM * WGN) / 4) void conv_x6_kernel(const ConvQ p) {
+template <int MODE, int TM, int TN, int WGM, int WGN, int DB = 0>
+__global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 : (WGM * WGN) / 4)) void conv_x6_kernel(const ConvQ p) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, BK = 32;
     constexpr int A_PLANE = BM * ROWB, B_PLANE = BN * ROWB;      // bytes
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4 < 2 ? 2 : (WGM * WG
     constexpr int NA = BM / RPP, NB = BN / RPP;
     static_assert(NA >= 1 && NB >= 1, "tile too small for the thread count");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int STAGE = 3 * (A_PLANE + B_PLANE);  // bytes per LDS stage
     unsigned char* As = smem;                       // [3][BM][80]
     unsigned char* Bs = smem + 3 * A_PLANE;         // [3][BN][80]
 
@@ -170,7 +172,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4 < 2 ? 2 : (WGM * WG
             rb[i] = (kok && b_ok[i]) ? ld4(p.b + off) : zero4;
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int sb = 0) {
+        unsigned char* As = smem + sb * STAGE;
+        unsigned char* Bs = As + 3 * A_PLANE;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             u32x2 q1, q2, q3;
@@ -199,12 +203,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4 < 2 ? 2 : (WGM * WG
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tile(0);
-    store_tile();
-    __syncthreads();
     const int arow = wm * 32 * TM + l31, brow = wn * 32 * TN + l31;
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) load_tile(kt + 1);
+    auto compute = [&](int sb) {
+        const unsigned char* As = smem + sb * STAGE;
+        const unsigned char* Bs = As + 3 * A_PLANE;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 af[TM][3], bfr[TN][3];
@@ -223,10 +225,65 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4 < 2 ? 2 : (WGM * WG
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = mma6(af[i], bfr[j], acc[i][j]);
         }
-        __syncthreads();                      // every wave is done reading the LDS planes
-        if (kt + 1 < nkt) {
-            store_tile();
+    };
+    if constexpr (DB) {
+        // software-pipelined form (1 block per CU): the fragments of tile kt are read from LDS stage kt&1 into registers
+        // first; then the 48 MFMAs of the tile are interleaved (sched_group_barrier) with the split of tile kt+1 into the
+        // other stage and the global loads of tile kt+2 -- VALU / LDS-write / VMEM work sits in the shadow of the MFMAs of
+        // the same instruction stream; one barrier per tile.
+        load_tile(0);
+        store_tile(0);
+        if (nkt > 1) load_tile(1);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            const unsigned char* Ac = smem + cur * STAGE;
+            const unsigned char* Bc = Ac + 3 * A_PLANE;
+            bf16x8 af[2][TM][3], bfr[2][TN][3];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        af[s2][i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Ac + pl * A_PLANE + (arow + 32 * i) * ROWB + (2 * s2 + h) * 16));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        bfr[s2][j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bc + pl * B_PLANE + (brow + 32 * j) * ROWB + (2 * s2 + h) * 16));
+            }
+            if (kt + 1 < nkt) {
+                store_tile(cur ^ 1);                 // registers hold tile kt+1
+                if (kt + 2 < nkt) load_tile(kt + 2);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mma6(af[s2][i], bfr[s2][j], acc[i][j]);
+#pragma unroll
+            for (int gq = 0; gq < 12 * TM * TN; ++gq) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);      // up to 6 VALU
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // 1 LDS write
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
+            }
             __syncthreads();
+        }
+    } else {
+        load_tile(0);
+        store_tile();
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            if (kt + 1 < nkt) load_tile(kt + 1);
+            compute(0);
+            __syncthreads();                      // every wave is done reading the LDS planes
+            if (kt + 1 < nkt) {
+                store_tile();
+                __syncthreads();
+            }
         }
     }
 
@@ -319,6 +376,185 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4 < 2 ? 2 : (WGM * WG
                         p.partials[((long long)tile_m * 2 + 0) * p.Nn + n] = sa + sb;
                         p.partials[((long long)tile_m * 2 + 1) * p.Nn + n] = m2;
                     }
+                }
+            }
+        }
+    }
+}
+
+// ============================================================================================ 1x1 / stride-1 fast path
+// C[M][N] = A[M][K] * B[N][K]^T for pointwise convolutions (fprop: A = x, B = W; dgrad: A = dy, B = Wt) -- ~60 % of the
+// conv flops of the step.  Software-pipelined, one block (4 waves, 128x128 tile) per CU with two LDS stages:
+//   iteration kt:  read the fragments of tile kt from stage kt&1 -> registers;
+//                  48 MFMAs interleaved (sched_group_barrier) with { split tile kt+1 (registers) -> other stage,
+//                  issue the global loads of tile kt+2 };   one barrier.
+// The steady-state loop body is ONE basic block (branch-free clamped loads, no tap arithmetic) so that hipcc can place
+// the VALU / LDS-write / VMEM work in the shadow of the MFMAs.
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void gemm_x6_kernel(const ConvQ p) {
+    constexpr int BM = 128, BN = 128, BK = 32;
+    constexpr int A_PLANE = BM * ROWB, B_PLANE = BN * ROWB, STAGE = 3 * (A_PLANE + B_PLANE);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const unsigned nblk = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+    const unsigned bid = xcd_remap(blockIdx.x, nblk);
+    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nkt = (p.K + BK - 1) / BK;
+    const int kc = t & 7, r0 = t >> 3;
+
+    // row pointers (clamped to the last valid row: out-of-range rows compute garbage that the epilogue never stores)
+    const float* ap[4];
+    const float* bp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = min(m0 + r0 + 32 * i, p.M - 1), n = min(n0 + r0 + 32 * i, p.Nn - 1);
+        ap[i] = p.a + (long long)m * p.lda + 4 * kc;
+        bp[i] = p.b + (long long)n * p.ldb + 4 * kc;
+    }
+    f32x4 ra[4], rb[4];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto load_full = [&]() {                 // tile completely inside K
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ra[i] = ld4(ap[i]); rb[i] = ld4(bp[i]); ap[i] += BK; bp[i] += BK; }
+    };
+    auto load_tail = [&](int kt) {           // last tile: mask k >= K (no out-of-bounds reads)
+        const bool ok = kt * BK + 4 * kc < p.K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ra[i] = ok ? ld4(ap[i]) : zero4; rb[i] = ok ? ld4(bp[i]) : zero4; ap[i] += BK; bp[i] += BK; }
+    };
+    auto load_any = [&](int kt) { if ((kt + 1) * BK <= p.K) load_full(); else load_tail(kt); };
+    auto store_tile = [&](int sb) {
+        unsigned char* As = smem + sb * STAGE;
+        unsigned char* Bs = As + 3 * A_PLANE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int off = (r0 + 32 * i) * ROWB + kc * 8;
+            u32x2 q1, q2, q3;
+            split4(ra[i], q1, q2, q3);
+            *reinterpret_cast<u32x2*>(As + off) = q1;
+            *reinterpret_cast<u32x2*>(As + A_PLANE + off) = q2;
+            *reinterpret_cast<u32x2*>(As + 2 * A_PLANE + off) = q3;
+            split4(rb[i], q1, q2, q3);
+            *reinterpret_cast<u32x2*>(Bs + off) = q1;
+            *reinterpret_cast<u32x2*>(Bs + B_PLANE + off) = q2;
+            *reinterpret_cast<u32x2*>(Bs + 2 * B_PLANE + off) = q3;
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int arow = wm * 64 + l31, brow = wn * 64 + l31;
+    bf16x8 af[2][2][3], bfr[2][2][3];
+    auto read_frags = [&](int sb) {
+        const unsigned char* Ac = smem + sb * STAGE;
+        const unsigned char* Bc = Ac + 3 * A_PLANE;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    af[s2][i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Ac + pl * A_PLANE + (arow + 32 * i) * ROWB + (2 * s2 + h) * 16));
+                    bfr[s2][i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bc + pl * B_PLANE + (brow + 32 * i) * ROWB + (2 * s2 + h) * 16));
+                }
+    };
+    auto mfmas = [&]() {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mma6(af[s2][i], bfr[s2][j], acc[i][j]);
+    };
+
+    load_any(0);
+    store_tile(0);
+    if (nkt > 1) load_any(1);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 2 < nkt && (kt + 3) * BK <= p.K; ++kt) {       // steady state: tiles kt+1 (registers) and kt+2 (full) exist
+        const int cur = kt & 1;
+        read_frags(cur);
+        store_tile(cur ^ 1);
+        load_full();
+        mfmas();
+#pragma unroll
+        for (int gq = 0; gq < 48; ++gq) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);      // 5 VALU
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // 1 LDS write
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
+        }
+        __syncthreads();
+    }
+    for (; kt < nkt; ++kt) {                                    // drain (and the masked K tail)
+        const int cur = kt & 1;
+        read_frags(cur);
+        if (kt + 1 < nkt) {
+            store_tile(cur ^ 1);
+            if (kt + 2 < nkt) load_any(kt + 2);
+        }
+        mfmas();
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ epilogue
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + 32 * j + l31;
+        const bool nok = n < p.Nn;
+        float bias = 0.f;
+        if constexpr (MODE == FPROP) bias = (p.extra != nullptr && nok) ? p.extra[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < p.M && nok) {
+                    float v = acc[i][j][r];
+                    if constexpr (MODE == FPROP) v += bias;
+                    else if (p.extra != nullptr) v += p.extra[(long long)m * p.ldadd + n];
+                    p.c[(long long)m * p.ldc + n] = v;
+                }
+            }
+    }
+    if constexpr (MODE == FPROP) {
+        if (p.partials != nullptr) {
+            const int wrow0 = m0 + wm * 64;
+            const int nw = max(0, min(64, p.M - wrow0));
+            const int pidx = tile_m * 2 + wm;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float ss = 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = wrow0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        ss += (nw == 64 || row < p.M) ? acc[i][j][r] : 0.f;          // clamped rows hold garbage: mask them
+                    }
+                ss += __shfl_xor(ss, 32, 64);
+                const float mean = nw > 0 ? ss / (float)nw : 0.f;
+                float qq = 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = wrow0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const float dv = acc[i][j][r] - mean;
+                        qq += (nw == 64 || row < p.M) ? dv * dv : 0.f;
+                    }
+                qq += __shfl_xor(qq, 32, 64);
+                const int n = n0 + wn * 64 + 32 * j + l31;
+                if (h == 0 && pidx < p.n_partials && n < p.Nn) {
+                    p.partials[((long long)pidx * 2 + 0) * p.Nn + n] = ss;
+                    p.partials[((long long)pidx * 2 + 1) * p.Nn + n] = qq;
                 }
             }
         }
@@ -534,23 +770,47 @@ extern "C" int sh_weight_transpose(const float* w, float* wt, int Cout, int KH, 
 }
 
 // ---------------------------------------------------------------------------------------- host side
-template <int MODE, int TM, int TN, int WGM, int WGN>
+template <int MODE, int TM, int TN, int WGM, int WGN, int DB = 0>
 static int launch_x6(ConvQ& p, hipStream_t st) {
     constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
-    constexpr size_t lds = 3 * (size_t)(BM + BN) * ROWB;
+    constexpr size_t lds = (DB ? 2 : 1) * 3 * (size_t)(BM + BN) * ROWB;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6_kernel<MODE, TM, TN, WGM, WGN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6_kernel<MODE, TM, TN, WGM, WGN, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     p.tiles_m = (int)sh_cdiv(p.M, BM);
     p.tiles_n = (int)sh_cdiv(p.Nn, BN);
-    conv_x6_kernel<MODE, TM, TN, WGM, WGN><<<(unsigned)(p.tiles_m * p.tiles_n), 64 * WGM * WGN, lds, st>>>(p);
+    conv_x6_kernel<MODE, TM, TN, WGM, WGN, DB><<<(unsigned)(p.tiles_m * p.tiles_n), 64 * WGM * WGN, lds, st>>>(p);
+    return sh_launch_status();
+}
+static int x6_variant() { static int v = -1; if (v < 0) { const char* e = getenv("SEGHIERO_X6_VARIANT"); v = e ? atoi(e) : 0; } return v; }
+template <int MODE>
+static int launch_gemm_x6(ConvQ& p, hipStream_t st) {
+    constexpr size_t lds = 2 * 3 * (size_t)(128 + 128) * ROWB;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    p.tiles_m = (int)sh_cdiv(p.M, 128);
+    p.tiles_n = (int)sh_cdiv(p.Nn, 128);
+    gemm_x6_kernel<MODE><<<(unsigned)(p.tiles_m * p.tiles_n), 256, lds, st>>>(p);
     return sh_launch_status();
 }
 template <int MODE>
 static int launch_conv_x6(ConvQ& p, hipStream_t st) {
     const long long M = p.M, N = p.Nn;
+    // pointwise, stride 1 (a plain NT GEMM) with a long K: software-pipelined kernel (1 block per CU).  Measured
+    // (tools/bench_conv.py): it wins for K >= 1024 (1024->256 @32^2: 56 vs 76 us) and loses for short K, where its
+    // un-overlapped prologue / epilogue dominate (64->256 @128^2: 221 vs 136 us), so short-K shapes keep the 2-blocks/CU form.
+    if (x6_variant() != 3 && p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0 && !p.scatter && N >= 96 && p.K >= 1024 &&
+        sh_cdiv(M, 128) * sh_cdiv(N, 128) >= 192) {
+        p.ldb = (MODE == FPROP) ? p.K : p.Kc;
+        return launch_gemm_x6<MODE>(p, st);
+    }
+    if (x6_variant() == 1) return launch_x6<MODE, 2, 2, 2, 2, 1>(p, st);      // experiment: software-pipelined 128x128
+    if (x6_variant() == 2) return launch_x6<MODE, 2, 2, 4, 2, 1>(p, st);      // experiment: software-pipelined 256x128 (512 thr)
     // big tiles while they still give >= 2 blocks per CU (they halve the L1 traffic per flop), then the 128/64 family
     if (N > 128 && sh_cdiv(M, 256) * sh_cdiv(N, 256) >= 512) return launch_x6<MODE, 2, 2, 4, 4>(p, st);
     if (N > 64 && sh_cdiv(M, 256) * sh_cdiv(N, 128) >= 512) return launch_x6<MODE, 2, 2, 4, 2>(p, st);
