@@ -29,6 +29,7 @@ struct ConvQ {
     int Kreal;              // channels actually present per tap in the A rows (dgrad: pad4(Cout); fprop: Cin)
     long long bplane;       // elements per B plane
     int scatter, sH, sW, sstride;
+    int parity;             // dgrad of a stride-2 KxK conv: blockIdx.y = input-pixel parity class (only its taps are non-zero)
     int kchunk;
     int tiles_m, tiles_n, n_partials;
 };
@@ -98,7 +99,20 @@ __global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 :
     const unsigned bid = xcd_remap(blockIdx.x, nblk);
     const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int nkt = (p.K + BK - 1) / BK;
+    // stride-2 dgrad by parity class: an input pixel (ih, iw) only sees taps with kh == (ih+pad) mod 2 (same for kw), so the
+    // four classes run as separate GEMMs over a quarter of the pixels with 1/2/2/4 of the 9 taps instead of 9 zero-filled ones
+    int cy = 0, cx = 0, Hc = p.H, Wc = p.W, oy0 = 0, ox0 = 0, nth = p.KH, ntw = p.KW, Mc = p.M, Kt = p.K;
+    if constexpr (MODE == DGRAD) {
+        if (p.parity) {
+            cy = blockIdx.y >> 1; cx = blockIdx.y & 1;
+            oy0 = (cy + p.pad) & 1; ox0 = (cx + p.pad) & 1;          // first input row / column with (i + pad) % 2 == c
+            Hc = (p.H - oy0 + 1) >> 1; Wc = (p.W - ox0 + 1) >> 1;
+            nth = (p.KH - cy + 1) >> 1; ntw = (p.KW - cx + 1) >> 1;
+            Mc = p.N * Hc * Wc; Kt = nth * ntw * p.Kc;
+            if (m0 >= Mc) return;                                    // block-uniform, before any barrier
+        }
+    }
+    const int nkt = (Kt + BK - 1) / BK;
     const bool single_tap = p.KH * p.KW == 1;
     const bool tap_uniform = single_tap || (p.Kc & 31) == 0;     // a K tile never straddles taps => tap math is scalar
 
@@ -107,12 +121,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 :
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int m = m0 + r0 + RPP * i;
-        if (m < p.M) {
+        if (m < Mc) {
             if constexpr (MODE == FPROP) {
                 const int ow = m % p.Wo, q = m / p.Wo, oh = q % p.Ho, n = q / p.Ho;
                 a_y[i] = oh * p.stride - p.pad; a_x[i] = ow * p.stride - p.pad; a_nb[i] = n * p.H * p.W;
             } else {
-                const int iw = m % p.W, q = m / p.W, ih = q % p.H, n = q / p.H;
+                const int iwc = m % Wc, q = m / Wc, ihc = q % Hc, n = q / Hc;
+                const int ih = p.parity ? 2 * ihc + oy0 : ihc, iw = p.parity ? 2 * iwc + ox0 : iwc;
                 a_y[i] = ih + p.pad; a_x[i] = iw + p.pad; a_nb[i] = n * p.Ho * p.Wo;
             }
         } else { a_y[i] = -(1 << 28); a_x[i] = 0; a_nb[i] = 0; }
@@ -121,7 +136,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 :
     bool a_ok[NA];
     int cur_tap = -1;
     auto set_tap = [&](int tap) {
-        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        int kh, kw;
+        if (MODE == DGRAD && p.parity) { const int ty = tap / ntw; kh = cy + 2 * ty; kw = cx + 2 * (tap - ty * ntw); }
+        else { kh = tap / p.KW; kw = tap - kh * p.KW; }
         const int dh = kh * p.dil, dw = kw * p.dil;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -160,15 +177,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 :
         if (single_tap) { tap = 0; cc = kbase + 4 * kc; }
         else if (tap_uniform) { tap = kbase / p.Kc; cc = kbase - tap * p.Kc + 4 * kc; }
         else { const int k = kbase + 4 * kc; tap = k / p.Kc; cc = k - tap * p.Kc; }
-        const bool kok = (kbase + 4 * kc) < p.K;
+        const bool kok = (kbase + 4 * kc) < Kt;
         if (!tap_uniform || tap != cur_tap) { set_tap(tap); cur_tap = tap; }
+        int wtap = tap;                                           // tap index into the weight tensor
+        if (MODE == DGRAD && p.parity) { const int ty = tap / ntw; wtap = (cy + 2 * ty) * p.KW + cx + 2 * (tap - ty * ntw); }
 #pragma unroll
         for (int i = 0; i < NA; ++i) ra[i] = (kok && a_ok[i]) ? ld4(p.a + a_off[i] + cc) : zero4;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             long long off;
             if constexpr (MODE == FPROP) off = b_row[i] + kbase + 4 * kc;
-            else off = (long long)tap * p.Cin * p.Kc + b_row[i] + cc;
+            else off = (long long)wtap * p.Cin * p.Kc + b_row[i] + cc;
             rb[i] = (kok && b_ok[i]) ? ld4(p.b + off) : zero4;
         }
     };
@@ -299,12 +318,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 :
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 32 * TM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m < p.M && nok) {
+                if (m < Mc && nok) {
                     if constexpr (MODE == FPROP) {
                         p.c[(long long)m * p.ldc + n] = acc[i][j][r] + bias;
                     } else {
                         float v = acc[i][j][r];
-                        if (p.extra != nullptr) v += p.extra[(long long)m * p.ldadd + n];
+                        long long mo = m;                         // output pixel row
+                        if (p.parity) {
+                            const int iwc = m % Wc, q2 = m / Wc, ihc = q2 % Hc, nb2 = q2 / Hc;
+                            mo = ((long long)nb2 * p.H + 2 * ihc + oy0) * p.W + 2 * iwc + ox0;
+                        }
+                        if (p.extra != nullptr) v += p.extra[mo * p.ldadd + n];
+                        if (p.parity) { p.c[mo * p.ldc + n] = v; continue; }
                         if (p.scatter) {
                             const int ow = m % p.W, q = m / p.W, oh = q % p.H, nb = q / p.H;
                             float* dst = p.c + ((long long)(nb * p.sH + oh * p.sstride) * p.sW + ow * p.sstride) * p.ldc + n;
@@ -781,7 +806,8 @@ static int launch_x6(ConvQ& p, hipStream_t st) {
     }
     p.tiles_m = (int)sh_cdiv(p.M, BM);
     p.tiles_n = (int)sh_cdiv(p.Nn, BN);
-    conv_x6_kernel<MODE, TM, TN, WGM, WGN, DB><<<(unsigned)(p.tiles_m * p.tiles_n), 64 * WGM * WGN, lds, st>>>(p);
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), p.parity ? 4u : 1u);
+    conv_x6_kernel<MODE, TM, TN, WGM, WGN, DB><<<grid, 64 * WGM * WGN, lds, st>>>(p);
     return sh_launch_status();
 }
 static int x6_variant() { static int v = -1; if (v < 0) { const char* e = getenv("SEGHIERO_X6_VARIANT"); v = e ? atoi(e) : 0; } return v; }
@@ -864,6 +890,10 @@ extern "C" int sh_conv_dgrad_x6(const float* dy, int lddy, const float* wt, cons
         p.M = N * p.Ho * p.Wo;
     } else if (mode == 0) {
         p.M = N * H * W;
+        if (stride == 2 && dil == 1 && KH * KW > 1) {      // parity classes: tile over the largest class
+            p.parity = 1;
+            p.M = N * ((H + 1) / 2) * ((W + 1) / 2);
+        }
     } else return SH_EINVAL;
     return launch_conv_x6<DGRAD>(p, (hipStream_t)stream);
 }

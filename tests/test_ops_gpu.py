@@ -45,6 +45,8 @@ CONV_CASES = [
     (2, 12, 12, 32, 32, 3, 1, 12, 12),    # dilated dense conv
     (16, 1, 1, 64, 32, 1, 1, 0, 1),       # image-pool conv: M = batch
     (2, 40, 40, 64, 160, 3, 1, 1, 1),
+    (2, 17, 13, 32, 64, 3, 2, 1, 1),      # stride-2 3x3 on odd sizes (parity-class dgrad)
+    (1, 9, 9, 64, 32, 5, 2, 2, 1),        # stride-2 5x5
 ]
 
 
