@@ -99,6 +99,135 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
     }
 }
 
+// ---------------------------------------------------------------------------------------------- 2-D tiled form (dilation 1)
+// One block = an 8x8 pixel tile x 64 channels.  The 10x10 input halo is staged ONCE in LDS (25.6 KB), so every input
+// element crosses L2->CU once instead of up to nine times; used when H and W are multiples of 8 (the decoder's 128x128).
+#define DT 8
+template <int MODE>   // 0 fprop (+stats), 1 dgrad (flipped taps, optional accumulate)
+__global__ __launch_bounds__(256) void dwconv_tile_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ w,
+                                                          float* __restrict__ y, long long ldy, float* __restrict__ partials,
+                                                          int H, int W, int C, int accumulate) {
+    __shared__ __attribute__((aligned(16))) float xs[(DT + 2) * (DT + 2)][DW_CH];
+    __shared__ float ws[9][DW_CH];
+    __shared__ float red[16][DW_CH];
+    __shared__ float colmean[DW_CH];
+    const int t = threadIdx.x, cq = t & 15, pl = t >> 4;
+    const int c0 = blockIdx.y * DW_CH;
+    const int tiles_x = W / DT, tiles_y = H / DT;
+    const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y;
+    const long long n = blockIdx.x / (tiles_x * tiles_y);
+    for (int i = t; i < 9 * DW_CH; i += 256) {
+        const int tap = i / DW_CH, cc = i % DW_CH;
+        ws[tap][cc] = (c0 + cc < C) ? w[(long long)(c0 + cc) * 9 + (MODE == 0 ? tap : 8 - tap)] : 0.f;
+    }
+    const int c = c0 + cq * 4;
+    const bool cok = c < C;
+    for (int i = pl; i < (DT + 2) * (DT + 2); i += 16) {
+        const int hy = i / (DT + 2), hx = i - hy * (DT + 2);
+        const int iy = ty * DT + hy - 1, ix = tx * DT + hx - 1;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (cok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = ld4(x + ((n * H + iy) * W + ix) * ldx + c);
+        st4(&xs[i][cq * 4], v);
+    }
+    __syncthreads();
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    f32x4 kept[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int pidx = it * 16 + pl, py = pidx / DT, px = pidx - py * DT;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+                acc += ld4(&xs[(py + kh) * (DT + 2) + px + kw][cq * 4]) * ld4(&ws[kh * 3 + kw][cq * 4]);
+        kept[it] = acc;
+        if (cok) {
+            float* dst = y + ((n * H + ty * DT + py) * W + tx * DT + px) * ldy + c;
+            if (MODE == 1 && accumulate) acc += ld4(dst);
+            st4(dst, acc);
+        }
+        s += kept[it];
+    }
+    if (MODE == 0 && partials != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[pl][cq * 4 + j] = s[j];
+        __syncthreads();
+        float colsum = 0.f;
+        if (t < DW_CH) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) colsum += red[k][t];
+            colmean[t] = colsum / (float)(DT * DT);
+        }
+        __syncthreads();
+        f32x4 q = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 mu = ld4(&colmean[cq * 4]);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) { const f32x4 dv = kept[it] - mu; q += dv * dv; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[pl][cq * 4 + j] = q[j];
+        __syncthreads();
+        if (t < DW_CH && c0 + t < C) {
+            float m2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) m2 += red[k][t];
+            partials[((long long)blockIdx.x * 2 + 0) * C + c0 + t] = colsum;
+            partials[((long long)blockIdx.x * 2 + 1) * C + c0 + t] = m2;
+        }
+    }
+}
+// wgrad, tiled: each block walks tiles (grid-stride), x halo staged in LDS, nine accumulators per thread
+__global__ __launch_bounds__(256) void dwconv_wgrad_tile_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ dy,
+                                                               long long lddy, float* __restrict__ partials, int H, int W, int C,
+                                                               long long ntiles) {
+    __shared__ __attribute__((aligned(16))) float xs[(DT + 2) * (DT + 2)][DW_CH];
+    __shared__ float red[16][DW_CH];
+    const int t = threadIdx.x, cq = t & 15, pl = t >> 4;
+    const int c0 = blockIdx.y * DW_CH, c = c0 + cq * 4;
+    const bool cok = c < C;
+    const int tiles_x = W / DT, tiles_y = H / DT;
+    f32x4 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
+        const long long n = tile / (tiles_x * tiles_y);
+        __syncthreads();
+        for (int i = pl; i < (DT + 2) * (DT + 2); i += 16) {
+            const int hy = i / (DT + 2), hx = i - hy * (DT + 2);
+            const int iy = ty * DT + hy - 1, ix = tx * DT + hx - 1;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (cok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = ld4(x + ((n * H + iy) * W + ix) * ldx + c);
+            st4(&xs[i][cq * 4], v);
+        }
+        __syncthreads();
+        if (cok) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int pidx = it * 16 + pl, py = pidx / DT, px = pidx - py * DT;
+                const f32x4 g = ld4(dy + ((n * H + ty * DT + py) * W + tx * DT + px) * lddy + c);
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] += g * ld4(&xs[(py + kh) * (DT + 2) + px + kw][cq * 4]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[pl][cq * 4 + j] = acc[k][j];
+        __syncthreads();
+        if (t < DW_CH) {
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a += red[r][t];
+            if (c0 + t < C) partials[((long long)blockIdx.x * 9 + k) * C + c0 + t] = a;
+        }
+    }
+}
+
 // wgrad: dw[c][tap] = sum_pix dy[pix][c] * x[pix + tap][c]; per-block partials [P][9][C], then a column reduce.
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ dy,
                                                            long long lddy, float* __restrict__ partials, int H, int W, int C,
@@ -173,7 +302,10 @@ extern "C" int sh_dwconv_fprop(const float* x, int ldx, const float* w, float* y
     if (!dw_args_ok(x, w, y, N, H, W, C, dil, ldx, ldy)) return SH_EINVAL;
     const long long M = (long long)N * H * W;
     dim3 grid((unsigned)sh_cdiv(M, DW_PIX), (unsigned)sh_cdiv(C, DW_CH));
-    dwconv_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, w, y, ldy, stat_partials, H, W, C, dil, M, 0);
+    if (dil == 1 && H % DT == 0 && W % DT == 0)       // same partial count: (H/8)*(W/8) tiles of 64 pixels per image
+        dwconv_tile_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, w, y, ldy, stat_partials, H, W, C, 0);
+    else
+        dwconv_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, w, y, ldy, stat_partials, H, W, C, dil, M, 0);
     return sh_launch_status();
 }
 extern "C" int sh_dwconv_dgrad(const float* dy, int lddy, const float* w, float* dx, int lddx, int N, int H, int W, int C,
@@ -181,7 +313,10 @@ extern "C" int sh_dwconv_dgrad(const float* dy, int lddy, const float* w, float*
     if (!dw_args_ok(dy, w, dx, N, H, W, C, dil, lddy, lddx)) return SH_EINVAL;
     const long long M = (long long)N * H * W;
     dim3 grid((unsigned)sh_cdiv(M, DW_PIX), (unsigned)sh_cdiv(C, DW_CH));
-    dwconv_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(dy, lddy, w, dx, lddx, nullptr, H, W, C, dil, M, accumulate);
+    if (dil == 1 && H % DT == 0 && W % DT == 0)
+        dwconv_tile_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(dy, lddy, w, dx, lddx, nullptr, H, W, C, accumulate);
+    else
+        dwconv_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(dy, lddy, w, dx, lddx, nullptr, H, W, C, dil, M, accumulate);
     return sh_launch_status();
 }
 extern "C" int sh_dwconv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw_partials, float* dw,
@@ -192,7 +327,10 @@ extern "C" int sh_dwconv_wgrad(const float* x, int ldx, const float* dy, int ldd
     const int cap = (int)sh_cdiv(1024, sh_cdiv(C, DW_CH));          // ~4 blocks per CU over all channel chunks
     if (P > cap) P = cap < 1 ? 1 : cap;
     dim3 grid((unsigned)P, (unsigned)sh_cdiv(C, DW_CH));
-    dwconv_wgrad_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, dy, lddy, dw_partials, H, W, C, dil, M);
+    if (dil == 1 && H % DT == 0 && W % DT == 0)
+        dwconv_wgrad_tile_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, dy, lddy, dw_partials, H, W, C, M / (DT * DT));
+    else
+        dwconv_wgrad_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, dy, lddy, dw_partials, H, W, C, dil, M);
     int rc = sh_launch_status();
     if (rc != SH_OK) return rc;
     dwconv_wgrad_reduce_kernel<<<(unsigned)sh_cdiv(9 * C, 64), 256, 0, (hipStream_t)stream>>>(dw_partials, dw, P, C);

@@ -108,7 +108,7 @@ def test_conv_reads_and_writes_channel_slices(ops):
 
 
 @pytest.mark.parametrize("shape,dil", [((2, 64, 16, 16), 1), ((2, 64, 16, 16), 12), ((2, 32, 16, 16), 24),
-                                       ((2, 560, 9, 11), 1), ((1, 8, 5, 7), 2)])
+                                       ((2, 560, 9, 11), 1), ((1, 8, 5, 7), 2), ((2, 72, 16, 24), 1), ((3, 64, 8, 8), 1)])
 def test_dwconv(ops, shape, dil):
     n, c, h, w = shape
     g = torch.Generator().manual_seed(c + dil)
