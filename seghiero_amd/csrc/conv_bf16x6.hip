@@ -228,21 +228,21 @@ __global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 :
         const unsigned char* Bs = As + 3 * A_PLANE;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 af[TM][3], bfr[TN][3];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    af[i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + pl * A_PLANE + (arow + 32 * i) * ROWB + (2 * s + h) * 16));
+            bf16x8 bfr[TN][3];
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
                     bfr[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + pl * B_PLANE + (brow + 32 * j) * ROWB + (2 * s + h) * 16));
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
+                bf16x8 af[3];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = mma6(af[i], bfr[j], acc[i][j]);
+                for (int pl = 0; pl < 3; ++pl)
+                    af[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + pl * A_PLANE + (arow + 32 * i) * ROWB + (2 * s + h) * 16));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mma6(af, bfr[j], acc[i][j]);
+            }
         }
     };
     if constexpr (DB) {
@@ -346,41 +346,57 @@ __global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 :
             const int wrow0 = m0 + wm * 32 * TM;
             const int nw = max(0, min(32 * TM, p.M - wrow0));
             float s[TN], q[TN];
+            if constexpr (TM % 2 == 0) {      // a wave covers TM/2 whole 64-row partials
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                float ss = 0.f;
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) ss += acc[i][j][r];
-                ss += __shfl_xor(ss, 32, 64);
-                const float mean = nw > 0 ? ss / (float)nw : 0.f;
-                float qq = 0.f;
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = wrow0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        const float dv = acc[i][j][r] - mean;
-                        qq += (nw == 32 * TM || row < p.M) ? dv * dv : 0.f;
-                    }
-                qq += __shfl_xor(qq, 32, 64);
-                s[j] = ss; q[j] = qq;
-            }
-            if constexpr (TM == 2) {          // a wave covers exactly one 64-row partial
-                const int pidx = tile_m * (BM / 64) + wm;
-                if (h == 0 && pidx < p.n_partials) {
+                for (int pr = 0; pr < TM / 2; ++pr) {
+                    const int prow0 = wrow0 + 64 * pr;
+                    const int npr = max(0, min(64, p.M - prow0));
+                    const int pidx = tile_m * (BM / 64) + wm * (TM / 2) + pr;
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
+                        float ss = 0.f;
+#pragma unroll
+                        for (int i = 2 * pr; i < 2 * pr + 2; ++i)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) ss += acc[i][j][r];      // rows >= M are exact zeros
+                        ss += __shfl_xor(ss, 32, 64);
+                        const float mean = npr > 0 ? ss / (float)npr : 0.f;
+                        float qq = 0.f;
+#pragma unroll
+                        for (int i = 2 * pr; i < 2 * pr + 2; ++i)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int row = wrow0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                                const float dv = acc[i][j][r] - mean;
+                                qq += (npr == 64 || row < p.M) ? dv * dv : 0.f;
+                            }
+                        qq += __shfl_xor(qq, 32, 64);
                         const int n = n0 + wn * 32 * TN + 32 * j + l31;
-                        if (n < p.Nn) {
-                            p.partials[((long long)pidx * 2 + 0) * p.Nn + n] = s[j];
-                            p.partials[((long long)pidx * 2 + 1) * p.Nn + n] = q[j];
+                        if (h == 0 && pidx < p.n_partials && n < p.Nn) {
+                            p.partials[((long long)pidx * 2 + 0) * p.Nn + n] = ss;
+                            p.partials[((long long)pidx * 2 + 1) * p.Nn + n] = qq;
                         }
                     }
                 }
             } else {                          // TM == 1 (only instantiated with WGM == 2): two waves share the 64-row partial
-                static_assert(TM == 2 || WGM == 2, "TM == 1 variants use a 2-wave M grid");
+                static_assert(TM % 2 == 0 || WGM == 2, "TM == 1 variants use a 2-wave M grid");
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float ss = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ss += acc[0][j][r];
+                    ss += __shfl_xor(ss, 32, 64);
+                    const float mean = nw > 0 ? ss / (float)nw : 0.f;
+                    float qq = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const float dv = acc[0][j][r] - mean;
+                        qq += (nw == 32 || row < p.M) ? dv * dv : 0.f;
+                    }
+                    qq += __shfl_xor(qq, 32, 64);
+                    s[j] = ss; q[j] = qq;
+                }
                 float* red = reinterpret_cast<float*>(smem);      // main loop ended with a barrier
                 if (h == 0) {
 #pragma unroll
@@ -838,6 +854,8 @@ static int launch_conv_x6(ConvQ& p, hipStream_t st) {
     if (x6_variant() == 1) return launch_x6<MODE, 2, 2, 2, 2, 1>(p, st);      // experiment: software-pipelined 128x128
     if (x6_variant() == 2) return launch_x6<MODE, 2, 2, 4, 2, 1>(p, st);      // experiment: software-pipelined 256x128 (512 thr)
     // big tiles while they still give >= 2 blocks per CU (they halve the L1 traffic per flop), then the 128/64 family
+    // (measured: 8 waves of 128x64 per 256x256 block -- half the LDS fragment reads per MFMA -- run at the same speed as
+    //  16 waves of 64x64, and its dgrad instantiation spills; the 16-wave form is used for both)
     if (N > 128 && sh_cdiv(M, 256) * sh_cdiv(N, 256) >= 512) return launch_x6<MODE, 2, 2, 4, 4>(p, st);
     if (N > 64 && sh_cdiv(M, 256) * sh_cdiv(N, 128) >= 512) return launch_x6<MODE, 2, 2, 4, 2>(p, st);
     int TN = N <= 64 ? 1 : 2, TM = 2;
@@ -902,7 +920,7 @@ struct WgX6Plan { int wgm, wgn, splits, kchunk; };
 static WgX6Plan wgrad_plan_x6(int Cout, long long Nn, long long npix) {
     WgX6Plan g;
     // measured (tools/bench_conv.py): 128x256 helps the narrow-Cout shapes, 256x256 on 1024 threads does not help wgrad
-    g.wgm = 2;
+    g.wgm = Cout <= 64 ? 1 : 2;
     g.wgn = (Nn >= 256 && Cout <= 128) ? 4 : 2;
     const long long tiles = sh_cdiv(Cout, 64 * g.wgm) * sh_cdiv(Nn, 64 * g.wgn);
     long long s = sh_cdiv(g.wgm * g.wgn >= 16 ? 512 : 640, tiles), maxs = sh_cdiv(npix, 256);
@@ -946,6 +964,8 @@ extern "C" int sh_conv_wgrad_x6(const float* x, int ldx, const float* dy, int ld
     if (g.wgm == 4 && g.wgn == 4) rc = launch_wgrad_x6<4, 4>(p, g.splits, st);
     else if (g.wgm == 2 && g.wgn == 4) rc = launch_wgrad_x6<2, 4>(p, g.splits, st);
     else if (g.wgm == 4 && g.wgn == 2) rc = launch_wgrad_x6<4, 2>(p, g.splits, st);
+    else if (g.wgm == 1 && g.wgn == 4) rc = launch_wgrad_x6<1, 4>(p, g.splits, st);
+    else if (g.wgm == 1 && g.wgn == 2) rc = launch_wgrad_x6<1, 2>(p, g.splits, st);
     else rc = launch_wgrad_x6<2, 2>(p, g.splits, st);
     if (rc != SH_OK) return rc;
     const long long n = (long long)Cout * p.Nn, n4 = n / 4;

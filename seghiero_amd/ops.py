@@ -206,8 +206,8 @@ def workspace(nbytes, device, tag="ws"):
 def conv_wgrad(x, dy, dweight, stride, pad, dil):
     n, cin, h, w = x.shape
     o, _, kh, kw = dweight.shape
-    # the x6 wgrad kernel has one tile shape (128x128): narrow outputs stay on the f32-MFMA kernel (64-wide tiles)
-    x6 = CONV_IMPL == "x6" and o >= 128 and cin * kh * kw >= 128
+    # tiny output-channel counts (cls_seg, aux head) stay on the f32-MFMA kernel
+    x6 = CONV_IMPL == "x6" and o >= 32 and cin * kh * kw >= 128
     need = LIB.raw("sh_conv_wgrad_x6_workspace" if x6 else "sh_conv_wgrad_workspace")(n, h, w, cin, o, kh, kw, stride, pad, dil)
     if need < 0:
         raise SegHieroHipError("sh_conv_wgrad_workspace rejected the geometry")
