@@ -220,3 +220,37 @@ def test_three_level_rmi_train_step_config4_family(sa):
         if step == 0:
             assert abs(lm - l32) < 1e-4 * max(1.0, abs(l32)), (lm, l32)
         assert abs(lm - l64) < 4 * abs(l32 - l64) + 1e-4 * max(1.0, abs(l64)), (step, lm, l32, l64)
+
+
+@pytest.mark.parametrize("cfg", ["C2", "C4", "C5"])
+def test_full_size_configs_run_and_stay_finite(sa, cfg):
+    """BASELINE configs at their real sizes (smaller batch): one training step runs, loss and every gradient are finite,
+    parameters move.  Size-independent property: an all-ignore (255) label map gives exactly zero fused-loss gradient."""
+    from seghiero_amd.synthetic import make_batch
+    from seghiero_amd.train_step import SegHieroTrainer
+    torch.manual_seed(0)
+    if cfg == "C2":      # ResNet-50, 2-level, 512x512
+        kw, size, batch, nf = dict(depth=50, n_fine=9, coarse_to_fine_map=[[0, 3], [4, 6], [7], [8]]), 512, 4, 9
+    elif cfg == "C4":    # ResNet-101, 3-level RMI, 512x512
+        kw, size, batch, nf = dict(depth=101, n_fine=7, coarse_to_fine_map=[[0], [1, 4], [5, 6]],
+                                   super_coarse_to_coarse_map=[[0], [1, 6]], fine_weight=0.5), 512, 4, 7
+    else:                # ResNet-101 + aux, 20 fine / 5 coarse, 1024x1024 (fp32 here; bf16 storage is a later round)
+        kw, size, batch, nf = dict(depth=101, n_fine=20, coarse_to_fine_map=[[0, 3], [4, 7], [8, 11], [12, 15], [16, 19]]), 1024, 2, 20
+    tr = SegHieroTrainer(device=DEV, lr=0.01, **kw)
+    tr.train()
+    img, lab = make_batch(batch, size, nf, seed=1, device=DEV)
+    w0 = tr.backbone.layer1[0].conv1.weight.detach().clone()
+    loss = tr.train_step(img, lab, 0)
+    assert torch.isfinite(loss).all(), float(loss)
+    for p in tr.params:
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all())
+    assert not torch.equal(w0, tr.backbone.layer1[0].conv1.weight)
+    # all-void labels: the fused main loss has no valid pixel -> its logits gradient is exactly zero
+    from seghiero_amd import ops
+    void = torch.full_like(lab, 255)
+    logits = torch.randn(batch, tr.aspp_head.cls_seg.out_channels, size // 4, size // 4, device=DEV).requires_grad_(True)
+    emb = torch.nn.functional.normalize(torch.randn(batch, 256, size // 32, size // 32, device=DEV), dim=1)
+    val = tr.hiera_loss_fn(0, emb, None, logits, void)
+    val.backward()
+    if cfg != "C4":      # (the RMI term is not masked by validity in the reference either: one-hot of class 0 on void pixels)
+        assert float(logits.grad.abs().max()) == 0.0
