@@ -104,6 +104,16 @@ int sh_bn_finalize(const float* partials, int n_partials, int C, double count, c
                    const float* beta, float eps, float momentum, float* running_mean,
                    float* running_var, float* mean, float* invstd, float* scale, float* shift,
                    int rows_per_partial, void* stream);
+/* SyncBN building blocks (cross-GPU BatchNorm is new functionality): reduce the partials to f64 per-channel
+ * sums sq[2][C] on each rank (forward: sum x, sum x^2 from the centred partials; backward, rows_per_partial = 0: sum g,
+ * sum g*xhat), all-reduce them over RCCL on the host side, then finalize on the global sums / count. */
+int sh_bn_reduce_partials(const float* partials, int n_partials, int C, double count, int rows_per_partial, double* sq,
+                          void* stream);
+int sh_bn_finalize_sq(const double* sq, int C, double count, const float* gamma, const float* beta, float eps,
+                      float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
+                      float* scale, float* shift, void* stream);
+int sh_bn_bwd_finalize_sq(const double* local_sq, const double* global_sq, int C, double count, float* dgamma,
+                          float* dbeta, float* c1, float* c2, void* stream);
 /* Eval-mode coefficients from the running statistics. */
 int sh_bn_eval_coefs(const float* gamma, const float* beta, const float* running_mean,
                      const float* running_var, float eps, int C, float* scale, float* shift, void* stream);

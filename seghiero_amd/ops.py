@@ -255,8 +255,33 @@ def dwconv_wgrad(x, dy, dweight, dil):
 
 
 # ----------------------------------------------------------------------------- batch norm
+SYNC_BN = False       # True: BatchNorm statistics (forward and backward) are all-reduced over the default process group
+
+
+def _sync_on():
+    return SYNC_BN and torch.distributed.is_available() and torch.distributed.is_initialized() and \
+        torch.distributed.get_world_size() > 1
+
+
+def _all_reduce_sq(sq):
+    from . import ddp
+    ddp.all_reduce(sq)
+    return sq
+
+
 def bn_finalize(partials, count, gamma, beta, eps, momentum, running_mean, running_var, c, device, rows=64):
     coefs = torch.empty((4, c), device=device, dtype=torch.float32)      # mean, invstd, scale, shift
+    if _sync_on():
+        sq = torch.empty((2 * c,), device=device, dtype=torch.float64)
+        _call("sh_bn_reduce_partials", partials.data_ptr(), partials.shape[0], c, float(count), rows, sq.data_ptr(), _st())
+        _all_reduce_sq(sq)
+        total = float(count) * torch.distributed.get_world_size()       # equal per-rank counts (same batch / crop per rank)
+        _call("sh_bn_finalize_sq", sq.data_ptr(), c, total, None if gamma is None else gamma.data_ptr(),
+              None if beta is None else beta.data_ptr(), eps, momentum,
+              None if running_mean is None else running_mean.data_ptr(),
+              None if running_var is None else running_var.data_ptr(),
+              coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(), coefs[3].data_ptr(), _st())
+        return coefs
     _call("sh_bn_finalize", partials.data_ptr(), partials.shape[0], c, float(count),
           None if gamma is None else gamma.data_ptr(), None if beta is None else beta.data_ptr(), eps, momentum,
           None if running_mean is None else running_mean.data_ptr(),
@@ -304,8 +329,15 @@ def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None):
     _call("sh_bn_bwd_reduce", dop, lddo, op, ldo, yp, ldy, coefs[0].data_ptr(), coefs[1].data_ptr(), partials.data_ptr(),
           m, c, int(relu), _st())
     red = torch.empty((4, c), device=dev, dtype=torch.float32)           # dgamma, dbeta, c1, c2
-    _call("sh_bn_bwd_finalize", partials.data_ptr(), p, c, None if gamma is None else gamma.data_ptr(),
-          coefs[1].data_ptr(), float(m), red[0].data_ptr(), red[1].data_ptr(), red[2].data_ptr(), red[3].data_ptr(), _st())
+    if _sync_on():
+        local = torch.empty((2 * c,), device=dev, dtype=torch.float64)
+        _call("sh_bn_reduce_partials", partials.data_ptr(), p, c, float(m), 0, local.data_ptr(), _st())
+        glob = _all_reduce_sq(local.clone())
+        _call("sh_bn_bwd_finalize_sq", local.data_ptr(), glob.data_ptr(), c, float(m) * torch.distributed.get_world_size(),
+              red[0].data_ptr(), red[1].data_ptr(), red[2].data_ptr(), red[3].data_ptr(), _st())
+    else:
+        _call("sh_bn_bwd_finalize", partials.data_ptr(), p, c, None if gamma is None else gamma.data_ptr(),
+              coefs[1].data_ptr(), float(m), red[0].data_ptr(), red[1].data_ptr(), red[2].data_ptr(), red[3].data_ptr(), _st())
     ld = pad4(c) if dy_ld is None else dy_ld
     dy = new_act(n, c, h, w, dev, ld=ld, zero=ld != c)
     dres = new_act(n, c, h, w, dev) if want_dres else None

@@ -1,0 +1,90 @@
+"""Cross-GPU BatchNorm (SyncBN, SURVEY 8e "new functionality"): two ranks, each with half of a batch and SYNC_BN on,
+must reproduce the single-rank full-batch forward, the input-side gradients and (summed over ranks) the parameter
+gradients of backbone + contrast head.  Both ranks share cuda:0 and exchange over gloo (staged through the host by
+seghiero_amd.ddp), which is the rehearsal path for RCCL on a one-GPU box."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HEAD_KW = dict(in_channels=512, c1_in_channels=64, c1_channels=16, aspp_channels=32,
+               dilations=(1, 2, 3, 4), num_classes=6, proj_dim=16, proj_type="convmlp")
+B, S = 4, 96
+
+
+def _run(lo, hi, sync):
+    """forward/backward of R18 trunk + head on images [lo, hi) of the fixed seeded batch"""
+    from seghiero_amd import ops
+    from seghiero_amd.backbone import ResNetBackbone
+    from seghiero_amd.head import DepthwiseSeparableASPPContrastHead
+    ops.SYNC_BN = sync
+    torch.manual_seed(0)
+    bb = ResNetBackbone(depth=18).to("cuda:0").train()
+    head = DepthwiseSeparableASPPContrastHead(**HEAD_KW).to("cuda:0").train()
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, 3, S, S, generator=g)
+    x = x[lo:hi].to("cuda:0").requires_grad_(True)
+    logits, emb = head(bb(x))
+    gl = torch.randn(B, *logits.shape[1:], generator=g)          # fixed per-image output weights of the full batch
+    ge = torch.randn(B, *emb.shape[1:], generator=g)
+    ((logits * gl[lo:hi].to("cuda:0")).sum() + (emb * ge[lo:hi].to("cuda:0")).sum()).backward()
+    torch.cuda.synchronize()
+    named = list(bb.named_parameters()) + list(head.named_parameters())
+    return dict(logits=logits.detach().cpu().numpy(), emb=emb.detach().cpu().numpy(), dx=x.grad.cpu().numpy(),
+                grads={k: p.grad.detach().cpu().numpy().copy() for k, p in named if p.grad is not None},
+                rm=bb.layer4[1].bn2.running_mean.cpu().numpy(), rv=head.sep_bottleneck[1].bn_pw.running_var.cpu().numpy())
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from seghiero_amd import ddp
+    ddp.init_from_env(backend="gloo")
+    n = B // world
+    try:
+        out = _run(rank * n, (rank + 1) * n, sync=True)
+    except Exception as e:                                       # report instead of leaving the parent to time out
+        import traceback
+        out = "rank %d failed: %s\n%s" % (rank, e, traceback.format_exc())
+    q.put((rank, out))
+    if not isinstance(out, str):
+        dist.barrier()
+    dist.destroy_process_group()
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def test_syncbn_two_ranks_equals_full_batch():
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + os.getpid() % 150
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+    for r in res.values():
+        assert not isinstance(r, str), r
+    full = _run(0, B, sync=False)
+    for k in ("logits", "emb", "dx"):
+        got = np.concatenate([res[0][k], res[1][k]], 0)
+        assert _rel(got, full[k]) < 2e-4, k          # fp32 sums in a different order; conv itself is the same arithmetic
+    # running statistics use the global batch on every rank
+    for k in ("rm", "rv"):
+        np.testing.assert_allclose(res[0][k], res[1][k], rtol=0, atol=0)
+        np.testing.assert_allclose(res[0][k], full[k], rtol=1e-4, atol=1e-6)
+    assert set(res[0]["grads"]) == set(full["grads"])
+    worst = max(_rel(res[0]["grads"][k] + res[1]["grads"][k], full["grads"][k]) for k in full["grads"])
+    tot = _rel(np.concatenate([(res[0]["grads"][k] + res[1]["grads"][k]).ravel() for k in full["grads"]]),
+               np.concatenate([full["grads"][k].ravel() for k in full["grads"]]))
+    assert tot < 5e-4 and worst < 5e-3, (tot, worst)
