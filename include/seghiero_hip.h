@@ -124,18 +124,20 @@ int sh_channel_stats(const float* y, int ldy, int64_t M, int C, float* partials,
 /* out = [relu]( y*scale + shift [+ residual] ).  Replaces BN-apply + ReLU (+ the Bottleneck residual add). */
 int sh_bn_act(const float* y, int ldy, const float* scale, const float* shift, const float* residual,
               int ldr, float* out, int ldo, int64_t M, int C, int relu, void* stream);
-/* Backward of the above.  g = dout * (out > 0 if relu).  reduce: partials [n][2][C] of (sum g, sum g*xhat);
+/* Backward of the above.  g = dout * mask.  relu = 0: no mask; 1: mask = out > 0 (needed when a residual was added);
+ * 2: mask = y*scale+shift > 0, the forward's own arithmetic recomputed from y (no residual) -- `out` is not read, which
+ * saves one activation-sized HBM read in each of the two passes.  reduce: partials [n][2][C] of (sum g, sum g*xhat);
  * finalize: dgamma, dbeta; apply: dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)), optionally dres = g. */
 int sh_bn_bwd_reduce(const float* dout, int lddo, const float* out, int ldo, const float* y, int ldy,
-                     const float* mean, const float* invstd, float* partials, int64_t M, int C,
-                     int relu, void* stream);
+                     const float* mean, const float* invstd, const float* scale, const float* shift,
+                     float* partials, int64_t M, int C, int relu, void* stream);
 int sh_bn_bwd_finalize(const float* partials, int n_partials, int C, const float* gamma,
                        const float* invstd, double count, float* dgamma, float* dbeta, float* c1,
                        float* c2, void* stream);
 int sh_bn_bwd_apply(const float* dout, int lddo, const float* out, int ldo, const float* y, int ldy,
-                    const float* mean, const float* invstd, const float* gamma, const float* c1,
-                    const float* c2, float* dy, int lddy, float* dres, int lddres, int64_t M, int C,
-                    int relu, void* stream);
+                    const float* mean, const float* invstd, const float* scale, const float* shift,
+                    const float* gamma, const float* c1, const float* c2, float* dy, int lddy, float* dres,
+                    int lddres, int64_t M, int C, int relu, void* stream);
 
 /* pooling / resampling -------------------------------------------------------------------- */
 /* nn.MaxPool2d(3, 2, 1) (models/backbone/resnet.py:68) and its backward (first-max tie rule). */

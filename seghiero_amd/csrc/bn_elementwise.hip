@@ -161,6 +161,7 @@ __global__ __launch_bounds__(256) void channel_partials_kernel(const float* __re
                                                                const float* __restrict__ dout, long long lddo,
                                                                const float* __restrict__ out, long long ldo,
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                                float* __restrict__ partials, long long M, int C, int relu) {
     __shared__ float red[2][4][64];
     const int t = threadIdx.x, cl = t & 63, g = t >> 6;
@@ -169,16 +170,18 @@ __global__ __launch_bounds__(256) void channel_partials_kernel(const float* __re
     const long long rend = rbeg + STAT_ROWS < M ? rbeg + STAT_ROWS : M;
     float s = 0.f, q = 0.f;
     if (c < C) {
-        float mu = 0.f, is = 0.f;
-        if (KIND == 1) { mu = mean[c]; is = invstd[c]; }
+        float mu = 0.f, is = 0.f, sc = 0.f, sh = 0.f;
+        if (KIND == 1) { mu = mean[c]; is = invstd[c]; if (relu == 2) { sc = scale[c]; sh = shift[c]; } }
         for (long long r = rbeg + g; r < rend; r += 4) {
             if (KIND == 0) {
                 const float v = y[r * ldy + c];
                 s += v; q += v * v;
             } else {
                 float gv = dout[r * lddo + c];
-                if (relu && !(out[r * ldo + c] > 0.f)) gv = 0.f;
-                const float xh = (y[r * ldy + c] - mu) * is;
+                const float yv = y[r * ldy + c];
+                if (relu == 1 && !(out[r * ldo + c] > 0.f)) gv = 0.f;
+                if (relu == 2 && !(yv * sc + sh > 0.f)) gv = 0.f;       // the forward's own arithmetic (bn_act_kernel)
+                const float xh = (yv - mu) * is;
                 s += gv; q += gv * xh;
             }
         }
@@ -230,7 +233,7 @@ extern "C" int sh_stats_tile_rows(void) { return STAT_ROWS; }
 extern "C" int sh_channel_stats(const float* y, int ldy, int64_t M, int C, float* partials, void* stream) {
     if (!y || !partials || M <= 0 || C <= 0 || ldy < C) return SH_EINVAL;
     dim3 grid((unsigned)sh_cdiv(M, STAT_ROWS), (unsigned)sh_cdiv(C, 64));
-    channel_partials_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(y, ldy, nullptr, 0, nullptr, 0, nullptr, nullptr, partials, M, C, 0);
+    channel_partials_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(y, ldy, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, partials, M, C, 0);
     return sh_launch_status();
 }
 // float4 variant of the BN-backward partials: block = 256 rows x 64 channels, thread = (channel quad, row lane),
@@ -239,6 +242,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partials_v4_kernel(const float* __
                                                                  const float* __restrict__ dout, long long lddo,
                                                                  const float* __restrict__ out, long long ldo,
                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                  float* __restrict__ partials, long long M, int C, int relu) {
     __shared__ float red[2][16][64];
     const int t = threadIdx.x, cq = t & 15, rl = t >> 4;
@@ -247,14 +251,20 @@ __global__ __launch_bounds__(256) void bn_bwd_partials_v4_kernel(const float* __
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
     if (c < C) {
         const f32x4 mu = ld4(mean + c), is = ld4(invstd + c);
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
+        if (relu == 2) { sc = ld4(scale + c); sh = ld4(shift + c); }
 #pragma unroll 4
         for (int k = 0; k < STAT_ROWS / 16; ++k) {
             const long long r = rbeg + rl + 16 * k;
             if (r < M) {
                 f32x4 g = ld4(dout + r * lddo + c);
                 const f32x4 yv = ld4(y + r * ldy + c);
-                if (relu) {
+                if (relu == 1) {
                     const f32x4 o = ld4(out + r * ldo + c);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
+                } else if (relu == 2) {                 // no residual: the mask is the sign of the forward's y*scale+shift
+                    const f32x4 o = yv * sc + sh;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
                 }
@@ -277,15 +287,16 @@ __global__ __launch_bounds__(256) void bn_bwd_partials_v4_kernel(const float* __
     }
 }
 extern "C" int sh_bn_bwd_reduce(const float* dout, int lddo, const float* out, int ldo, const float* y, int ldy,
-                                const float* mean, const float* invstd, float* partials, int64_t M, int C, int relu,
-                                void* stream) {
+                                const float* mean, const float* invstd, const float* scale, const float* shift, float* partials,
+                                int64_t M, int C, int relu, void* stream) {
     if (!dout || !y || !mean || !invstd || !partials || M <= 0 || C <= 0 || lddo < C || ldy < C) return SH_EINVAL;
-    if (relu && (!out || ldo < C)) return SH_EINVAL;
+    if (relu < 0 || relu > 2 || (relu == 1 && (!out || ldo < C)) || (relu == 2 && (!scale || !shift))) return SH_EINVAL;
     dim3 grid((unsigned)sh_cdiv(M, STAT_ROWS), (unsigned)sh_cdiv(C, 64));
-    const bool v4 = (C & 3) == 0 && ((lddo | ldy | (relu ? ldo : 0)) & 3) == 0 && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
-                    (!relu || ((uintptr_t)out & 15) == 0) && ((uintptr_t)mean & 15) == 0 && ((uintptr_t)invstd & 15) == 0;
-    if (v4) bn_bwd_partials_v4_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(y, ldy, dout, lddo, out, ldo, mean, invstd, partials, M, C, relu);
-    else channel_partials_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(y, ldy, dout, lddo, out, ldo, mean, invstd, partials, M, C, relu);
+    const bool v4 = (C & 3) == 0 && ((lddo | ldy | (relu == 1 ? ldo : 0)) & 3) == 0 && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
+                    (relu != 1 || ((uintptr_t)out & 15) == 0) && ((uintptr_t)mean & 15) == 0 && ((uintptr_t)invstd & 15) == 0 &&
+                    (relu != 2 || ((((uintptr_t)scale | (uintptr_t)shift) & 15) == 0));
+    if (v4) bn_bwd_partials_v4_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(y, ldy, dout, lddo, out, ldo, mean, invstd, scale, shift, partials, M, C, relu);
+    else channel_partials_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(y, ldy, dout, lddo, out, ldo, mean, invstd, scale, shift, partials, M, C, relu);
     return sh_launch_status();
 }
 
@@ -357,6 +368,7 @@ template <int V>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, long long lddo, const float* __restrict__ out,
                                                            long long ldo, const float* __restrict__ y, long long ldy,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ gamma, const float* __restrict__ c1,
                                                            const float* __restrict__ c2, float* __restrict__ dy, long long lddy,
                                                            float* __restrict__ dres, long long lddres, long long M, int C, int relu) {
@@ -369,13 +381,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const int c = (e - r * cv) * V;
         if (V == 4) {
             f32x4 g = ld4(dout + m * lddo + c);
-            if (relu) {
+            const f32x4 yv = ld4(y + m * ldy + c);
+            if (relu == 1) {
                 const f32x4 o = ld4(out + m * ldo + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (!(o[j] > 0.f)) g[j] = 0.f;
+            } else if (relu == 2) {
+                const f32x4 o = yv * ld4(scale + c) + ld4(shift + c);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) if (!(o[j] > 0.f)) g[j] = 0.f;
             }
             const f32x4 is = ld4(invstd + c);
-            const f32x4 xh = (ld4(y + m * ldy + c) - ld4(mean + c)) * is;
+            const f32x4 xh = (yv - ld4(mean + c)) * is;
             f32x4 ga = {1.f, 1.f, 1.f, 1.f};
             if (gamma) ga = ld4(gamma + c);
             const f32x4 r = ga * is * (g - ld4(c1 + c) - xh * ld4(c2 + c));
@@ -383,24 +400,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             if (dres) st4(dres + m * lddres + c, g);
         } else {
             float g = dout[m * lddo + c];
-            if (relu && !(out[m * ldo + c] > 0.f)) g = 0.f;
+            const float yv = y[m * ldy + c];
+            if (relu == 1 && !(out[m * ldo + c] > 0.f)) g = 0.f;
+            if (relu == 2 && !(yv * scale[c] + shift[c] > 0.f)) g = 0.f;
             const float is = invstd[c];
-            const float xh = (y[m * ldy + c] - mean[c]) * is;
+            const float xh = (yv - mean[c]) * is;
             dy[m * lddy + c] = (gamma ? gamma[c] : 1.f) * is * (g - c1[c] - xh * c2[c]);
             if (dres) dres[m * lddres + c] = g;
         }
     }
 }
 extern "C" int sh_bn_bwd_apply(const float* dout, int lddo, const float* out, int ldo, const float* y, int ldy,
-                               const float* mean, const float* invstd, const float* gamma, const float* c1, const float* c2,
-                               float* dy, int lddy, float* dres, int lddres, int64_t M, int C, int relu, void* stream) {
+                               const float* mean, const float* invstd, const float* scale, const float* shift, const float* gamma,
+                               const float* c1, const float* c2, float* dy, int lddy, float* dres, int lddres, int64_t M, int C, int relu,
+                               void* stream) {
     if (!dout || !y || !mean || !invstd || !c1 || !c2 || !dy || M <= 0 || C <= 0 || lddo < C || ldy < C || lddy < C) return SH_EINVAL;
-    if (relu && (!out || ldo < C)) return SH_EINVAL;
+    if (relu < 0 || relu > 2 || (relu == 1 && (!out || ldo < C)) || (relu == 2 && (!scale || !shift))) return SH_EINVAL;
     if (dres && lddres < C) return SH_EINVAL;
-    const bool v4 = vec4_ok(C, lddo, ldy, lddy, relu ? ldo : 0, dres ? lddres : 0) && ptr16(dout) && ptr16(y) && ptr16(dy) &&
-                    ptr16(mean) && ptr16(invstd) && ptr16(c1) && ptr16(c2) && (!gamma || ptr16(gamma)) && (!relu || ptr16(out)) && (!dres || ptr16(dres));
-    if (v4) bn_bwd_apply_kernel<4><<<rows_grid(M, C / 4), 256, 0, (hipStream_t)stream>>>(dout, lddo, out, ldo, y, ldy, mean, invstd, gamma, c1, c2, dy, lddy, dres, lddres, M, C, relu);
-    else bn_bwd_apply_kernel<1><<<rows_grid(M, C), 256, 0, (hipStream_t)stream>>>(dout, lddo, out, ldo, y, ldy, mean, invstd, gamma, c1, c2, dy, lddy, dres, lddres, M, C, relu);
+    const bool v4 = vec4_ok(C, lddo, ldy, lddy, relu == 1 ? ldo : 0, dres ? lddres : 0) && ptr16(dout) && ptr16(y) && ptr16(dy) &&
+                    ptr16(mean) && ptr16(invstd) && ptr16(c1) && ptr16(c2) && (!gamma || ptr16(gamma)) && (relu != 1 || ptr16(out)) &&
+                    (relu != 2 || (ptr16(scale) && ptr16(shift))) && (!dres || ptr16(dres));
+    if (v4) bn_bwd_apply_kernel<4><<<rows_grid(M, C / 4), 256, 0, (hipStream_t)stream>>>(dout, lddo, out, ldo, y, ldy, mean, invstd, scale, shift, gamma, c1, c2, dy, lddy, dres, lddres, M, C, relu);
+    else bn_bwd_apply_kernel<1><<<rows_grid(M, C), 256, 0, (hipStream_t)stream>>>(dout, lddo, out, ldo, y, ldy, mean, invstd, scale, shift, gamma, c1, c2, dy, lddy, dres, lddres, M, C, relu);
     return sh_launch_status();
 }
 

@@ -86,12 +86,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 :
     constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, BK = 32;
     constexpr int A_PLANE = BM * ROWB, B_PLANE = BN * ROWB;      // bytes
     constexpr int RPP = NT / 8;                                  // rows covered per loader pass (8 lanes x 16 B per row)
-    constexpr int NA = BM / RPP, NB = BN / RPP;
-    static_assert(NA >= 1 && NB >= 1, "tile too small for the thread count");
+    constexpr int NA = (BM + RPP - 1) / RPP, NB = (BN + RPP - 1) / RPP;      // the last pass may be partial (12-wave blocks)
+    static_assert(BM >= RPP && BN >= RPP, "tile too small for the thread count");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int STAGE = 3 * (A_PLANE + B_PLANE);  // bytes per LDS stage
-    unsigned char* As = smem;                       // [3][BM][80]
-    unsigned char* Bs = smem + 3 * A_PLANE;         // [3][BN][80]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WGN, wn = wave % WGN, l31 = lane & 31, h = lane >> 5;
@@ -121,7 +119,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 :
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int m = m0 + r0 + RPP * i;
-        if (m < Mc) {
+        if (m < Mc && (BM % RPP == 0 || r0 + RPP * i < BM)) {
             if constexpr (MODE == FPROP) {
                 const int ow = m % p.Wo, q = m / p.Wo, oh = q % p.Ho, n = q / p.Ho;
                 a_y[i] = oh * p.stride - p.pad; a_x[i] = ow * p.stride - p.pad; a_nb[i] = n * p.H * p.W;
@@ -164,7 +162,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 :
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int j = n0 + r0 + RPP * i;
-        b_ok[i] = j < p.Nn;
+        b_ok[i] = j < p.Nn && (BN % RPP == 0 || r0 + RPP * i < BN);
         b_row[i] = (long long)j * (MODE == FPROP ? p.K : p.Kc);
     }
 
@@ -196,6 +194,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 :
         unsigned char* Bs = As + 3 * A_PLANE;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
+            if (BM % RPP != 0 && r0 + RPP * i >= BM) continue;
             u32x2 q1, q2, q3;
             split4(ra[i], q1, q2, q3);
             const int off = (r0 + RPP * i) * ROWB + kc * 8;
@@ -205,6 +204,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 :
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
+            if (BN % RPP != 0 && r0 + RPP * i >= BN) continue;
             u32x2 q1, q2, q3;
             split4(rb[i], q1, q2, q3);
             const int off = (r0 + RPP * i) * ROWB + kc * 8;
@@ -856,7 +856,11 @@ static int launch_conv_x6(ConvQ& p, hipStream_t st) {
     // big tiles while they still give >= 2 blocks per CU (they halve the L1 traffic per flop), then the 128/64 family
     // (measured: 8 waves of 128x64 per 256x256 block -- half the LDS fragment reads per MFMA -- run at the same speed as
     //  16 waves of 64x64, and its dgrad instantiation spills; the 16-wave form is used for both)
-    if (N > 128 && sh_cdiv(M, 256) * sh_cdiv(N, 256) >= 512) return launch_x6<MODE, 2, 2, 4, 4>(p, st);
+    if (N > 128 && sh_cdiv(M, 256) * sh_cdiv(N, 256) >= 512) {
+        // a 192-wide tile when 256 would pad N by > 10 % more (N = 560, the decoder's concat width: 576 vs 768 columns)
+        if (sh_cdiv(N, 192) * 192 * 10 < sh_cdiv(N, 256) * 256 * 9) return launch_x6<MODE, 2, 2, 4, 3>(p, st);
+        return launch_x6<MODE, 2, 2, 4, 4>(p, st);
+    }
     if (N > 64 && sh_cdiv(M, 256) * sh_cdiv(N, 128) >= 512) return launch_x6<MODE, 2, 2, 4, 2>(p, st);
     int TN = N <= 64 ? 1 : 2, TM = 2;
     if (sh_cdiv(M, 128) * sh_cdiv(N, 64 * TN) < 256) {

@@ -38,7 +38,7 @@ def bump_bn_counters(bns):
 
 # ----------------------------------------------------------------------------- conv + BN (+res) (+ReLU)
 class CBARec:
-    __slots__ = ("x", "y", "out", "coefs", "relu", "geom", "weight")
+    __slots__ = ("x", "y", "out", "coefs", "relu", "geom", "weight", "has_res")
 
 
 def _bn_coefs(bn, partials, count, training, c, device):
@@ -65,6 +65,7 @@ def cba_fwd(x, weight, geom, bn, relu, training, residual=None, out=None):
     ops.bn_act(y, coefs, out, relu, residual)
     rec = CBARec()
     rec.x, rec.y, rec.out, rec.coefs, rec.relu, rec.geom, rec.weight = x, y, out, coefs, relu, geom, weight
+    rec.has_res = residual is not None
     return out, rec
 
 
@@ -72,8 +73,10 @@ def cba_bwd(rec, bn, dout, need_dx=True, addend=None, want_dres=False, scatter_i
     """-> (dx, dweight, dgamma, dbeta, dres).  `addend` is summed into dx by the dgrad epilogue;
     `scatter_into` (1x1 strided convs) accumulates the result into an existing dx instead."""
     s, p, d = rec.geom
-    dy, dgamma, dbeta, dres = ops.bn_backward(dout, rec.out if rec.relu else None, rec.y, rec.coefs, bn.weight,
-                                              rec.relu, want_dres)
+    # ReLU mask: from `out` only where a residual was added; otherwise recomputed from y (one activation read less)
+    mode = 0 if not rec.relu else (1 if rec.has_res else 2)
+    dy, dgamma, dbeta, dres = ops.bn_backward(dout, rec.out if mode == 1 else None, rec.y, rec.coefs, bn.weight,
+                                              mode, want_dres)
     dw = torch.empty_like(rec.weight)
     ops.conv_wgrad(rec.x, dy, dw, s, p, d)
     dx = None
@@ -107,7 +110,7 @@ def dw_fwd(x, weight, dil, bn, training):
 
 def dw_bwd(rec, bn, dout, dx_accumulate_into=None):
     """-> (dx, dweight, dgamma, dbeta); with dx_accumulate_into the input gradient is added into that tensor."""
-    dy, dgamma, dbeta, _ = ops.bn_backward(dout, rec.out, rec.y, rec.coefs, bn.weight, True)
+    dy, dgamma, dbeta, _ = ops.bn_backward(dout, None, rec.y, rec.coefs, bn.weight, 2)
     dw = torch.empty_like(rec.weight)
     ops.dwconv_wgrad(rec.x, dy, dw, rec.dil)
     if dx_accumulate_into is not None:

@@ -317,7 +317,11 @@ def bn_act(y, coefs, out, relu, residual=None):
 
 
 def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None):
-    """-> (dy, dgamma, dbeta, dres).  out may be None when relu is False."""
+    """-> (dy, dgamma, dbeta, dres).  relu: 0 none, 1 mask from `out` (residual blocks), 2 mask recomputed from y and
+    the forward coefficients (out may be None)."""
+    relu = int(relu)
+    if relu == 2:
+        out = None
     n, c, h, w = y.shape
     m = n * h * w
     dev = y.device
@@ -326,8 +330,8 @@ def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None):
     op, ldo = (None, 0) if out is None else pm(out)
     p = LIB.raw("sh_stats_partials_count")(m)
     partials = torch.empty((p, 2, c), device=dev, dtype=torch.float32)
-    _call("sh_bn_bwd_reduce", dop, lddo, op, ldo, yp, ldy, coefs[0].data_ptr(), coefs[1].data_ptr(), partials.data_ptr(),
-          m, c, int(relu), _st())
+    _call("sh_bn_bwd_reduce", dop, lddo, op, ldo, yp, ldy, coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(),
+          coefs[3].data_ptr(), partials.data_ptr(), m, c, relu, _st())
     red = torch.empty((4, c), device=dev, dtype=torch.float32)           # dgamma, dbeta, c1, c2
     if _sync_on():
         local = torch.empty((2 * c,), device=dev, dtype=torch.float64)
@@ -343,9 +347,9 @@ def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None):
     dres = new_act(n, c, h, w, dev) if want_dres else None
     dyp, lddy = pm(dy)
     drp, lddr = (None, 0) if dres is None else pm(dres)
-    _call("sh_bn_bwd_apply", dop, lddo, op, ldo, yp, ldy, coefs[0].data_ptr(), coefs[1].data_ptr(),
-          None if gamma is None else gamma.data_ptr(), red[2].data_ptr(), red[3].data_ptr(), dyp, lddy, drp, lddr,
-          m, c, int(relu), _st())
+    _call("sh_bn_bwd_apply", dop, lddo, op, ldo, yp, ldy, coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(),
+          coefs[3].data_ptr(), None if gamma is None else gamma.data_ptr(), red[2].data_ptr(), red[3].data_ptr(), dyp, lddy,
+          drp, lddr, m, c, relu, _st())
     return dy, red[0], red[1], dres
 
 

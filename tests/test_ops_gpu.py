@@ -47,6 +47,11 @@ CONV_CASES = [
     (2, 40, 40, 64, 160, 3, 1, 1, 1),
     (2, 17, 13, 32, 64, 3, 2, 1, 1),      # stride-2 3x3 on odd sizes (parity-class dgrad)
     (1, 9, 9, 64, 32, 5, 2, 2, 1),        # stride-2 5x5
+    # M large enough (>= 512 blocks) for the 1024-thread 256x256 tiles and the 768-thread 256x192 ones (N = 272: 384 vs 512 columns)
+    (1, 370, 370, 64, 256, 1, 1, 0, 1),
+    (1, 370, 370, 256, 64, 1, 1, 0, 1),
+    (1, 370, 370, 272, 272, 1, 1, 0, 1),
+    (1, 372, 372, 32, 272, 3, 1, 1, 1),
 ]
 
 
@@ -163,6 +168,9 @@ def test_batchnorm_train_fwd_bwd(ops, shape, relu, res):
     close(rvg, rv, 1e-5, 1e-6, "running_var")
     dy, dgamma, dbeta, dres = ops.bn_backward(nhwc(dout), out if relu else None, yg, coefs, gamma.detach().to(DEV), relu, want_dres=res)
     close(dy, y.grad, 1e-4, 2e-5, "bn dy")
+    if relu and not res:      # mode 2: mask recomputed from y and the forward coefficients -- bit-identical to mode 1
+        dy2, dg2, db2, _ = ops.bn_backward(nhwc(dout), None, yg, coefs, gamma.detach().to(DEV), 2)
+        assert torch.equal(dy2, dy) and torch.equal(dg2, dgamma) and torch.equal(db2, dbeta)
     close(dgamma, gamma.grad, 1e-4, 1e-4, "dgamma")
     close(dbeta, beta.grad, 1e-4, 1e-4, "dbeta")
     if res:
