@@ -65,18 +65,19 @@ int sh_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw,
  * v_mfma_f32_32x32x16_bf16 products per term (fp32-class accuracy, 2.7x fewer MFMA cycles than the f32 MFMA; see
  * csrc/conv_bf16x6.hip).  Same arguments, except that dgrad takes the transposed weight copy made by
  * sh_weight_transpose ([KH*KW][Cin][pad4(Cout)], zero padded) and needs lddy >= pad4(Cout) with zeroed padding lanes. */
+/* fprop / dgrad take an optional split-K workspace (sh_conv_x6_workspace bytes; NULL / 0 = never split): shapes whose
+ * 128x128 tiling gives < 1.5 blocks per CU but have a long K (layer3/4 3x3, the ASPP bottleneck, the aux head) run as
+ * S K-slices into fp32 slabs [S][M][N] plus a deterministic reduce that applies bias / addend / the BN statistics. */
+int64_t sh_conv_x6_workspace(int which /* 0 fprop, 1 dgrad */, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                             int stride, int pad, int dil, int dgrad_mode);
 int sh_conv_fprop_x6(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
                      float* stat_partials, int N, int H, int W, int Cin, int Cout, int KH, int KW,
-                     int stride, int pad, int dil, void* stream);
+                     int stride, int pad, int dil, float* workspace, int64_t workspace_bytes, void* stream);
 int sh_weight_transpose(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream);
-/* Pre-split weights into three bf16 planes (exact 3-way split), rows zero-padded to a multiple of 32:
- * mode 0: [3][Cout][round32(KH*KW*Cin)] for sh_conv_fprop_x6; mode 1: [3][KH*KW*Cin][round32(pad4(Cout))] for
- * sh_conv_dgrad_x6.  Buffer size: sh_weight_split_bytes. */
-int64_t sh_weight_split_bytes(int Cout, int KH, int KW, int Cin, int mode);
-int sh_weight_split(const float* w, void* planes, int Cout, int KH, int KW, int Cin, int mode, void* stream);
 int sh_conv_dgrad_x6(const float* dy, int lddy, const float* wt, const float* addend, int ldadd,
                      float* dx, int lddx, int N, int H, int W, int Cin, int Cout, int KH, int KW,
-                     int stride, int pad, int dil, int mode, void* stream);
+                     int stride, int pad, int dil, int mode, float* workspace, int64_t workspace_bytes,
+                     void* stream);
 int64_t sh_conv_wgrad_x6_workspace(int N, int H, int W, int Cin, int Cout, int KH, int KW,
                                    int stride, int pad, int dil);
 int sh_conv_wgrad_x6(const float* x, int ldx, const float* dy, int lddy, float* dw, float* workspace,

@@ -32,6 +32,9 @@ struct ConvQ {
     int parity;             // dgrad of a stride-2 KxK conv: blockIdx.y = input-pixel parity class (only its taps are non-zero)
     int kchunk;
     int tiles_m, tiles_n, n_partials;
+    int ksplit;             // fprop / dgrad split-K: blockIdx.y = K slice, raw accumulators go to slab[ksplit][M][ldslab]
+    float* slab;
+    long long ldslab;
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -80,7 +83,7 @@ __device__ __forceinline__ f32x16 mma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3
 // (every K tile re-reads (BM+BN)*128 B through the vector L1), not by MFMA or VALU issue -- so the big shapes use
 // 256x256 tiles on 1024 threads (half the L1 lines per flop), with both operands kept fp32 in memory (4 B/element) and
 // split to bf16 in registers on their way to LDS.
-template <int MODE, int TM, int TN, int WGM, int WGN, int DB = 0>
+template <int MODE, int TM, int TN, int WGM, int WGN, int DB = 0, int SK = 0>      // SK: split-K instantiation (K slice = blockIdx.y)
 __global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 : (WGM * WGN) / 4)) void conv_x6_kernel(const ConvQ p) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, BK = 32;
@@ -111,6 +114,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 :
         }
     }
     const int nkt = (Kt + BK - 1) / BK;
+    int kt_begin = 0, kt_end = nkt;
+    if constexpr (SK) {                                              // never combined with the parity classes (both use blockIdx.y)
+        const int per = (nkt + p.ksplit - 1) / p.ksplit;
+        kt_begin = min(nkt, (int)blockIdx.y * per); kt_end = min(nkt, kt_begin + per);
+    }
     const bool single_tap = p.KH * p.KW == 1;
     const bool tap_uniform = single_tap || (p.Kc & 31) == 0;     // a K tile never straddles taps => tap math is scalar
 
@@ -292,18 +300,36 @@ __global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 :
             __syncthreads();
         }
     } else {
-        load_tile(0);
-        store_tile();
+        if (!SK || kt_begin < kt_end) {
+            load_tile(kt_begin);
+            store_tile();
+        }
         __syncthreads();
-        for (int kt = 0; kt < nkt; ++kt) {
-            if (kt + 1 < nkt) load_tile(kt + 1);
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            if (kt + 1 < kt_end) load_tile(kt + 1);
             compute(0);
             __syncthreads();                      // every wave is done reading the LDS planes
-            if (kt + 1 < nkt) {
+            if (kt + 1 < kt_end) {
                 store_tile();
                 __syncthreads();
             }
         }
+    }
+
+    if constexpr (SK) {          // split-K: raw partial sums; bias / addend / BN statistics are applied by splitk_reduce_kernel
+        float* slab = p.slab + (long long)blockIdx.y * p.M * p.ldslab;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * 32 * TN + 32 * j + l31;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 32 * TM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (m < p.M && n < p.Nn) slab[(long long)m * p.ldslab + n] = acc[i][j][r];
+                }
+        }
+        return;
     }
 
     // ------------------------------------------------------------------ epilogue (same as conv_gemm.hip)
@@ -763,44 +789,6 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __re
         wt[i] = co < Cout ? w[((long long)co * T + tap) * Cin + ci] : 0.f;
     }
 }
-// Pre-split weights into three bf16 planes, K-contiguous rows of length Kp (multiple of 32, zero padded):
-//   mode 0 (fprop): planes[pl][co][Kp]            from W[co][K]           (rows = Cout, K = T*Cin)
-//   mode 1 (dgrad): planes[pl][tap*Cin + ci][Kp]  from W[co][tap][ci]     (rows = T*Cin, per-tap K = Cout)
-__global__ __launch_bounds__(256) void weight_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes, int Cout, int T,
-                                                          int Cin, int Kp, int mode, long long rows) {
-    const long long total = rows * Kp, plane = total;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int k = (int)(i % Kp);
-        const long long row = i / Kp;
-        float v = 0.f;
-        if (mode == 0) { if (k < T * Cin) v = w[row * (long long)(T * Cin) + k]; }
-        else { const int ci = (int)(row % Cin), tap = (int)(row / Cin); if (k < Cout) v = w[((long long)k * T + tap) * Cin + ci]; }
-        const unsigned u = __float_as_uint(v);
-        const float r1 = v - __uint_as_float(u & 0xffff0000u);
-        const unsigned u2 = __float_as_uint(r1);
-        const float r2 = r1 - __uint_as_float(u2 & 0xffff0000u);
-        planes[i] = (unsigned short)(u >> 16);
-        planes[plane + i] = (unsigned short)(u2 >> 16);
-        planes[2 * plane + i] = (unsigned short)(__float_as_uint(r2) >> 16);
-    }
-}
-static inline int round32(int v) { return (v + 31) & ~31; }
-// bytes of the plane buffer for sh_weight_split
-extern "C" int64_t sh_weight_split_bytes(int Cout, int KH, int KW, int Cin, int mode) {
-    if (Cout <= 0 || KH <= 0 || KW <= 0 || Cin <= 0) return SH_EINVAL;
-    const long long rows = mode == 0 ? Cout : (long long)KH * KW * Cin;
-    const int Kp = mode == 0 ? round32(KH * KW * Cin) : round32((Cout + 3) & ~3);
-    return 3 * rows * Kp * 2;
-}
-extern "C" int sh_weight_split(const float* w, void* planes, int Cout, int KH, int KW, int Cin, int mode, void* stream) {
-    if (!w || !planes || Cout <= 0 || KH <= 0 || KW <= 0 || Cin <= 0 || (mode != 0 && mode != 1)) return SH_EINVAL;
-    const long long rows = mode == 0 ? Cout : (long long)KH * KW * Cin;
-    const int Kp = mode == 0 ? round32(KH * KW * Cin) : round32((Cout + 3) & ~3);
-    long long g = sh_cdiv(rows * Kp, 256);
-    if (g > 4096) g = 4096;
-    weight_split_kernel<<<(unsigned)g, 256, 0, (hipStream_t)stream>>>(w, (unsigned short*)planes, Cout, KH * KW, Cin, Kp, mode, rows);
-    return sh_launch_status();
-}
 extern "C" int sh_weight_transpose(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream) {
     if (!w || !wt || Cout <= 0 || KH <= 0 || KW <= 0 || Cin <= 0) return SH_EINVAL;
     const int CoutP = (Cout + 3) & ~3;
@@ -810,20 +798,91 @@ extern "C" int sh_weight_transpose(const float* w, float* wt, int Cout, int KH, 
     return sh_launch_status();
 }
 
+// Split-K reduce for fprop / dgrad: out[m][n] = sum_s slab[s][m][n] (+ bias[n] | + addend[m][n]); for fprop also the BN
+// statistics of the conv epilogue (centred (sum, M2) per 64 rows).  Block = 64 rows x 64 columns, thread = 4 rows x 4 columns.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, long long ldslab, int S, long long M, int Nn,
+                                                            const float* __restrict__ bias, const float* __restrict__ addend, long long ldadd,
+                                                            float* __restrict__ out, long long ldc, float* __restrict__ partials) {
+    __shared__ float red[16][64];
+    __shared__ float colmean[64];
+    const int t = threadIdx.x, cq = t & 15, rl = t >> 4;
+    const int n = blockIdx.y * 64 + cq * 4;
+    const long long row0 = (long long)blockIdx.x * 64;
+    const int npr = (int)(M - row0 < 64 ? M - row0 : 64);
+    f32x4 v[4];
+    const bool nok = n < Nn;                 // Nn % 4 == 0 on this path
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long m = row0 + rl + 16 * k;
+        v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (nok && m < M) {
+            for (int s2 = 0; s2 < S; ++s2) v[k] += ld4(slab + ((long long)s2 * M + m) * ldslab + n);
+            f32x4 o = v[k];
+            if (bias) o += ld4(bias + n);
+            if (addend) o += ld4(addend + m * ldadd + n);
+            st4(out + m * ldc + n, o);
+        }
+    }
+    if (partials == nullptr) return;         // block-uniform
+    f32x4 ssum = (v[0] + v[1]) + (v[2] + v[3]);           // rows >= M contribute exact zeros
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[rl][cq * 4 + j] = ssum[j];
+    __syncthreads();
+    if (t < 64) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += red[k][t];
+        colmean[t] = a / (float)npr;
+        if (blockIdx.y * 64 + t < Nn) partials[((long long)blockIdx.x * 2 + 0) * Nn + blockIdx.y * 64 + t] = a;
+    }
+    __syncthreads();
+    f32x4 q = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (row0 + rl + 16 * k < M) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[k][j] - colmean[cq * 4 + j]; q[j] += d * d; }
+        }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[rl][cq * 4 + j] = q[j];
+    __syncthreads();
+    if (t < 64 && blockIdx.y * 64 + t < Nn) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += red[k][t];
+        partials[((long long)blockIdx.x * 2 + 1) * Nn + blockIdx.y * 64 + t] = a;
+    }
+}
+// K slices for an under-filled grid: the mid-network shapes (M*N small, K long) give < 2 blocks per CU with 128x128 tiles.
+static int splitk_plan(long long M, long long N, long long K, int parity, int scatter) {
+    if (parity || scatter || (N & 3)) return 1;
+    const long long tiles = sh_cdiv(M, 128) * sh_cdiv(N, 128), nkt = sh_cdiv(K, 32);
+    if (tiles >= 384 || nkt < 32) return 1;
+    long long S = sh_cdiv(512, tiles);
+    if (S > nkt / 16) S = nkt / 16;          // >= 16 K tiles per slice
+    if (S > 8) S = 8;
+    return S < 2 ? 1 : (int)S;
+}
 // ---------------------------------------------------------------------------------------- host side
-template <int MODE, int TM, int TN, int WGM, int WGN, int DB = 0>
+template <int MODE, int TM, int TN, int WGM, int WGN, int DB = 0, int SK = 0>
 static int launch_x6(ConvQ& p, hipStream_t st) {
     constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
     constexpr size_t lds = (DB ? 2 : 1) * 3 * (size_t)(BM + BN) * ROWB;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6_kernel<MODE, TM, TN, WGM, WGN, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6_kernel<MODE, TM, TN, WGM, WGN, DB, SK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     p.tiles_m = (int)sh_cdiv(p.M, BM);
     p.tiles_n = (int)sh_cdiv(p.Nn, BN);
-    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), p.parity ? 4u : 1u);
-    conv_x6_kernel<MODE, TM, TN, WGM, WGN, DB><<<grid, 64 * WGM * WGN, lds, st>>>(p);
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), p.parity ? 4u : (SK ? (unsigned)p.ksplit : 1u));
+    conv_x6_kernel<MODE, TM, TN, WGM, WGN, DB, SK><<<grid, 64 * WGM * WGN, lds, st>>>(p);
+    if (SK) {
+        dim3 rg((unsigned)sh_cdiv(p.M, 64), (unsigned)sh_cdiv(p.Nn, 64));
+        splitk_reduce_kernel<<<rg, 256, 0, st>>>(p.slab, p.ldslab, p.ksplit, p.M, p.Nn, MODE == FPROP ? p.extra : nullptr,
+                                                 MODE == DGRAD ? p.extra : nullptr, p.ldadd, p.c, p.ldc, MODE == FPROP ? p.partials : nullptr);
+    }
     return sh_launch_status();
 }
 static int x6_variant() { static int v = -1; if (v < 0) { const char* e = getenv("SEGHIERO_X6_VARIANT"); v = e ? atoi(e) : 0; } return v; }
@@ -843,6 +902,7 @@ static int launch_gemm_x6(ConvQ& p, hipStream_t st) {
 template <int MODE>
 static int launch_conv_x6(ConvQ& p, hipStream_t st) {
     const long long M = p.M, N = p.Nn;
+    if (p.ksplit > 1) return launch_x6<MODE, 2, 2, 2, 2, 0, 1>(p, st);
     // pointwise, stride 1 (a plain NT GEMM) with a long K: software-pipelined kernel (1 block per CU).  Measured
     // (tools/bench_conv.py): it wins for K >= 1024 (1024->256 @32^2: 56 vs 76 us) and loses for short K, where its
     // un-overlapped prologue / epilogue dominate (64->256 @128^2: 221 vs 136 us), so short-K shapes keep the 2-blocks/CU form.
@@ -859,13 +919,15 @@ static int launch_conv_x6(ConvQ& p, hipStream_t st) {
     if (N > 128 && sh_cdiv(M, 256) * sh_cdiv(N, 256) >= 512) {
         // a 192-wide tile when 256 would pad N by > 10 % more (N = 560, the decoder's concat width: 576 vs 768 columns)
         if (sh_cdiv(N, 192) * 192 * 10 < sh_cdiv(N, 256) * 256 * 9) return launch_x6<MODE, 2, 2, 4, 3>(p, st);
+        // (measured: 12 waves of 192x256 instead: dgrad +8 % on 512->512 @128^2, fprop equal or worse -- not used)
         return launch_x6<MODE, 2, 2, 4, 4>(p, st);
     }
     if (N > 64 && sh_cdiv(M, 256) * sh_cdiv(N, 128) >= 512) return launch_x6<MODE, 2, 2, 4, 2>(p, st);
+    // >= 2 blocks per CU where the shape allows it (measured: layer3/4 shapes gain 10-20 % over 1 block per CU)
     int TN = N <= 64 ? 1 : 2, TM = 2;
-    if (sh_cdiv(M, 128) * sh_cdiv(N, 64 * TN) < 256) {
+    if (sh_cdiv(M, 128) * sh_cdiv(N, 64 * TN) < 512) {
         TM = 1;
-        if (TN == 2 && sh_cdiv(M, 64) * sh_cdiv(N, 128) < 256) TN = 1;
+        if (TN == 2 && sh_cdiv(M, 64) * sh_cdiv(N, 128) < 512) TN = 1;
     }
     if (M <= 64) TM = 1;
     if (TM == 2 && TN == 2) return launch_x6<MODE, 2, 2, 2, 2>(p, st);
@@ -885,19 +947,41 @@ static bool geom(ConvQ& p, int N, int H, int W, int Cin, int Cout, int KH, int K
     return true;
 }
 
+// bytes of split-K workspace sh_conv_fprop_x6 (which = 0) / sh_conv_dgrad_x6 (which = 1, with its `mode`) can use; 0 = no split
+extern "C" int64_t sh_conv_x6_workspace(int which, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, int mode) {
+    ConvQ p{};
+    if (!geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil)) return -1;
+    long long M, Nn, K;
+    int parity = 0;
+    if (which == 0) { M = (long long)N * p.Ho * p.Wo; Nn = Cout; K = (long long)KH * KW * Cin; }
+    else {
+        if (mode != 0) return 0;
+        M = (long long)N * H * W; Nn = Cin; K = (long long)KH * KW * ((Cout + 3) & ~3);
+        parity = stride == 2 && dil == 1 && KH * KW > 1;
+    }
+    const int S = splitk_plan(M, Nn, K, parity, 0);
+    return S > 1 ? (int64_t)S * M * Nn * 4 : 0;
+}
+static void use_splitk(ConvQ& p, float* workspace, int64_t workspace_bytes) {
+    const int S = splitk_plan(p.M, p.Nn, p.K, p.parity, p.scatter);
+    if (S > 1 && workspace && workspace_bytes >= (int64_t)S * p.M * p.Nn * 4) { p.ksplit = S; p.slab = workspace; p.ldslab = p.Nn; }
+}
 extern "C" int sh_conv_fprop_x6(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, float* stat_partials,
-                                int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, void* stream) {
+                                int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil,
+                                float* workspace, int64_t workspace_bytes, void* stream) {
     ConvQ p{};
     if (!x || !w || !y || !geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil)) return SH_EINVAL;
     if (ldx < Cin || ldy < Cout || (ldx & 3)) return SH_EINVAL;
     p.a = x; p.b = w; p.c = y; p.extra = bias; p.partials = stat_partials; p.lda = ldx; p.ldc = ldy;
     p.M = N * p.Ho * p.Wo; p.Nn = Cout; p.K = KH * KW * Cin; p.Kc = Cin;
     p.n_partials = (int)sh_cdiv(p.M, 64);
+    if ((ldy & 3) == 0 && ((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0)) use_splitk(p, workspace, workspace_bytes);
     return launch_conv_x6<FPROP>(p, (hipStream_t)stream);
 }
 // wt = sh_weight_transpose(w): fp32 [KH*KW][Cin][pad4(Cout)]
 extern "C" int sh_conv_dgrad_x6(const float* dy, int lddy, const float* wt, const float* addend, int ldadd, float* dx, int lddx,
-                                int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, int mode, void* stream) {
+                                int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, int mode,
+                                float* workspace, int64_t workspace_bytes, void* stream) {
     ConvQ p{};
     if (!dy || !wt || !dx || !geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil)) return SH_EINVAL;
     const int CoutP = (Cout + 3) & ~3;
@@ -917,6 +1001,8 @@ extern "C" int sh_conv_dgrad_x6(const float* dy, int lddy, const float* wt, cons
             p.M = N * ((H + 1) / 2) * ((W + 1) / 2);
         }
     } else return SH_EINVAL;
+    if ((lddx & 3) == 0 && ((uintptr_t)dx & 15) == 0 && (!addend || ((ldadd & 3) == 0 && ((uintptr_t)addend & 15) == 0)))
+        use_splitk(p, workspace, workspace_bytes);
     return launch_conv_x6<DGRAD>(p, (hipStream_t)stream);
 }
 

@@ -152,19 +152,27 @@ def conv_fprop(x, weight, bias, y, partials, stride, pad, dil):
     m = n * ho * wo
     x6 = CONV_IMPL == "x6"
     wptr = w_ohwi(weight).data_ptr()
-    _call("sh_conv_fprop_x6" if x6 else "sh_conv_fprop", xp, ldx, wptr,
-          None if bias is None else bias.data_ptr(), yp, ldy,
-          None if partials is None else partials.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, _st(),
-          cost=(2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin + m * o + o * cin * kh * kw)))
+    cost = (2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin + m * o + o * cin * kh * kw))
+    args = (xp, ldx, wptr, None if bias is None else bias.data_ptr(), yp, ldy,
+            None if partials is None else partials.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil)
+    if x6:
+        ws, nb = _splitk_ws(0, n, h, w, cin, o, kh, kw, stride, pad, dil, 0, x.device)
+        _call("sh_conv_fprop_x6", *args, ws, nb, _st(), cost=cost)
+    else:
+        _call("sh_conv_fprop", *args, _st(), cost=cost)
 
 
-def weight_split(weight, mode):
-    """Exact 3-way bf16 split of an [O,I,KH,KW] (OHWI memory) weight into planes for the x6 fprop (mode 0) / dgrad (1)."""
-    o, i, kh, kw = weight.shape
-    nbytes = LIB.raw("sh_weight_split_bytes")(o, kh, kw, i, mode)
-    planes = torch.empty((nbytes,), device=weight.device, dtype=torch.uint8)
-    _call("sh_weight_split", w_ohwi(weight).data_ptr(), planes.data_ptr(), o, kh, kw, i, mode, _st())
-    return planes
+SPLIT_K = os.environ.get("SEGHIERO_SPLITK", "1") != "0"      # debugging knob: 0 = never hand the conv kernels a split-K workspace
+
+
+def _splitk_ws(which, n, h, w, cin, o, kh, kw, stride, pad, dil, mode, device):
+    """(pointer, bytes) of the split-K slab workspace the x6 fprop / dgrad may use for this shape; (None, 0) = no split."""
+    if not SPLIT_K:
+        return None, 0
+    need = LIB.raw("sh_conv_x6_workspace")(which, n, h, w, cin, o, kh, kw, stride, pad, dil, mode)
+    if need <= 0:
+        return None, 0
+    return workspace(need, device, "splitk").data_ptr(), need
 
 
 def weight_transpose(weight):
@@ -185,9 +193,13 @@ def conv_dgrad(dy, weight, dx, stride, pad, dil, addend=None, mode=0):
     m = n * ho * wo
     x6 = CONV_IMPL == "x6" and lddy >= pad4(o)
     wptr = weight_transpose(weight).data_ptr() if x6 else w_ohwi(weight).data_ptr()
-    _call("sh_conv_dgrad_x6" if x6 else "sh_conv_dgrad", dyp, lddy, wptr, ap, lda, dxp, lddx, n, h, w, cin, o, kh, kw,
-          stride, pad, dil, mode, _st(),
-          cost=(2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin * (2 if addend is not None or mode else 1) + m * o + o * cin * kh * kw)))
+    cost = (2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin * (2 if addend is not None or mode else 1) + m * o + o * cin * kh * kw))
+    args = (dyp, lddy, wptr, ap, lda, dxp, lddx, n, h, w, cin, o, kh, kw, stride, pad, dil, mode)
+    if x6:
+        ws, nb = _splitk_ws(1, n, h, w, cin, o, kh, kw, stride, pad, dil, mode, dx.device)
+        _call("sh_conv_dgrad_x6", *args, ws, nb, _st(), cost=cost)
+    else:
+        _call("sh_conv_dgrad", *args, _st(), cost=cost)
 
 
 _WS = {}

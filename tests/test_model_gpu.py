@@ -75,13 +75,16 @@ def _sync_modules(dst, src):
     dst.load_state_dict({k: v.clone() for k, v in src.state_dict().items()})
 
 
-@pytest.mark.parametrize("depth,size", [(18, 64), (50, 96), (50, 64)])
+@pytest.mark.parametrize("depth,size", [(18, 64), (50, 96), (50, 128)])
 def test_backbone_matches_oracle(sa, depth, size):
     """fp32 HIP trunk vs the oracle.  Tolerance is principled: an fp64 run of the oracle is the ground truth, and the
     HIP result must be no further from it than 4x the oracle's own fp32 rounding error (+1e-6).  For parameter
     gradients the bound must hold for >= 95 % of the tensors and for the concatenated gradient as a whole: with
     only 12-24 samples per BatchNorm channel in layer4 at these tiny inputs, a single ReLU whose pre-activation
-    rounds to the other side of 0 moves one channel's gradient by O(1/12) in EITHER fp32 implementation."""
+    rounds to the other side of 0 moves one channel's gradient by O(1/12) in EITHER fp32 implementation.
+    (A 64x96 input -- 12 samples per layer4 channel -- is past that edge: whether it passes depends on the summation
+    order of layer4's convs, e.g. it flips with the split-K slices on or off (SEGHIERO_SPLITK), so the sizes used here
+    keep >= 24 samples per channel.)"""
     import copy
     from oracle import nets
     from seghiero_amd.backbone import ResNetBackbone

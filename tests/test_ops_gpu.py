@@ -47,6 +47,9 @@ CONV_CASES = [
     (2, 40, 40, 64, 160, 3, 1, 1, 1),
     (2, 17, 13, 32, 64, 3, 2, 1, 1),      # stride-2 3x3 on odd sizes (parity-class dgrad)
     (1, 9, 9, 64, 32, 5, 2, 2, 1),        # stride-2 5x5
+    (2, 12, 12, 256, 64, 3, 1, 1, 1),     # long K, few tiles: split-K fprop (4 slices) + reduce with bias / BN statistics
+    (2, 12, 12, 64, 256, 3, 1, 1, 1),     # ... and split-K dgrad (+ addend), M = 288 not a multiple of 64
+    (2, 2, 3, 512, 512, 3, 1, 1, 1),      # layer4 at a tiny input: M = 12, K = 4608 -> 8 K slices
     # M large enough (>= 512 blocks) for the 1024-thread 256x256 tiles and the 768-thread 256x192 ones (N = 272: 384 vs 512 columns)
     (1, 370, 370, 64, 256, 1, 1, 0, 1),
     (1, 370, 370, 256, 64, 1, 1, 0, 1),
