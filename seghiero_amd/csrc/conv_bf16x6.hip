@@ -1013,9 +1013,22 @@ static WgX6Plan wgrad_plan_x6(int Cout, long long Nn, long long npix) {
     g.wgm = Cout <= 64 ? 1 : 2;
     g.wgn = (Nn >= 256 && Cout <= 128) ? 4 : 2;
     const long long tiles = sh_cdiv(Cout, 64 * g.wgm) * sh_cdiv(Nn, 64 * g.wgn);
-    long long s = sh_cdiv(g.wgm * g.wgn >= 16 ? 512 : 640, tiles), maxs = sh_cdiv(npix, 256);
-    if (s > maxs) s = maxs;
-    if (s < 1) s = 1;
+    // K slices: the grid should be a whole number of "rounds" of 512 resident blocks (2 per CU) -- measured
+    // (tools/wg_target_sweep.sh): 640 blocks cost as much as 1024, e.g. 512->512 @128^2: 1143 us at 640 vs 878 us at 512 --
+    // and each slice writes + re-reads one fp32 copy of dW, which prices many short slices out for the small layers.
+    //   cost(r) = r * (npix / s_r) * t_pixel + s_r * dW_bytes * 2 / HBM,   s_r = floor(512 r / tiles)
+    const long long maxs = sh_cdiv(npix, 256);
+    const double t_pixel = 2.0 * (64 * g.wgm) * (64 * g.wgn) / 0.29e12, dwb = 4.0 * Cout * (double)Nn;
+    const long long slots = g.wgm * g.wgn >= 16 ? 256 : 512;
+    long long s = 1;
+    double best = 1e30;
+    for (int r = 1; r <= 4; ++r) {
+        long long sr = slots * r / tiles;
+        if (sr < 1) sr = 1;
+        if (sr > maxs) sr = maxs;
+        const double cost = (double)sh_cdiv(tiles * sr, slots) * sh_cdiv(npix, sr) * t_pixel + sr * dwb * 2.0 / 4e12;
+        if (cost < best * 0.97) { best = cost; s = sr; }          // more rounds only for a clear (> 3 %) gain
+    }
     const long long chunk = sh_cdiv(sh_cdiv(npix, s), 32) * 32;
     g.kchunk = (int)chunk;
     g.splits = (int)sh_cdiv(npix, chunk);
