@@ -64,7 +64,11 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2& p1, u32x2& p2, u32x
     p3[0] = __builtin_amdgcn_perm(h3[1], h3[0], 0x07060302u); p3[1] = __builtin_amdgcn_perm(h3[3], h3[2], 0x07060302u);
 }
 
-#define ROWB 80            // bytes per LDS row of a K-contiguous plane (64 data + 16 pad)
+// LDS rows of a K-contiguous plane are 64 bytes (32 bf16) with the 16-byte k-chunk XOR-swizzled by (row >> 2) & 3: the 16
+// lanes of every ds_read_b128 lane group ({0-3,12-15,20-27}, ...) then cover all 64 banks once, and the ds_write_b64 of 16
+// consecutive lanes (2 rows) covers the 32 store banks once -- conflict-free without padding (20 % less LDS than 80-byte rows).
+#define ROWB 64
+#define ROWB_G 80          // gemm_x6_kernel keeps padded rows (64 data + 16 pad)
 
 // six-product accumulate of one 32x32 tile over K=16
 __device__ __forceinline__ f32x16 mma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c) {
@@ -83,8 +87,10 @@ __device__ __forceinline__ f32x16 mma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3
 // (every K tile re-reads (BM+BN)*128 B through the vector L1), not by MFMA or VALU issue -- so the big shapes use
 // 256x256 tiles on 1024 threads (half the L1 lines per flop), with both operands kept fp32 in memory (4 B/element) and
 // split to bf16 in registers on their way to LDS.
-template <int MODE, int TM, int TN, int WGM, int WGN, int DB = 0, int SK = 0>      // SK: split-K instantiation (K slice = blockIdx.y)
-__global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 : (WGM * WGN) / 4)) void conv_x6_kernel(const ConvQ p) {
+// PROF: instrumented build for tools/bench_conv.py (SEGHIERO_X6_PROF=1): per-wave s_memtime totals of the main-loop phases
+// OCC: waves per SIMD the register budget is held to (0 = one resident block's worth, at least 2)
+template <int MODE, int TM, int TN, int WGM, int WGN, int OCC = 0, int SK = 0, int PROF = 0>      // SK: split-K instantiation (K slice = blockIdx.y)
+__global__ __launch_bounds__(64 * WGM * WGN, OCC ? OCC : ((WGM * WGN) / 4 < 2 ? 2 : (WGM * WGN) / 4)) void conv_x6_kernel(const ConvQ p) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, BK = 32;
     constexpr int A_PLANE = BM * ROWB, B_PLANE = BN * ROWB;      // bytes
@@ -92,10 +98,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 :
     constexpr int NA = (BM + RPP - 1) / RPP, NB = (BN + RPP - 1) / RPP;      // the last pass may be partial (12-wave blocks)
     static_assert(BM >= RPP && BN >= RPP, "tile too small for the thread count");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int STAGE = 3 * (A_PLANE + B_PLANE);  // bytes per LDS stage
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WGN, wn = wave % WGN, l31 = lane & 31, h = lane >> 5;
+    unsigned long long tk0 = 0;
+    if constexpr (PROF) tk0 = __builtin_amdgcn_s_memtime();
     const unsigned nblk = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
     const unsigned bid = xcd_remap(blockIdx.x, nblk);
     const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
@@ -124,6 +131,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 :
 
     const int kc = t & 7, r0 = t >> 3;
     int a_y[NA], a_x[NA], a_nb[NA];
+    long long b_row[NB];             // B rows: fprop W[co][K] (k linear over taps); dgrad Wt[tap][ci][Kc] (per-tap rows of Kc floats)
+    bool b_ok[NB];
+    int cur_tap = -1;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int m = m0 + r0 + RPP * i;
@@ -138,9 +148,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 :
             }
         } else { a_y[i] = -(1 << 28); a_x[i] = 0; a_nb[i] = 0; }
     }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int j = n0 + r0 + RPP * i;
+        b_ok[i] = j < p.Nn && (BN % RPP == 0 || r0 + RPP * i < BN);
+        b_row[i] = (long long)j * (MODE == FPROP ? p.K : p.Kc);
+    }
     long long a_off[NA];             // element offset of each A row for the current tap (never recomputed for 1x1 convs)
     bool a_ok[NA];
-    int cur_tap = -1;
     auto set_tap = [&](int tap) {
         int kh, kw;
         if (MODE == DGRAD && p.parity) { const int ty = tap / ntw; kh = cy + 2 * ty; kw = cx + 2 * (tap - ty * ntw); }
@@ -164,16 +179,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 :
             }
         }
     };
-    // B rows: fprop W[co][K] (k linear over taps); dgrad Wt[tap][ci][Kc] (per-tap rows of Kc = pad4(Cout) floats)
-    long long b_row[NB];
-    bool b_ok[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int j = n0 + r0 + RPP * i;
-        b_ok[i] = j < p.Nn && (BN % RPP == 0 || r0 + RPP * i < BN);
-        b_row[i] = (long long)j * (MODE == FPROP ? p.K : p.Kc);
-    }
-
     f32x4 ra[NA], rb[NB];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -197,15 +202,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 :
             rb[i] = (kok && b_ok[i]) ? ld4(p.b + off) : zero4;
         }
     };
-    auto store_tile = [&](int sb = 0) {
-        unsigned char* As = smem + sb * STAGE;
+    const int wr_off = ((((kc >> 1) ^ ((t >> 5) & 3))) << 4) + ((kc & 1) << 3);      // swizzled chunk + half of this thread's 8 bytes
+    auto store_tile = [&]() {
+        unsigned char* As = smem;
         unsigned char* Bs = As + 3 * A_PLANE;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if (BM % RPP != 0 && r0 + RPP * i >= BM) continue;
             u32x2 q1, q2, q3;
             split4(ra[i], q1, q2, q3);
-            const int off = (r0 + RPP * i) * ROWB + kc * 8;
+            const int off = (r0 + RPP * i) * ROWB + wr_off;
             *reinterpret_cast<u32x2*>(As + off) = q1;
             *reinterpret_cast<u32x2*>(As + A_PLANE + off) = q2;
             *reinterpret_cast<u32x2*>(As + 2 * A_PLANE + off) = q3;
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 :
             if (BN % RPP != 0 && r0 + RPP * i >= BN) continue;
             u32x2 q1, q2, q3;
             split4(rb[i], q1, q2, q3);
-            const int off = (r0 + RPP * i) * ROWB + kc * 8;
+            const int off = (r0 + RPP * i) * ROWB + wr_off;
             *reinterpret_cast<u32x2*>(Bs + off) = q1;
             *reinterpret_cast<u32x2*>(Bs + B_PLANE + off) = q2;
             *reinterpret_cast<u32x2*>(Bs + 2 * B_PLANE + off) = q3;
@@ -231,8 +237,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 :
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int arow = wm * 32 * TM + l31, brow = wn * 32 * TN + l31;
-    auto compute = [&](int sb) {
-        const unsigned char* As = smem + sb * STAGE;
+    const int rd_off[2] = {((h ^ ((l31 >> 2) & 3)) << 4), (((2 + h) ^ ((l31 >> 2) & 3)) << 4)};   // swizzled k-chunk for s = 0, 1
+    auto compute = [&]() {
+        const unsigned char* As = smem;
         const unsigned char* Bs = As + 3 * A_PLANE;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -241,78 +248,54 @@ __global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 :
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
-                    bfr[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + pl * B_PLANE + (brow + 32 * j) * ROWB + (2 * s + h) * 16));
+                    bfr[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + pl * B_PLANE + (brow + 32 * j) * ROWB + rd_off[s]));
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 bf16x8 af[3];
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
-                    af[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + pl * A_PLANE + (arow + 32 * i) * ROWB + (2 * s + h) * 16));
+                    af[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + pl * A_PLANE + (arow + 32 * i) * ROWB + rd_off[s]));
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = mma6(af, bfr[j], acc[i][j]);
             }
         }
     };
-    if constexpr (DB) {
-        // software-pipelined form (1 block per CU): the fragments of tile kt are read from LDS stage kt&1 into registers
-        // first; then the 48 MFMAs of the tile are interleaved (sched_group_barrier) with the split of tile kt+1 into the
-        // other stage and the global loads of tile kt+2 -- VALU / LDS-write / VMEM work sits in the shadow of the MFMAs of
-        // the same instruction stream; one barrier per tile.
-        load_tile(0);
-        store_tile(0);
-        if (nkt > 1) load_tile(1);
-        __syncthreads();
-        for (int kt = 0; kt < nkt; ++kt) {
-            const int cur = kt & 1;
-            const unsigned char* Ac = smem + cur * STAGE;
-            const unsigned char* Bc = Ac + 3 * A_PLANE;
-            bf16x8 af[2][TM][3], bfr[2][TN][3];
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        af[s2][i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Ac + pl * A_PLANE + (arow + 32 * i) * ROWB + (2 * s2 + h) * 16));
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        bfr[s2][j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bc + pl * B_PLANE + (brow + 32 * j) * ROWB + (2 * s2 + h) * 16));
-            }
-            if (kt + 1 < nkt) {
-                store_tile(cur ^ 1);                 // registers hold tile kt+1
-                if (kt + 2 < nkt) load_tile(kt + 2);
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = mma6(af[s2][i], bfr[s2][j], acc[i][j]);
-#pragma unroll
-            for (int gq = 0; gq < 12 * TM * TN; ++gq) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);      // up to 6 VALU
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // 1 LDS write
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
-            }
-            __syncthreads();
-        }
-    } else {
-        if (!SK || kt_begin < kt_end) {
-            load_tile(kt_begin);
-            store_tile();
-        }
-        __syncthreads();
+    unsigned long long tc = 0, tb1 = 0, tv = 0, ts = 0, tb2 = 0, tloop = 0, tpro = 0;      // PROF only
+    if (!SK || kt_begin < kt_end) {
+        load_tile(kt_begin);
+        store_tile();
+    }
+    __syncthreads();
+    if constexpr (PROF) {
+        const unsigned long long tstart = __builtin_amdgcn_s_memtime();
+        tpro = tstart - tk0;
         for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
             if (kt + 1 < kt_end) load_tile(kt + 1);
-            compute(0);
-            __syncthreads();                      // every wave is done reading the LDS planes
+            compute();
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+            tc += t1 - t0; tb1 += t2 - t1;
             if (kt + 1 < kt_end) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned long long t3 = __builtin_amdgcn_s_memtime();
                 store_tile();
+                const unsigned long long t4 = __builtin_amdgcn_s_memtime();
                 __syncthreads();
+                const unsigned long long t5 = __builtin_amdgcn_s_memtime();
+                tv += t3 - t2; ts += t4 - t3; tb2 += t5 - t4;
             }
+        }
+        tloop = __builtin_amdgcn_s_memtime() - tstart;
+    } else
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        if (kt + 1 < kt_end) load_tile(kt + 1);
+        compute();
+        __syncthreads();                      // every wave is done reading the LDS planes
+        if (kt + 1 < kt_end) {
+            store_tile();
+            __syncthreads();
         }
     }
 
@@ -447,6 +430,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 :
             }
         }
     }
+    if constexpr (PROF) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long tk1 = __builtin_amdgcn_s_memtime();
+        if (lane == 0 && bid < 64) {
+            unsigned long long* d = reinterpret_cast<unsigned long long*>(p.slab) + ((long long)bid * (WGM * WGN) + wave) * 8;
+            d[0] = tc; d[1] = tb1; d[2] = tv; d[3] = ts; d[4] = tb2; d[5] = tloop; d[6] = (unsigned long long)(kt_end - kt_begin); d[7] = tpro;
+            reinterpret_cast<unsigned long long*>(p.slab)[65536 + (long long)bid * (WGM * WGN) + wave] = tk1 - tk0;
+        }
+    }
 }
 
 // ============================================================================================ 1x1 / stride-1 fast path
@@ -460,7 +452,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, DB ? 1 : ((WGM * WGN) / 4 < 2 ? 2 :
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void gemm_x6_kernel(const ConvQ p) {
     constexpr int BM = 128, BN = 128, BK = 32;
-    constexpr int A_PLANE = BM * ROWB, B_PLANE = BN * ROWB, STAGE = 3 * (A_PLANE + B_PLANE);
+    constexpr int A_PLANE = BM * ROWB_G, B_PLANE = BN * ROWB_G, STAGE = 3 * (A_PLANE + B_PLANE);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
@@ -497,7 +489,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_kernel(const ConvQ p) {
         unsigned char* Bs = As + 3 * A_PLANE;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int off = (r0 + 32 * i) * ROWB + kc * 8;
+            const int off = (r0 + 32 * i) * ROWB_G + kc * 8;
             u32x2 q1, q2, q3;
             split4(ra[i], q1, q2, q3);
             *reinterpret_cast<u32x2*>(As + off) = q1;
@@ -527,8 +519,8 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_kernel(const ConvQ p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
-                    af[s2][i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Ac + pl * A_PLANE + (arow + 32 * i) * ROWB + (2 * s2 + h) * 16));
-                    bfr[s2][i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bc + pl * B_PLANE + (brow + 32 * i) * ROWB + (2 * s2 + h) * 16));
+                    af[s2][i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Ac + pl * A_PLANE + (arow + 32 * i) * ROWB_G + (2 * s2 + h) * 16));
+                    bfr[s2][i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bc + pl * B_PLANE + (brow + 32 * i) * ROWB_G + (2 * s2 + h) * 16));
                 }
     };
     auto mfmas = [&]() {
@@ -865,19 +857,19 @@ static int splitk_plan(long long M, long long N, long long K, int parity, int sc
     return S < 2 ? 1 : (int)S;
 }
 // ---------------------------------------------------------------------------------------- host side
-template <int MODE, int TM, int TN, int WGM, int WGN, int DB = 0, int SK = 0>
+template <int MODE, int TM, int TN, int WGM, int WGN, int OCC = 0, int SK = 0, int PROF = 0>
 static int launch_x6(ConvQ& p, hipStream_t st) {
     constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
-    constexpr size_t lds = (DB ? 2 : 1) * 3 * (size_t)(BM + BN) * ROWB;
+    constexpr size_t lds = 3 * (size_t)(BM + BN) * ROWB;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6_kernel<MODE, TM, TN, WGM, WGN, DB, SK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6_kernel<MODE, TM, TN, WGM, WGN, OCC, SK, PROF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     p.tiles_m = (int)sh_cdiv(p.M, BM);
     p.tiles_n = (int)sh_cdiv(p.Nn, BN);
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), p.parity ? 4u : (SK ? (unsigned)p.ksplit : 1u));
-    conv_x6_kernel<MODE, TM, TN, WGM, WGN, DB, SK><<<grid, 64 * WGM * WGN, lds, st>>>(p);
+    conv_x6_kernel<MODE, TM, TN, WGM, WGN, OCC, SK, PROF><<<grid, 64 * WGM * WGN, lds, st>>>(p);
     if (SK) {
         dim3 rg((unsigned)sh_cdiv(p.M, 64), (unsigned)sh_cdiv(p.Nn, 64));
         splitk_reduce_kernel<<<rg, 256, 0, st>>>(p.slab, p.ldslab, p.ksplit, p.M, p.Nn, MODE == FPROP ? p.extra : nullptr,
@@ -888,7 +880,7 @@ static int launch_x6(ConvQ& p, hipStream_t st) {
 static int x6_variant() { static int v = -1; if (v < 0) { const char* e = getenv("SEGHIERO_X6_VARIANT"); v = e ? atoi(e) : 0; } return v; }
 template <int MODE>
 static int launch_gemm_x6(ConvQ& p, hipStream_t st) {
-    constexpr size_t lds = 2 * 3 * (size_t)(128 + 128) * ROWB;
+    constexpr size_t lds = 2 * 3 * (size_t)(128 + 128) * ROWB_G;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -911,8 +903,6 @@ static int launch_conv_x6(ConvQ& p, hipStream_t st) {
         p.ldb = (MODE == FPROP) ? p.K : p.Kc;
         return launch_gemm_x6<MODE>(p, st);
     }
-    if (x6_variant() == 1) return launch_x6<MODE, 2, 2, 2, 2, 1>(p, st);      // experiment: software-pipelined 128x128
-    if (x6_variant() == 2) return launch_x6<MODE, 2, 2, 4, 2, 1>(p, st);      // experiment: software-pipelined 256x128 (512 thr)
     // big tiles while they still give >= 2 blocks per CU (they halve the L1 traffic per flop), then the 128/64 family
     // (measured: 8 waves of 128x64 per 256x256 block -- half the LDS fragment reads per MFMA -- run at the same speed as
     //  16 waves of 64x64, and its dgrad instantiation spills; the 16-wave form is used for both)
@@ -920,6 +910,9 @@ static int launch_conv_x6(ConvQ& p, hipStream_t st) {
         // a 192-wide tile when 256 would pad N by > 10 % more (N = 560, the decoder's concat width: 576 vs 768 columns)
         if (sh_cdiv(N, 192) * 192 * 10 < sh_cdiv(N, 256) * 256 * 9) return launch_x6<MODE, 2, 2, 4, 3>(p, st);
         // (measured: 12 waves of 192x256 instead: dgrad +8 % on 512->512 @128^2, fprop equal or worse -- not used)
+        if (MODE == FPROP && x6_variant() == 7 && p.slab) return launch_x6<FPROP, 2, 2, 4, 4, 0, 0, 1>(p, st);      // instrumented
+        // (measured: two 256x128 blocks per CU at 128 VGPRs are 20 % slower -- spills; three 128x128 blocks per CU: no change;
+        //  a persistent tile loop that requests the next tile's first K tile before the epilogue: slower main loop, more spills)
         return launch_x6<MODE, 2, 2, 4, 4>(p, st);
     }
     if (N > 64 && sh_cdiv(M, 256) * sh_cdiv(N, 128) >= 512) return launch_x6<MODE, 2, 2, 4, 2>(p, st);
@@ -930,6 +923,7 @@ static int launch_conv_x6(ConvQ& p, hipStream_t st) {
         if (TN == 2 && sh_cdiv(M, 64) * sh_cdiv(N, 128) < 512) TN = 1;
     }
     if (M <= 64) TM = 1;
+    if (MODE == FPROP && TM == 2 && TN == 2 && x6_variant() == 7 && p.slab) return launch_x6<FPROP, 2, 2, 2, 2, 0, 0, 1>(p, st);
     if (TM == 2 && TN == 2) return launch_x6<MODE, 2, 2, 2, 2>(p, st);
     if (TM == 2 && TN == 1) return launch_x6<MODE, 2, 1, 2, 2>(p, st);
     if (TM == 1 && TN == 2) return launch_x6<MODE, 1, 2, 2, 2>(p, st);
@@ -963,6 +957,7 @@ extern "C" int64_t sh_conv_x6_workspace(int which, int N, int H, int W, int Cin,
     return S > 1 ? (int64_t)S * M * Nn * 4 : 0;
 }
 static void use_splitk(ConvQ& p, float* workspace, int64_t workspace_bytes) {
+    if (x6_variant() == 7 && workspace && workspace_bytes >= (1 << 20)) { p.slab = workspace; return; }      // phase-timing buffer
     const int S = splitk_plan(p.M, p.Nn, p.K, p.parity, p.scatter);
     if (S > 1 && workspace && workspace_bytes >= (int64_t)S * p.M * p.Nn * 4) { p.ksplit = S; p.slab = workspace; p.ldslab = p.Nn; }
 }

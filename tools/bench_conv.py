@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the implicit-GEMM conv kernels on the layer shapes of the ResNet-50 / 512x512 / B=16 step.
 Times fprop / dgrad / wgrad with HIP events (torch current stream) and prints TFLOP/s (fp32 MFMA peak 157.3)."""
+import os
 import sys
 import torch
 sys.path.insert(0, ".")
@@ -39,6 +40,32 @@ def timeit(fn, iters=10):
     return e0.elapsed_time(e1) / iters
 
 
+def phase_profile(x, wt, y, part, n, h, w, cin, cout, k, s, p):
+    """SEGHIERO_X6_VARIANT=7 SEGHIERO_X6_PROF=1: run the instrumented fprop once and print the per-wave phase cycle totals
+    (s_memtime ticks, averaged over the waves of the first 64 blocks)."""
+    import numpy as np
+    dbg = torch.zeros(1 << 20, dtype=torch.uint8, device=DEV)
+    xp, ldx = ops.pm(x)
+    yp, ldy = ops.pm(y)
+    ops._call("sh_conv_fprop_x6", xp, ldx, ops.w_ohwi(wt).data_ptr(), None, yp, ldy, part.data_ptr(), n, h, w, cin, cout, k, k, s, p, 1,
+              dbg.data_ptr(), dbg.numel(), ops._st())
+    torch.cuda.synchronize()
+    raw = dbg.cpu().numpy().view(np.uint64)
+    total = raw[65536:65536 + 64 * 16].astype(np.float64)
+    total = total[total > 0]
+    d = raw[:65536].reshape(-1, 8)
+    d = d[d[:, 5] > 0].astype(np.float64)
+    if len(d) == 0:
+        print("   (no instrumented instantiation for this shape)")
+        return
+    tot = d[:, 5].mean()
+    names = ["lds-read+mfma", "barrier1", "vmcnt wait", "split+lds-write", "barrier2"]
+    print(f"   waves sampled {len(d)}, k tiles {int(d[0, 6])}, loop cycles/wave {tot:.0f} = {tot / d[0, 6]:.0f} per k tile;  " +
+          "  ".join(f"{nm} {d[:, i].mean() / tot * 100:.1f}%" for i, nm in enumerate(names)))
+    if len(total):
+        print(f"   whole block {total.mean():.0f} cycles: prologue {d[:, 7].mean():.0f}, loop {tot:.0f}, epilogue {total.mean() - tot - d[:, 7].mean():.0f}")
+
+
 def main():
     only = sys.argv[1] if len(sys.argv) > 1 else None
     tot = {"fprop": [0, 0], "dgrad": [0, 0], "wgrad": [0, 0]}
@@ -55,6 +82,8 @@ def main():
         dw = torch.empty_like(wt)
         fl = 2.0 * n * ho * wo * cout * cin * k * k
         tf = timeit(lambda: ops.conv_fprop(x, wt, None, y, part, s, p, 1))
+        if os.environ.get("SEGHIERO_X6_PROF") == "1":
+            phase_profile(x, wt, y, part, n, h, w, cin, cout, k, s, p)
         td = timeit(lambda: ops.conv_dgrad(dy, wt, dx, s, p, 1))
         tw = timeit(lambda: ops.conv_wgrad(x, dy, dw, s, p, 1))
         for key, t in (("fprop", tf), ("dgrad", td), ("wgrad", tw)):
