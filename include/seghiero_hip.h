@@ -38,6 +38,16 @@ int sh_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int Cp
 /* NHWC (Cpad channels per pixel, first C used) -> NCHW. */
 int sh_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, int Cpad, void* stream);
 
+/* On-device input pipeline (dataset/dataloader.py:49-63 after PIL decoding / PIL resizing, which stay
+ * on the host): per-sample horizontal flip (flip[n] != 0; NULL = none), ToTensor (u8/255) and Normalize((v-mean)/std)
+ * from interleaved RGB u8 [N,H,W,3] straight into the stem's NHWC4 fp32 layout (4th channel 0). */
+int sh_ingest_image_u8(const uint8_t* rgb, float* out, const uint8_t* flip, int N, int H, int W,
+                       const float* mean3_host, const float* std3_host, void* stream);
+/* Label maps: F.interpolate(mode="nearest") from [N,Hs,Ws] to [N,H,W] (ATen index rule), then the same flip, to u8.
+ * mask: int64 (is_i64 = 1, as the reference holds them) or uint8. */
+int sh_ingest_mask(const void* mask, int is_i64, uint8_t* out, const uint8_t* flip, int N, int Hs, int Ws, int H,
+                   int W, void* stream);
+
 /* dense convolution as implicit GEMM on fp32 MFMA ----------------------------------------- */
 /* y[n,oh,ow,co] = bias[co] + sum x[n, oh*s-p+kh*d, ow*s-p+kw*d, ci] * w[co,kh,kw,ci]
  * Replaces nn.Conv2d forward: torchvision Bottleneck convs behind models/backbone/resnet.py:65-73,

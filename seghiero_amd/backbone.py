@@ -110,10 +110,13 @@ class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mod, x, *params):
         training = mod.training
-        n, _, hh, ww = x.shape
-        x4 = ops.new_act(n, 4, hh, ww, x.device)                       # NHWC, 3 -> 4 channels (4th = 0)
-        xc = x if x.is_contiguous() else x.contiguous()
-        ops._call("sh_nchw_to_nhwc", xc.data_ptr(), x4.data_ptr(), n, 3, hh, ww, 4, ops._st())
+        n, cin, hh, ww = x.shape
+        if cin == 4:                                                   # already ingested (seghiero_amd.ingest): NHWC4, 4th channel 0
+            x4 = x
+        else:
+            x4 = ops.new_act(n, 4, hh, ww, x.device)                   # NHWC, 3 -> 4 channels (4th = 0)
+            xc = x if x.is_contiguous() else x.contiguous()
+            ops._call("sh_nchw_to_nhwc", xc.data_ptr(), x4.data_ptr(), n, 3, hh, ww, 4, ops._st())
         w = mod.stem_conv.weight                                       # [64,3,7,7] -> OHWI with I padded to 4
         if not w.is_contiguous():
             raise SegHieroHipError("stem_conv.weight must be contiguous")
@@ -209,7 +212,8 @@ class ResNetBackbone(nn.Module):
         return out
 
     def forward(self, x: torch.Tensor):
-        if x.dim() != 4 or x.shape[1] != 3:
-            raise ValueError("expected input of shape [B, 3, H, W]")
+        ingested = x.dim() == 4 and x.shape[1] == 4 and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+        if x.dim() != 4 or (x.shape[1] != 3 and not ingested):
+            raise ValueError("expected input of shape [B, 3, H, W] (or the NHWC4 tensor made by seghiero_amd.ingest)")
         ops._require_gpu(x)
         return _BackboneFn.apply(self, x, *self.parameters())

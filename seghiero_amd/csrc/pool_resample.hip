@@ -274,3 +274,59 @@ extern "C" int sh_l2norm_bwd(const float* dy, const float* y, const float* norm,
     l2norm_bwd_kernel<<<(unsigned)sh_cdiv(M, 4), 256, 0, (hipStream_t)stream>>>(dy, y, norm, dx, M, C);
     return sh_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------- on-device input pipeline
+// dataset/dataloader.py:49-63 after PIL decoding: [hflip] -> ToTensor (u8 / 255) -> Normalize((v - mean) / std), written
+// straight into the stem's NHWC4 layout (4th channel 0); masks: F.interpolate(mode="nearest") [+ hflip] -> u8 labels.
+__global__ __launch_bounds__(256) void ingest_image_kernel(const unsigned char* __restrict__ rgb, float* __restrict__ out,
+                                                           const unsigned char* __restrict__ flip, long long NHW, int HW, int W,
+                                                           float m0, float m1, float m2, float s0, float s1, float s2) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < NHW; i += (long long)gridDim.x * 256) {
+        const long long n = i / HW;
+        const int x = (int)(i % W);
+        long long src = i;
+        if (flip != nullptr && flip[n]) src = i - x + (W - 1 - x);
+        const unsigned char* q = rgb + src * 3;
+        f32x4 v;
+        v[0] = ((float)q[0] / 255.0f - m0) / s0;
+        v[1] = ((float)q[1] / 255.0f - m1) / s1;
+        v[2] = ((float)q[2] / 255.0f - m2) / s2;
+        v[3] = 0.f;
+        st4(out + i * 4, v);
+    }
+}
+extern "C" int sh_ingest_image_u8(const uint8_t* rgb, float* out, const uint8_t* flip, int N, int H, int W, const float* mean3_host,
+                                  const float* std3_host, void* stream) {
+    if (!rgb || !out || !mean3_host || !std3_host || N <= 0 || H <= 0 || W <= 0) return SH_EINVAL;
+    if (std3_host[0] == 0.f || std3_host[1] == 0.f || std3_host[2] == 0.f) return SH_EINVAL;
+    const long long nhw = (long long)N * H * W;
+    long long g = sh_cdiv(nhw, 256);
+    if (g > 16384) g = 16384;
+    ingest_image_kernel<<<(unsigned)g, 256, 0, (hipStream_t)stream>>>(rgb, out, flip, nhw, H * W, W, mean3_host[0], mean3_host[1], mean3_host[2],
+                                                                      std3_host[0], std3_host[1], std3_host[2]);
+    return sh_launch_status();
+}
+template <typename T>
+__global__ __launch_bounds__(256) void ingest_mask_kernel(const T* __restrict__ mask, unsigned char* __restrict__ out,
+                                                          const unsigned char* __restrict__ flip, int N, int Hs, int Ws, int H, int W) {
+    const float sy = (float)Hs / (float)H, sx = (float)Ws / (float)W;            // ATen nearest: src = min(floor(dst * in/out), in-1)
+    const long long total = (long long)N * H * W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        int x = (int)(i % W);
+        const long long r = i / W;
+        const int y = (int)(r % H);
+        const long long n = r / H;
+        if (flip != nullptr && flip[n]) x = W - 1 - x;                           // resize first, then flip (dataloader.py:50-59)
+        const int yy = min((int)floorf((float)y * sy), Hs - 1), xx = min((int)floorf((float)x * sx), Ws - 1);
+        out[i] = (unsigned char)mask[(n * Hs + yy) * Ws + xx];
+    }
+}
+extern "C" int sh_ingest_mask(const void* mask, int is_i64, uint8_t* out, const uint8_t* flip, int N, int Hs, int Ws, int H, int W,
+                              void* stream) {
+    if (!mask || !out || N <= 0 || Hs <= 0 || Ws <= 0 || H <= 0 || W <= 0) return SH_EINVAL;
+    long long g = sh_cdiv((long long)N * H * W, 256);
+    if (g > 16384) g = 16384;
+    if (is_i64) ingest_mask_kernel<long long><<<(unsigned)g, 256, 0, (hipStream_t)stream>>>((const long long*)mask, out, flip, N, Hs, Ws, H, W);
+    else ingest_mask_kernel<unsigned char><<<(unsigned)g, 256, 0, (hipStream_t)stream>>>((const unsigned char*)mask, out, flip, N, Hs, Ws, H, W);
+    return sh_launch_status();
+}

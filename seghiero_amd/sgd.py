@@ -12,7 +12,20 @@ class FusedSGD(torch.optim.Optimizer):
     def __init__(self, params, lr, momentum=0.9, weight_decay=1e-4):
         if lr < 0 or momentum < 0 or weight_decay < 0:
             raise ValueError("lr, momentum and weight_decay must be non-negative")
-        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        # the extra keys are torch.optim.SGD's own (at their defaults -- the only values the kernel implements), so that a
+        # state_dict written here loads into the reference's ``optim.SGD`` and vice versa (train.py:419-435 checkpoints)
+        super().__init__(params, dict(lr=lr, momentum=momentum, dampening=0, weight_decay=weight_decay, nesterov=False,
+                                      maximize=False, foreach=None, differentiable=False, fused=None))
+
+    def adopt_layouts(self):
+        """After ``load_state_dict``: momentum buffers must live in their parameter's memory layout (OHWI conv weights)."""
+        for group in self.param_groups:
+            if group.get("dampening", 0) != 0 or group.get("nesterov", False) or group.get("maximize", False):
+                raise ValueError("FusedSGD implements plain momentum SGD only (dampening=0, nesterov=False, maximize=False)")
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st and st.get("momentum_buffer") is not None and st["momentum_buffer"].stride() != p.stride():
+                    st["momentum_buffer"] = torch.empty_like(p).copy_(st["momentum_buffer"])
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):

@@ -81,6 +81,29 @@ class SegHieroTrainer:
         for k, m in self.modules().items():
             m.load_state_dict(sd[k])
 
+    def save_checkpoint(self, path, epoch, config=None):
+        """Write the dict ``train.py:421-428`` writes (same keys; state_dicts in the reference's NCHW shapes, optimizer state
+        in ``torch.optim.SGD``'s format), so reference tooling -- ``infer.py:277-279``, a resumed ``train.py`` -- can load it."""
+        ckpt = {"epoch": int(epoch),
+                "backbone_state_dict": self.backbone.state_dict(),
+                "aspp_head_state_dict": self.aspp_head.state_dict(),
+                "aux_head_state_dict": self.aux_head.state_dict(),
+                "optimizer_state_dict": self.optimizer.state_dict(),
+                "config": config if config is not None else {}}
+        torch.save(ckpt, path)
+
+    def load_checkpoint(self, path, load_optimizer=True):
+        """Load a checkpoint written by the reference (``train.py:419-435``) or by ``save_checkpoint``.  Only tensors and plain
+        containers are read (``weights_only=True``); returns the stored epoch."""
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+        self.backbone.load_state_dict(ckpt["backbone_state_dict"])
+        self.aspp_head.load_state_dict(ckpt["aspp_head_state_dict"])
+        self.aux_head.load_state_dict(ckpt["aux_head_state_dict"])
+        if load_optimizer and ckpt.get("optimizer_state_dict") is not None:
+            self.optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+            self.optimizer.adopt_layouts()
+        return int(ckpt.get("epoch", 0))
+
     def train(self):
         for m in self.modules().values():
             m.train()

@@ -257,3 +257,37 @@ def test_full_size_configs_run_and_stay_finite(sa, cfg):
     val.backward()
     if cfg != "C4":      # (the RMI term is not masked by validity in the reference either: one-hot of class 0 on void pixels)
         assert float(logits.grad.abs().max()) == 0.0
+
+
+def test_checkpoint_roundtrip_reference_format(sa, tmp_path):
+    """checkpoints in the reference's format (train.py:419-435).  A trained-one-step trainer saves, a fresh
+    one loads and continues identically; the optimizer part loads into torch.optim.SGD (what the reference builds)."""
+    from seghiero_amd.train_step import SegHieroTrainer
+    from seghiero_amd.synthetic import make_batch
+    kw = dict(depth=18, n_fine=4, coarse_to_fine_map=[[0, 1], [2, 3]], lr=0.01, device=DEV,
+              head_kw=dict(c1_channels=16, aspp_channels=32, dilations=(1, 2, 3, 4), proj_dim=16))
+    torch.manual_seed(0)
+    a = SegHieroTrainer(**kw)
+    img, lab = make_batch(2, 64, 4, seed=1, device=DEV)
+    a.train_step(img, lab, 0)
+    path = str(tmp_path / "ck.pth")
+    a.save_checkpoint(path, epoch=3, config={"training": {"lr": 0.01}})
+    raw = torch.load(path, map_location="cpu", weights_only=True)
+    assert set(raw) == {"epoch", "backbone_state_dict", "aspp_head_state_dict", "aux_head_state_dict", "optimizer_state_dict", "config"}
+    assert raw["backbone_state_dict"]["layer1.0.conv1.weight"].shape == (64, 64, 3, 3)
+    torch.manual_seed(123)
+    b = SegHieroTrainer(**kw)
+    assert b.load_checkpoint(path) == 3
+    for (k, va), (_, vb) in zip(a.backbone.state_dict().items(), b.backbone.state_dict().items()):
+        assert torch.equal(va, vb), k
+    la, lb = a.train_step(img, lab, 1), b.train_step(img, lab, 1)
+    assert float(la) == float(lb)
+    for pa, pb in zip(a.params, b.params):
+        assert torch.equal(pa, pb)
+    # the reference's optimizer accepts the saved optimizer state
+    ref_params = [torch.nn.Parameter(p.detach().cpu().contiguous()) for p in a.params]
+    ref_opt = torch.optim.SGD(ref_params, lr=0.01, momentum=0.9, weight_decay=1e-4)
+    ref_opt.load_state_dict(raw["optimizer_state_dict"])
+    for p in ref_params:
+        p.grad = torch.zeros_like(p)
+    ref_opt.step()

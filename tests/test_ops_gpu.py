@@ -271,3 +271,48 @@ def test_sgd(ops):
         ops.sgd_step(gp, [gr.to(DEV) for gr in grads], bufs, 0.05, 0.9, 1e-4, step == 0)
     for a, b in zip(gp, ref):
         close(a, b, 1e-6, 1e-6)
+
+
+@pytest.mark.parametrize("resize", [None, (40, 28)])
+def test_ingest_matches_reference_transform_arithmetic(ops, resize):
+    """flip + ToTensor + Normalize + nearest mask resize (dataset/dataloader.py:49-63) on the device,
+    against the same steps in torch on the CPU -- bit-exact for the image (same operation order) and the labels."""
+    from seghiero_amd.ingest import JointTransformDevice
+    g = torch.Generator().manual_seed(3)
+    n, h, w = 5, 28, 40                       # resize is (W, H) as in PIL
+    rgb = torch.randint(0, 256, (n, h, w, 3), generator=g, dtype=torch.uint8)
+    hs, ws = (h, w) if resize is None else (61, 47)
+    mask = torch.randint(0, 9, (n, hs, ws), generator=g)
+    mask[0, :3] = 255
+    tf = JointTransformDevice(resize=resize, hflip_prob=0.5)
+    img, lab = tf(rgb.to(DEV), mask.to(DEV), generator=torch.Generator().manual_seed(11))
+    flip = torch.rand(n, generator=torch.Generator().manual_seed(11)) < 0.5
+    assert flip.any() and not flip.all()
+    mean, std = torch.tensor(tf.normalize_mean).view(1, 3, 1, 1), torch.tensor(tf.normalize_std).view(1, 3, 1, 1)
+    ref = rgb.permute(0, 3, 1, 2).float().div(255)             # ToTensor
+    m = mask
+    if resize is not None:
+        m = F.interpolate(mask[:, None].float(), size=(h, w), mode="nearest").long()[:, 0]
+    ref = torch.where(flip.view(n, 1, 1, 1), ref.flip(3), ref)
+    m = torch.where(flip.view(n, 1, 1), m.flip(2), m)
+    ref = (ref - mean) / std                                     # Normalize
+    assert tuple(img.shape) == (n, 4, h, w) and img.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(img[:, :3].cpu(), ref)
+    assert float(img[:, 3].abs().max()) == 0.0
+    assert lab.dtype == torch.uint8 and torch.equal(lab.cpu().long(), m)
+
+
+def test_backbone_accepts_ingested_input(ops):
+    from seghiero_amd.backbone import ResNetBackbone
+    torch.manual_seed(0)
+    bb = ResNetBackbone(depth=18, pretrained=False).to(DEV).train()
+    x = torch.randn(2, 3, 64, 64)
+    a = bb(x.to(DEV))
+    x4 = ops.new_act(2, 4, 64, 64, DEV, zero=True)
+    x4[:, :3] = x.to(DEV)
+    bb2 = ResNetBackbone(depth=18, pretrained=False).to(DEV).train()
+    bb2.load_state_dict(bb.state_dict())
+    b = bb2(x4)
+    # running stats were bumped once in each module from the same input: compare the features directly
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
