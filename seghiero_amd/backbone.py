@@ -161,6 +161,8 @@ class _BackboneFn(torch.autograd.Function):
             if d is None:
                 continue
             d = _block_bwd(blk, saved[idx], d, gm)
+            if idx == 0 or blocks[idx - 1][0] != li:                      # first block of a stage: the stage's gradients are final
+                gm.flush(list(layers[li].parameters()))
         if d is not None:
             x4, wpad, s_rec, s_out = ctx.stem
             dpool = ops.maxpool_bwd(s_out, d)
@@ -168,6 +170,7 @@ class _BackboneFn(torch.autograd.Function):
             dw = torch.empty_like(mod.stem_conv.weight)
             ops._call("sh_nhwc_to_nchw", dwp.data_ptr(), dw.data_ptr(), dw.shape[0], 3, 7, 7, 4, ops._st())
             gm.put(mod.stem_conv.weight, dw); gm.put(mod.stem_bn.weight, dg); gm.put(mod.stem_bn.bias, db)
+            gm.flush([mod.stem_conv.weight, mod.stem_bn.weight, mod.stem_bn.bias])
         ctx.saved = ctx.stem = None
         return (None, None) + gm.ordered(ctx.params)
 

@@ -64,7 +64,24 @@ def broadcast_module_state(modules, src=0):
                 dist.broadcast(t.data, src=src)
 
 
+_ACTIVE = None          # the GradSync that is collecting gradients of the backward pass in flight (set by begin())
+
+
+def early_flush(pairs):
+    """Called from inside the hand-scheduled backward nodes with (parameter, final gradient) pairs: lets the gradient
+    exchange of finished buckets start while the rest of the backward is still running.  No-op without an active sync."""
+    if _ACTIVE is not None:
+        _ACTIVE.early(pairs)
+
+
 class GradSync:
+    """Bucketed gradient all-reduce over one flat fp32 arena laid out in backward order (aux, head, layer4 ... stem).
+
+    ``begin()`` before ``loss.backward()``; the backward nodes hand finished gradients to ``early()`` (via ``early_flush``)
+    at a few points -- end of the aux / head nodes, end of each ResNet stage -- which copies them into the arena and launches
+    the all-reduce of every bucket that became complete on a side stream, overlapped with the remaining backward kernels;
+    ``reduce()`` after backward sends what is left, waits, and points ``p.grad`` at the reduced arena (no copy back)."""
+
     def __init__(self, params, bucket_mb=32.0, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -73,11 +90,12 @@ class GradSync:
         dev = self.order[0].device
         total = sum(p.numel() for p in self.order)
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
-        self.views, self.buckets = {}, []
+        self.views, self.buckets, self.bucket_of = {}, [], {}
         off, start, limit = 0, 0, int(bucket_mb * (1 << 20) / 4)
         cur = []
         for p in self.order:
             self.views[id(p)] = (off, p.numel())
+            self.bucket_of[id(p)] = len(self.buckets)
             cur.append(p)
             off += p.numel()
             if off - start >= limit:
@@ -86,44 +104,69 @@ class GradSync:
         if cur:
             self.buckets.append((start, off, cur))
         self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self._in_arena, self._launched, self._works = set(), set(), []
+
+    # ------------------------------------------------------------------ per-step protocol
+    def begin(self):
+        global _ACTIVE
+        self._in_arena, self._launched, self._works = set(), set(), []
+        _ACTIVE = self if self.world > 1 else None
+
+    def _stage(self, pairs):
+        srcs, dsts = [], []
+        for p, g in pairs:
+            if g is None or id(p) not in self.views or id(p) in self._in_arena:
+                continue
+            o, n = self.views[id(p)]
+            if g.shape != p.shape:
+                g = g.reshape(p.shape)
+            if g.stride() != p.stride():
+                g = torch.empty_like(p).copy_(g)
+            srcs.append(g.as_strided((n,), (1,)) if not g.is_contiguous() else g.reshape(-1))
+            dsts.append(self.flat[o:o + n])
+            self._in_arena.add(id(p))
+        if srcs:
+            torch._foreach_copy_(dsts, srcs)
+
+    def _launch(self, bi):
+        start, end, _ = self.buckets[bi]
+        buf = self.flat[start:end]
+        self._launched.add(bi)
+        if self.stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ev)
+                self._works.append(all_reduce(buf, group=self.group, async_op=True))
+        else:
+            self._works.append(all_reduce(buf, group=self.group, async_op=True))
+
+    def early(self, pairs):
+        if self.world == 1:
+            return
+        self._stage(pairs)
+        for bi, (_, _, plist) in enumerate(self.buckets):
+            if bi not in self._launched and all(id(p) in self._in_arena for p in plist):
+                self._launch(bi)
 
     def reduce(self, params):
         """All-reduce (sum) every gradient in place; returns the scale (1/world) the optimizer must apply."""
+        global _ACTIVE
+        _ACTIVE = None
         if self.world == 1:
             return 1.0
-        cur = torch.cuda.current_stream() if self.stream is not None else None
-        works = []
-        for start, end, plist in self.buckets:
-            srcs, dsts = [], []
-            for p in plist:
-                if p.grad is None:
-                    continue
-                o, n = self.views[id(p)]
-                g = p.grad
-                if g.stride() != p.stride():
-                    g = torch.empty_like(p).copy_(g)
-                srcs.append(g.as_strided((n,), (1,)) if not g.is_contiguous() else g.reshape(-1))
-                dsts.append(self.flat[o:o + n])
-            if not srcs:
-                continue
-            torch._foreach_copy_(dsts, srcs)
-            buf = self.flat[start:end]
-            if self.stream is not None:
-                ev = torch.cuda.Event()
-                ev.record(cur)
-                with torch.cuda.stream(self.stream):
-                    self.stream.wait_event(ev)
-                    works.append(all_reduce(buf, group=self.group, async_op=True))
-            else:
-                works.append(all_reduce(buf, group=self.group, async_op=True))
-        for w in works:
+        self._stage([(p, p.grad) for p in params])
+        for bi, (_, _, plist) in enumerate(self.buckets):
+            if bi not in self._launched and any(id(p) in self._in_arena for p in plist):
+                self._launch(bi)
+        for w in self._works:
             if w is not None:
                 w.wait()
         if self.stream is not None:
-            cur.wait_stream(self.stream)
-        for start, end, plist in self.buckets:          # point the grads at the reduced arena (no copy back)
-            for p in plist:
-                if p.grad is not None:
-                    o, n = self.views[id(p)]
-                    p.grad = self.flat[o:o + n].as_strided(p.shape, p.stride())
+            torch.cuda.current_stream().wait_stream(self.stream)
+        for p in params:                                # point the grads at the reduced arena (no copy back)
+            if p.grad is not None and id(p) in self._in_arena:
+                o, n = self.views[id(p)]
+                p.grad = self.flat[o:o + n].as_strided(p.shape, p.stride())
+        self._works = []
         return 1.0 / self.world

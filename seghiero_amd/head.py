@@ -202,6 +202,7 @@ class _HeadFn(torch.autograd.Function):
                 gm.put(proj.weight, dwp)
                 dc4 = dc4n
         ctx.R = None
+        gm.flush(ctx.params)
         return (None, dc1, dc4) + gm.ordered(ctx.params)
 
 
@@ -259,6 +260,7 @@ class _AuxFn(torch.autograd.Function):
         gm = L.GradMap()
         gm.put(mod[0].weight, dw); gm.put(mod[1].weight, dg); gm.put(mod[1].bias, db)
         ctx.rec = None
+        gm.flush(ctx.params)
         return (None, dx) + gm.ordered(ctx.params)
 
 

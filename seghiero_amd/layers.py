@@ -173,3 +173,8 @@ class GradMap:
 
     def ordered(self, params):
         return tuple(self.g.get(id(p)) for p in params)
+
+    def flush(self, params):
+        """Hand the (final) gradients of `params` to the data-parallel exchange while backward continues (ddp.GradSync)."""
+        from . import ddp
+        ddp.early_flush([(p, self.g.get(id(p))) for p in params])

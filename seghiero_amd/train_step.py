@@ -123,6 +123,8 @@ class SegHieroTrainer:
         """One iteration of train.py:260-320.  Returns the (device) loss scalar; nothing is synchronised."""
         self.optimizer.zero_grad(set_to_none=True)
         loss, _, _, _ = self.forward_loss(img, fine_mask, epoch)
+        if self.grad_sync is not None:
+            self.grad_sync.begin()                       # buckets are exchanged as the backward nodes finish them
         loss.backward()
         gscale = 1.0
         if self.grad_sync is not None:

@@ -1,6 +1,8 @@
-"""Cross-GPU BatchNorm (SyncBN, SURVEY 8e "new functionality"): two ranks, each with half of a batch and SYNC_BN on,
+"""Data-parallel path on the GPU.  (1) Cross-GPU BatchNorm (SyncBN): two ranks, each with half of a batch and SYNC_BN on,
 must reproduce the single-rank full-batch forward and (summed over ranks) the parameter gradients of backbone + contrast head.  Both ranks share cuda:0 and exchange over gloo (staged through the host by
-seghiero_amd.ddp), which is the rehearsal path for RCCL on a one-GPU box."""
+seghiero_amd.ddp), which is the rehearsal path for RCCL on a one-GPU box.  (2) The whole DDP training step -- GradSync with
+buckets handed over from inside the backward nodes -- on two ranks fed the same batch must reproduce single-rank training
+bit for bit (x + x, then the 1/2 folded into SGD, is exact)."""
 import os
 
 import numpy as np
@@ -87,3 +89,64 @@ def test_syncbn_two_ranks_equals_full_batch():
     tot = _rel(np.concatenate([(res[0]["grads"][k] + res[1]["grads"][k]).ravel() for k in full["grads"]]),
                np.concatenate([full["grads"][k].ravel() for k in full["grads"]]))
     assert tot < 5e-4 and worst < 5e-3, (tot, worst)
+
+
+TR_KW = dict(depth=18, n_fine=4, coarse_to_fine_map=[[0, 1], [2, 3]], lr=0.01, device="cuda:0",
+             head_kw=dict(c1_channels=16, aspp_channels=32, dilations=(1, 2, 3, 4), proj_dim=16))
+
+
+def _train(n_steps, sync):
+    from seghiero_amd import ddp
+    from seghiero_amd.synthetic import make_batch
+    from seghiero_amd.train_step import SegHieroTrainer
+    torch.manual_seed(0)
+    tr = SegHieroTrainer(**TR_KW)
+    if sync:
+        ddp.broadcast_module_state(list(tr.modules().values()))
+        tr.grad_sync = ddp.GradSync(tr.params, bucket_mb=4.0)
+    img, lab = make_batch(2, 64, 4, seed=5, device="cuda:0")
+    losses = [float(tr.train_step(img, lab, 0)) for _ in range(n_steps)]
+    torch.cuda.synchronize()
+    launched = len(tr.grad_sync.buckets) if sync else 0
+    return losses, [p.detach().cpu().numpy().copy() for p in tr.params], launched
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from seghiero_amd import ddp
+    ddp.init_from_env(backend="gloo")
+    try:
+        out = _train(2, sync=True)
+    except Exception as e:
+        import traceback
+        out = "rank %d failed: %s\n%s" % (rank, e, traceback.format_exc())
+    q.put((rank, out))
+    if not isinstance(out, str):
+        dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_two_ranks_same_batch_equals_single_rank():
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29400 + os.getpid() % 150
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+    for r in res.values():
+        assert not isinstance(r, str), r
+    losses, params, _ = _train(2, sync=False)
+    for rank in (0, 1):
+        l2, p2, nb = res[rank]
+        assert nb >= 3                                  # several buckets => some left during backward
+        assert l2 == losses, (rank, l2, losses)
+        for a, b in zip(p2, params):
+            np.testing.assert_array_equal(a, b)

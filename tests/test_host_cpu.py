@@ -133,9 +133,17 @@ def _ddp_worker(rank, world, port, q):
     sync = ddp.GradSync(params, bucket_mb=0.01)
     assert len(sync.buckets) >= 2
     g = torch.Generator().manual_seed(100 + rank)
-    for p in params:
-        p.grad = torch.empty_like(p).copy_(torch.randn(p.shape, generator=g))
+    grads = [torch.empty_like(p).copy_(torch.randn(p.shape, generator=g)) for p in params]
+    # protocol of a training step: begin, the backward nodes hand over finished gradients early (last parameters first),
+    # autograd then stores p.grad, reduce() sends the rest and repoints p.grad at the reduced arena
+    sync.begin()
+    ddp.early_flush([(params[3], grads[3])])
+    ddp.early_flush([(params[2], grads[2]), (params[1], grads[1])])
+    assert len(sync._launched) >= 1                 # at least one bucket went out before the "backward" ended
+    for p, gr in zip(params, grads):
+        p.grad = gr
     scale = sync.reduce(params)
+    assert ddp._ACTIVE is None
     m = torch.nn.Linear(3, 2)
     with torch.no_grad():
         m.weight.fill_(float(rank))
