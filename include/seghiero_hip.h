@@ -151,9 +151,11 @@ int sh_bn_bwd_apply(const float* dout, int lddo, const float* out, int ldo, cons
                     int lddres, int64_t M, int C, int relu, void* stream);
 
 /* pooling / resampling -------------------------------------------------------------------- */
-/* nn.MaxPool2d(3, 2, 1) (models/backbone/resnet.py:68) and its backward (first-max tie rule). */
-int sh_maxpool_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
-int sh_maxpool_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+/* nn.MaxPool2d(3, 2, 1) (models/backbone/resnet.py:68) and its backward (first-max tie rule).  argmax: one byte per
+ * output element [N,Ho,Wo,C] = window position kh*3+kw of the first maximum (NULL in fwd = not recorded); the backward
+ * gathers from it and dy alone (x is not re-read, so the stem activation need not be kept). */
+int sh_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int N, int H, int W, int C, void* stream);
+int sh_maxpool_bwd(const uint8_t* argmax, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
 /* nn.AdaptiveAvgPool2d(1) (sep_aspp_contrast_head.py:93,104): x [N,HW,C] -> y [N,C]; backward broadcasts. */
 int sh_avgpool_fwd(const float* x, int ldx, float* y, int N, int HW, int C, void* stream);
 int sh_avgpool_bwd(const float* dy, float* dx, int lddx, int N, int HW, int C, float scale, int accumulate, void* stream);

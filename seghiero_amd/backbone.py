@@ -123,7 +123,7 @@ class _BackboneFn(torch.autograd.Function):
         wpad = ops.new_act(w.shape[0], 4, 7, 7, w.device, zero=True)
         ops._call("sh_nchw_to_nhwc", w.data_ptr(), wpad.data_ptr(), w.shape[0], 3, 7, 7, 4, ops._st())
         s_out, s_rec = L.cba_fwd(x4, wpad, L.conv_geom(mod.stem_conv), mod.stem_bn, True, training)
-        pooled = ops.maxpool_fwd(s_out)
+        pooled, pool_idx = ops.maxpool_fwd(s_out, want_argmax=training)
         h = pooled
         saved, outs = [], []
         for layer in (mod.layer1, mod.layer2, mod.layer3, mod.layer4):
@@ -133,7 +133,9 @@ class _BackboneFn(torch.autograd.Function):
             outs.append(h)
         if training:
             L.bump_bn_counters(_all_bns(mod))
-        ctx.mod, ctx.saved, ctx.stem = mod, saved, (x4, wpad, s_rec, s_out)
+        if training:
+            s_rec.out = None                                           # BN+ReLU backward recomputes its mask from y (no residual here)
+        ctx.mod, ctx.saved, ctx.stem = mod, saved, (x4, wpad, s_rec, pool_idx, tuple(s_out.shape[2:]))
         ctx.training = training
         ctx.params = params
         return tuple(outs)
@@ -164,8 +166,8 @@ class _BackboneFn(torch.autograd.Function):
             if idx == 0 or blocks[idx - 1][0] != li:                      # first block of a stage: the stage's gradients are final
                 gm.flush(list(layers[li].parameters()))
         if d is not None:
-            x4, wpad, s_rec, s_out = ctx.stem
-            dpool = ops.maxpool_bwd(s_out, d)
+            x4, wpad, s_rec, pool_idx, (sh, sw) = ctx.stem
+            dpool = ops.maxpool_bwd(pool_idx, d, sh, sw)
             _, dwp, dg, db, _ = L.cba_bwd(s_rec, mod.stem_bn, dpool, need_dx=False)
             dw = torch.empty_like(mod.stem_conv.weight)
             ops._call("sh_nhwc_to_nchw", dwp.data_ptr(), dw.data_ptr(), dw.shape[0], 3, 7, 7, 4, ops._st())

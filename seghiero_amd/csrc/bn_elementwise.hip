@@ -73,6 +73,7 @@ __device__ __forceinline__ void reduce_partials_4ch(const float* __restrict__ pa
     const int t = threadIdx.x;
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool vec = (C & 3) == 0;
+#pragma unroll 4                    // the loads of successive partials are independent: keep several in flight (latency-bound kernel)
     for (int p = t; p < P; p += 256) {
         const float* r0 = partials + ((long long)p * 2 + 0) * C + c0;
         const float* r1 = partials + ((long long)p * 2 + 1) * C + c0;

@@ -13,8 +13,8 @@ static inline unsigned grid_for(long long work_items, int block = 256, int cap =
 
 // ------------------------------------------------------------------------------------------ maxpool 3x3 / 2 / pad 1
 // reference: nn.MaxPool2d(kernel_size=3, stride=2, padding=1) behind models/backbone/resnet.py:68
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
-                                                          int Ho, int Wo, int C4, long long total) {
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned* __restrict__ argmax,
+                                                          int H, int W, int Ho, int Wo, int C4, long long total) {
     GRID_STRIDE(i, total) {
         const int c = (int)(i % C4);
         long long q = i / C4;
@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
         const int oh = (int)(q % Ho);
         const long long n = q / Ho;
         f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        unsigned idx = 0;                  // per channel one byte: window position kh*3+kw of the FIRST maximum (ATen's rule)
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int ih = oh * 2 - 1 + kh;
@@ -32,15 +33,17 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
                 if ((unsigned)iw >= (unsigned)W) continue;
                 const f32x4 v = ld4(x + (((n * H + ih) * W + iw) * C4 + c) * 4);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) m[j] = (v[j] > m[j] || v[j] != v[j]) ? v[j] : m[j];
+                for (int j = 0; j < 4; ++j)
+                    if (v[j] > m[j] || v[j] != v[j]) { m[j] = v[j]; idx = (idx & ~(0xffu << (8 * j))) | ((unsigned)(kh * 3 + kw) << (8 * j)); }
             }
         }
         st4(y + i * 4, m);
+        if (argmax != nullptr) argmax[i] = idx;
     }
 }
-// backward, gather form: input pixel (ih,iw) receives dy from every window whose FIRST maximum (row-major scan,
-// the rule ATen's max_pool2d uses) is this pixel.
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+// backward, gather form: input pixel (ih,iw) receives dy from every window whose recorded first maximum is this pixel
+// (each input element is written exactly once: deterministic, no atomics, x is not re-read).
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned* __restrict__ argmax, const float* __restrict__ dy,
                                                           float* __restrict__ dx, int H, int W, int Ho, int Wo, int C4,
                                                           long long total) {
     GRID_STRIDE(i, total) {
@@ -50,51 +53,37 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
         const int ih = (int)(q % H);
         const long long n = q / H;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        // windows containing (ih,iw): oh in {(ih+1)/2 - 1, (ih+1)/2} filtered by the containment test
         for (int oh = (ih + 1) / 2 - 1; oh <= (ih + 1) / 2; ++oh) {
             if (oh < 0 || oh >= Ho) continue;
-            if (ih < oh * 2 - 1 || ih > oh * 2 + 1) continue;
+            const int kh = ih - (oh * 2 - 1);
+            if (kh < 0 || kh > 2) continue;
             for (int ow = (iw + 1) / 2 - 1; ow <= (iw + 1) / 2; ++ow) {
                 if (ow < 0 || ow >= Wo) continue;
-                if (iw < ow * 2 - 1 || iw > ow * 2 + 1) continue;
-                // is (ih,iw) the first max of window (oh,ow)?  scan the window in row-major order
-                f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-                int bidx[4] = {-1, -1, -1, -1};
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh) {
-                    const int yy = oh * 2 - 1 + kh;
-                    if ((unsigned)yy >= (unsigned)H) continue;
-#pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) {
-                        const int xx = ow * 2 - 1 + kw;
-                        if ((unsigned)xx >= (unsigned)W) continue;
-                        const f32x4 v = ld4(x + (((n * H + yy) * W + xx) * C4 + c) * 4);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (v[j] > best[j] || v[j] != v[j]) { best[j] = v[j]; bidx[j] = yy * W + xx; }
-                    }
-                }
-                const f32x4 g = ld4(dy + (((n * Ho + oh) * Wo + ow) * C4 + c) * 4);
+                const int kw = iw - (ow * 2 - 1);
+                if (kw < 0 || kw > 2) continue;
+                const long long o = ((n * Ho + oh) * Wo + ow) * C4 + c;
+                const unsigned idx = argmax[o], want = (unsigned)(kh * 3 + kw);
+                const f32x4 g = ld4(dy + o * 4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (bidx[j] == ih * W + iw) acc[j] += g[j];
+                    if (((idx >> (8 * j)) & 0xffu) == want) acc[j] += g[j];
             }
         }
         st4(dx + i * 4, acc);
     }
 }
-extern "C" int sh_maxpool_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
-    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return SH_EINVAL;
+extern "C" int sh_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int N, int H, int W, int C, void* stream) {
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || ((uintptr_t)argmax & 3)) return SH_EINVAL;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const long long total = (long long)N * Ho * Wo * (C / 4);
-    maxpool_fwd_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>(x, y, H, W, Ho, Wo, C / 4, total);
+    maxpool_fwd_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>(x, y, reinterpret_cast<unsigned*>(argmax), H, W, Ho, Wo, C / 4, total);
     return sh_launch_status();
 }
-extern "C" int sh_maxpool_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
-    if (!x || !dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return SH_EINVAL;
+extern "C" int sh_maxpool_bwd(const uint8_t* argmax, const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
+    if (!argmax || !dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || ((uintptr_t)argmax & 3)) return SH_EINVAL;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const long long total = (long long)N * H * W * (C / 4);
-    maxpool_bwd_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>(x, dy, dx, H, W, Ho, Wo, C / 4, total);
+    maxpool_bwd_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const unsigned*>(argmax), dy, dx, H, W, Ho, Wo, C / 4, total);
     return sh_launch_status();
 }
 

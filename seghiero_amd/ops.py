@@ -366,23 +366,27 @@ def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None):
 
 
 # ----------------------------------------------------------------------------- pooling / resampling
-def maxpool_fwd(x):
+def maxpool_fwd(x, want_argmax=True):
+    """-> (y, argmax): argmax uint8 [N,Ho,Wo,C] (window position of the first maximum) or None."""
     n, c, h, w = x.shape
     xp, ldx = pm(x)
     if ldx != c:
         raise SegHieroHipError("maxpool needs a dense NHWC tensor")
-    y = new_act(n, c, (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1, x.device)
-    _call("sh_maxpool_fwd", xp, y.data_ptr(), n, h, w, c, _st())
-    return y
+    ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    y = new_act(n, c, ho, wo, x.device)
+    am = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.uint8) if want_argmax else None
+    _call("sh_maxpool_fwd", xp, y.data_ptr(), None if am is None else am.data_ptr(), n, h, w, c, _st())
+    return y, am
 
 
-def maxpool_bwd(x, dy):
-    n, c, h, w = x.shape
+def maxpool_bwd(argmax, dy, h, w):
+    """dx [N,C,h,w] from the recorded argmax and dy (the pooled tensor's gradient)."""
+    n, c = dy.shape[:2]
     dyp, ld = pm(dy)
     if ld != c:
         raise SegHieroHipError("maxpool backward needs a dense NHWC gradient")
-    dx = new_act(n, c, h, w, x.device)
-    _call("sh_maxpool_bwd", x.data_ptr(), dyp, dx.data_ptr(), n, h, w, c, _st())
+    dx = new_act(n, c, h, w, dy.device)
+    _call("sh_maxpool_bwd", argmax.data_ptr(), dyp, dx.data_ptr(), n, h, w, c, _st())
     return dx
 
 

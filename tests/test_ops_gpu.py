@@ -202,9 +202,9 @@ def test_maxpool(ops, shape):
     dy = torch.randn(ref.shape, generator=g)
     ref.backward(dy)
     xg = nhwc(x.detach())
-    y = ops.maxpool_fwd(xg)
+    y, am = ops.maxpool_fwd(xg)
     assert torch.equal(y.cpu(), ref.detach())
-    dx = ops.maxpool_bwd(xg, nhwc(dy))
+    dx = ops.maxpool_bwd(am, nhwc(dy), xg.shape[2], xg.shape[3])
     close(dx, x.grad, 1e-6, 1e-6)
 
 
