@@ -112,10 +112,13 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const float* __restric
     __shared__ float red[16][DW_CH];
     __shared__ float colmean[DW_CH];
     const int t = threadIdx.x, cq = t & 15, pl = t >> 4;
-    const int c0 = blockIdx.y * DW_CH;
+    // 1-D grid, channel chunk fastest: the blocks that run together read adjacent 256-byte pieces of the same pixel rows
+    const unsigned nch = (unsigned)((C + DW_CH - 1) / DW_CH);
+    const unsigned tile = blockIdx.x / nch;
+    const int c0 = (int)(blockIdx.x % nch) * DW_CH;
     const int tiles_x = W / DT, tiles_y = H / DT;
-    const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y;
-    const long long n = blockIdx.x / (tiles_x * tiles_y);
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y;
+    const long long n = tile / (tiles_x * tiles_y);
     for (int i = t; i < 9 * DW_CH; i += 256) {
         const int tap = i / DW_CH, cc = i % DW_CH;
         ws[tap][cc] = (c0 + cc < C) ? w[(long long)(c0 + cc) * 9 + (MODE == 0 ? tap : 8 - tap)] : 0.f;
@@ -171,8 +174,8 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const float* __restric
             float m2 = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) m2 += red[k][t];
-            partials[((long long)blockIdx.x * 2 + 0) * C + c0 + t] = colsum;
-            partials[((long long)blockIdx.x * 2 + 1) * C + c0 + t] = m2;
+            partials[((long long)tile * 2 + 0) * C + c0 + t] = colsum;
+            partials[((long long)tile * 2 + 1) * C + c0 + t] = m2;
         }
     }
 }
@@ -183,13 +186,15 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tile_kernel(const float* __r
     __shared__ __attribute__((aligned(16))) float xs[(DT + 2) * (DT + 2)][DW_CH];
     __shared__ float red[16][DW_CH];
     const int t = threadIdx.x, cq = t & 15, pl = t >> 4;
-    const int c0 = blockIdx.y * DW_CH, c = c0 + cq * 4;
+    // 1-D grid, channel chunk fastest (see dwconv_tile_kernel): group = blockIdx.x / nch walks the tiles with stride ngroups
+    const unsigned nch = (unsigned)((C + DW_CH - 1) / DW_CH), group = blockIdx.x / nch, ngroups = gridDim.x / nch;
+    const int c0 = (int)(blockIdx.x % nch) * DW_CH, c = c0 + cq * 4;
     const bool cok = c < C;
     const int tiles_x = W / DT, tiles_y = H / DT;
     f32x4 acc[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (long long tile = group; tile < ntiles; tile += ngroups) {
         const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
         const long long n = tile / (tiles_x * tiles_y);
         __syncthreads();
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tile_kernel(const float* __r
             float a = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) a += red[r][t];
-            if (c0 + t < C) partials[((long long)blockIdx.x * 9 + k) * C + c0 + t] = a;
+            if (c0 + t < C) partials[((long long)group * 9 + k) * C + c0 + t] = a;
         }
     }
 }
@@ -303,7 +308,7 @@ extern "C" int sh_dwconv_fprop(const float* x, int ldx, const float* w, float* y
     const long long M = (long long)N * H * W;
     dim3 grid((unsigned)sh_cdiv(M, DW_PIX), (unsigned)sh_cdiv(C, DW_CH));
     if (dil == 1 && H % DT == 0 && W % DT == 0)       // same partial count: (H/8)*(W/8) tiles of 64 pixels per image
-        dwconv_tile_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, w, y, ldy, stat_partials, H, W, C, 0);
+        dwconv_tile_kernel<0><<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(x, ldx, w, y, ldy, stat_partials, H, W, C, 0);
     else
         dwconv_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, w, y, ldy, stat_partials, H, W, C, dil, M, 0);
     return sh_launch_status();
@@ -314,7 +319,7 @@ extern "C" int sh_dwconv_dgrad(const float* dy, int lddy, const float* w, float*
     const long long M = (long long)N * H * W;
     dim3 grid((unsigned)sh_cdiv(M, DW_PIX), (unsigned)sh_cdiv(C, DW_CH));
     if (dil == 1 && H % DT == 0 && W % DT == 0)
-        dwconv_tile_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(dy, lddy, w, dx, lddx, nullptr, H, W, C, accumulate);
+        dwconv_tile_kernel<1><<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(dy, lddy, w, dx, lddx, nullptr, H, W, C, accumulate);
     else
         dwconv_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(dy, lddy, w, dx, lddx, nullptr, H, W, C, dil, M, accumulate);
     return sh_launch_status();
@@ -328,7 +333,7 @@ extern "C" int sh_dwconv_wgrad(const float* x, int ldx, const float* dy, int ldd
     if (P > cap) P = cap < 1 ? 1 : cap;
     dim3 grid((unsigned)P, (unsigned)sh_cdiv(C, DW_CH));
     if (dil == 1 && H % DT == 0 && W % DT == 0)
-        dwconv_wgrad_tile_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, dy, lddy, dw_partials, H, W, C, M / (DT * DT));
+        dwconv_wgrad_tile_kernel<<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(x, ldx, dy, lddy, dw_partials, H, W, C, M / (DT * DT));
     else
         dwconv_wgrad_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, dy, lddy, dw_partials, H, W, C, dil, M);
     int rc = sh_launch_status();
