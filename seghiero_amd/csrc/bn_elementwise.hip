@@ -247,8 +247,10 @@ __global__ __launch_bounds__(256) void bn_bwd_partials_v4_kernel(const float* __
                                                                  float* __restrict__ partials, long long M, int C, int relu) {
     __shared__ float red[2][16][64];
     const int t = threadIdx.x, cq = t & 15, rl = t >> 4;
-    const int c = blockIdx.y * 64 + cq * 4;
-    const long long rbeg = (long long)blockIdx.x * STAT_ROWS;
+    // 1-D grid, channel chunk fastest: blocks that run together read adjacent 256-byte pieces of the same rows
+    const unsigned nch = (unsigned)((C + 63) / 64), rb = blockIdx.x / nch, cb = blockIdx.x % nch;
+    const int c = cb * 64 + cq * 4;
+    const long long rbeg = (long long)rb * STAT_ROWS;
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
     if (c < C) {
         const f32x4 mu = ld4(mean + c), is = ld4(invstd + c);
@@ -278,12 +280,12 @@ __global__ __launch_bounds__(256) void bn_bwd_partials_v4_kernel(const float* __
     for (int j = 0; j < 4; ++j) { red[0][rl][cq * 4 + j] = s[j]; red[1][rl][cq * 4 + j] = q[j]; }
     __syncthreads();
     if (t < 128) {
-        const int st = t >> 6, cc = t & 63, ch = blockIdx.y * 64 + cc;
+        const int st = t >> 6, cc = t & 63, ch = cb * 64 + cc;
         if (ch < C) {
             float a = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) a += red[st][k][cc];
-            partials[((long long)blockIdx.x * 2 + st) * C + ch] = a;
+            partials[((long long)rb * 2 + st) * C + ch] = a;
         }
     }
 }
@@ -296,7 +298,7 @@ extern "C" int sh_bn_bwd_reduce(const float* dout, int lddo, const float* out, i
     const bool v4 = (C & 3) == 0 && ((lddo | ldy | (relu == 1 ? ldo : 0)) & 3) == 0 && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
                     (relu != 1 || ((uintptr_t)out & 15) == 0) && ((uintptr_t)mean & 15) == 0 && ((uintptr_t)invstd & 15) == 0 &&
                     (relu != 2 || ((((uintptr_t)scale | (uintptr_t)shift) & 15) == 0));
-    if (v4) bn_bwd_partials_v4_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(y, ldy, dout, lddo, out, ldo, mean, invstd, scale, shift, partials, M, C, relu);
+    if (v4) bn_bwd_partials_v4_kernel<<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(y, ldy, dout, lddo, out, ldo, mean, invstd, scale, shift, partials, M, C, relu);
     else channel_partials_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(y, ldy, dout, lddo, out, ldo, mean, invstd, scale, shift, partials, M, C, relu);
     return sh_launch_status();
 }

@@ -235,7 +235,24 @@ __global__ __launch_bounds__(256) void loss_bwd_tile_kernel(const float* __restr
         contrib_range(j0, 1.f / sx, W, xlo, tmp); contrib_range(j1, 1.f / sx, W, tmp, xhi);
     }
     const int RH = yhi - ylo + 1, RW = xhi - xlo + 1;
-    if (RH * RW * C > lds_cap) return;                       // cannot happen (host sizes lds_cap from the same bound)
+    if (RH * RW * C + 2 * (RH + RW) > lds_cap) return;       // cannot happen (host sizes lds_cap from the same bound)
+    // source index / weight of every full-resolution row and column of the region, computed once per block (both phases
+    // would otherwise redo lerp_src per pixel and per gathered tap): tab[k] = {i0, bits(w1)}; i1 = i0 + (i0 < in-1), w0 = 1-w1
+    int* tabY = reinterpret_cast<int*>(gt + RH * RW * C);
+    int* tabX = tabY + 2 * RH;
+    for (int k = t; k < RH + RW; k += 256) {
+        const bool isy = k < RH;
+        const Lerp l = isy ? lerp_src(ylo + k, sy, h) : lerp_src(xlo + (k - RH), sx, w);
+        int* dst = isy ? tabY + 2 * k : tabX + 2 * (k - RH);
+        dst[0] = l.i0; dst[1] = __float_as_int(l.w1);
+    }
+    __syncthreads();
+    auto lerp_tab = [&](const int* tab, int k, int in) {
+        Lerp l;
+        l.i0 = tab[2 * k]; l.w1 = __int_as_float(tab[2 * k + 1]);
+        l.i1 = l.i0 + (l.i0 < in - 1 ? 1 : 0); l.w0 = 1.f - l.w1;
+        return l;
+    };
     const float gs = gscale * (gscale_dev ? gscale_dev[0] : 1.f);
     float af = 0.f, ac = 0.f, b;
     if (MODE == 0) {
@@ -255,7 +272,7 @@ __global__ __launch_bounds__(256) void loss_bwd_tile_kernel(const float* __restr
         for (int j = 0; j < MAXC; ++j) g[j] = 0.f;
         const int f = labels[(n * H + oy) * W + ox];
         if (f != IGN) {
-            const Lerp ly = lerp_src(oy, sy, h), lx = lerp_src(ox, sx, w);
+            const Lerp ly = lerp_tab(tabY, ry, h), lx = lerp_tab(tabX, rx, w);
             float z[MAXC];
             fetch_logits<MAXC>(base, ldl, w, ly, lx, identity, C, z);
             if (MODE == 0) {
@@ -280,12 +297,12 @@ __global__ __launch_bounds__(256) void loss_bwd_tile_kernel(const float* __restr
             if (identity) { cylo = cyhi = iy; cxlo = cxhi = ix; }
             else { contrib_range(iy, 1.f / sy, H, cylo, cyhi); contrib_range(ix, 1.f / sx, W, cxlo, cxhi); }
             for (int oy = cylo; oy <= cyhi; ++oy) {
-                const Lerp ly = lerp_src(oy, sy, h);
+                const Lerp ly = lerp_tab(tabY, oy - ylo, h);
                 const float wy = identity ? 1.f : (ly.i0 == iy ? ly.w0 : 0.f) + (ly.i1 == iy ? ly.w1 : 0.f);
                 if (wy == 0.f) continue;
                 const float* row = gt + ((oy - ylo) * RW - xlo) * C + ch;
                 for (int ox = cxlo; ox <= cxhi; ++ox) {
-                    const Lerp lx = lerp_src(ox, sx, w);
+                    const Lerp lx = lerp_tab(tabX, ox - xlo, w);
                     const float wx = identity ? 1.f : (lx.i0 == ix ? lx.w0 : 0.f) + (lx.i1 == ix ? lx.w1 : 0.f);
                     if (wx != 0.f) acc += (wy * wx) * row[ox * C];
                 }
@@ -302,9 +319,9 @@ static int pick_tile(int h, int w, int H, int W, int C, int budget_bytes, int& r
     int best = 0;
     for (int TL = 1; TL <= 32; ++TL) {
         const int side = (h == H && w == W) ? TL : (int)ceilf(TL * s + s) + 3;
-        const long long bytes = (long long)side * side * C * 4;
-        if (bytes > budget_bytes) break;
-        best = TL; region_elems = side * side * C;
+        const long long elems = (long long)side * side * C + 4 * side;      // gradient tile + the row / column lerp tables
+        if (elems * 4 > budget_bytes) break;
+        best = TL; region_elems = (int)elems;
     }
     return best;
 }

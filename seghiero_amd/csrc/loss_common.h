@@ -34,8 +34,25 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 template <int MAXC>
 __device__ __forceinline__ void fetch_logits(const float* __restrict__ base, long long ldl, int w, const Lerp& ly, const Lerp& lx,
                                              bool identity, int C, float (&z)[MAXC]) {
+    // rows of ldl floats: 16-byte loads when the layout allows it (padded NHWC logits: ldl % 4 == 0, ldl >= round4(C),
+    // 16-byte aligned base) -- 4x fewer vector-memory instructions; the per-channel arithmetic is the same either way
+    const bool vec = (MAXC % 4 == 0) && (ldl & 3) == 0 && ldl >= ((C + 3) & ~3) && ((uintptr_t)base & 15) == 0;
     if (identity) {
         const float* p = base + ((long long)ly.i0 * w + lx.i0) * ldl;
+        if (vec) {
+#pragma unroll
+            for (int j = 0; j < MAXC; j += 4) {
+                if (j < C) {
+                    const f32x4 v = ld4(p + j);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) z[j + e] = j + e < C ? v[e] : 0.f;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) z[j + e] = 0.f;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < MAXC; ++j) z[j] = j < C ? p[j] : 0.f;
     } else {
@@ -43,6 +60,21 @@ __device__ __forceinline__ void fetch_logits(const float* __restrict__ base, lon
         const float* p01 = base + ((long long)ly.i0 * w + lx.i1) * ldl;
         const float* p10 = base + ((long long)ly.i1 * w + lx.i0) * ldl;
         const float* p11 = base + ((long long)ly.i1 * w + lx.i1) * ldl;
+        if (vec) {
+#pragma unroll
+            for (int j = 0; j < MAXC; j += 4) {
+                if (j < C) {
+                    const f32x4 a = ld4(p00 + j), b = ld4(p01 + j), c = ld4(p10 + j), d = ld4(p11 + j);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        z[j + e] = j + e < C ? ly.w0 * (lx.w0 * a[e] + lx.w1 * b[e]) + ly.w1 * (lx.w0 * c[e] + lx.w1 * d[e]) : 0.f;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) z[j + e] = 0.f;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < MAXC; ++j)
             z[j] = j < C ? ly.w0 * (lx.w0 * p00[j] + lx.w1 * p01[j]) + ly.w1 * (lx.w0 * p10[j] + lx.w1 * p11[j]) : 0.f;
