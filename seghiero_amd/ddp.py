@@ -7,9 +7,10 @@ per-rank losses), and the only data-path exchange per step is the gradient all-r
 ``class_count`` MIN-reduce inside the loss, ``hiera_triplet_loss.py:193-198``).
 
 ``GradSync`` keeps one flat fp32 arena for all gradients, split into buckets of ~``bucket_mb`` in backward order
-(aux head, ASPP head, backbone from layer4 down to the stem).  Each bucket is all-reduced with ONE RCCL call on a
-side HIP stream as soon as its gradients have been copied in, so the collective of bucket k overlaps the copy of
-bucket k+1; the 1/world scaling is folded into the SGD kernel (``grad_scale``) instead of a separate pass.
+(aux head, ASPP head, backbone from layer4 down to the stem).  The hand-scheduled backward nodes hand finished
+gradients over while backward is still running (``early_flush``: end of the aux / head nodes, end of every ResNet
+stage); each bucket that becomes complete is all-reduced with ONE RCCL call on a side HIP stream, overlapped with the
+remaining backward kernels; the 1/world scaling is folded into the SGD kernel (``grad_scale``) instead of a separate pass.
 """
 import os
 
