@@ -204,6 +204,11 @@ __global__ __launch_bounds__(256) void rmi_gram_kernel(const float* __restrict__
     const int x = blockIdx.x * 64 + lane;
     const int y0 = blockIdx.y * GRAM_ROWS, y1 = min(y0 + GRAM_ROWS, nH);
     const int bc = blockIdx.z, n = bc / C, c = bc - n * C;
+    // label -> one-hot value of this block's channel, as an LDS table (a per-lane index into the by-value table struct
+    // would otherwise live in scratch memory)
+    __shared__ float lut[256];
+    lut[threadIdx.x] = (threadIdx.x < T.nf || threadIdx.x == IGN) ? la_of((int)threadIdx.x, c, T) : 0.f;
+    __syncthreads();
     const float* P = probs + (long long)bc * H * W;
     const uint8_t* L = labels + (long long)n * H * W;
     double acc[45];
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(256) void rmi_gram_kernel(const float* __restrict__
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 pr[3 * (dy + 1) + dx] = (double)P[(long long)(y0 + dy) * W + x + dx];
-                la[3 * (dy + 1) + dx] = (double)la_of(L[(long long)(y0 + dy) * W + x + dx], c, T);
+                la[3 * (dy + 1) + dx] = (double)lut[L[(long long)(y0 + dy) * W + x + dx]];
             }
         for (int y = y0; y < y1; ++y) {
 #pragma unroll
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(256) void rmi_gram_kernel(const float* __restrict__
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 pr[6 + dx] = (double)P[(long long)(y + 2) * W + x + dx];
-                la[6 + dx] = (double)la_of(L[(long long)(y + 2) * W + x + dx], c, T);
+                la[6 + dx] = (double)lut[L[(long long)(y + 2) * W + x + dx]];
             }
             if (grp == 0) {            // pp upper triangle
                 int e = 0;
@@ -288,14 +293,17 @@ __device__ void mm9(const double* A, const double* B, double* Cm, bool tA, bool 
 // one thread per (image, channel): out rmi[bc], K1[bc][81], K2[bc][81]
 __global__ void rmi_solve_kernel(const double* __restrict__ partials, int nparts, int BC, double* __restrict__ rmi, double* __restrict__ K1,
                                  double* __restrict__ K2) {
-    const int bc = blockIdx.x * blockDim.x + threadIdx.x;
-    if (bc >= BC) return;
-    double e[GRAM_ENTRIES];
-    for (int k = 0; k < GRAM_ENTRIES; ++k) e[k] = 0.0;
-    for (int pp = 0; pp < nparts; ++pp) {
-        const double* src = partials + ((long long)bc * nparts + pp) * GRAM_ENTRIES;
-        for (int k = 0; k < GRAM_ENTRIES; ++k) e[k] += src[k];
+    // one block (192 threads) per (image, channel): the Gram partials are summed entry-parallel (same order over the
+    // parts as a serial loop), then one thread runs the 9x9 algebra
+    __shared__ double e[GRAM_ENTRIES];
+    const int bc = blockIdx.x;
+    if (threadIdx.x < GRAM_ENTRIES) {
+        double a = 0.0;
+        for (int pp = 0; pp < nparts; ++pp) a += partials[((long long)bc * nparts + pp) * GRAM_ENTRIES + threadIdx.x];
+        e[threadIdx.x] = a;
     }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     const double alpha = (double)1e-3f;              // f32 1e-3 promoted to f64, as `diag_eye * _POS_ALPHA` does
     double Spp[81], Slp[81], Sll[81];
     { int k = 0; for (int i = 0; i < 9; ++i) for (int j = i; j < 9; ++j) { Spp[i * 9 + j] = Spp[j * 9 + i] = e[k]; Sll[i * 9 + j] = Sll[j * 9 + i] = e[126 + k]; ++k; } }
@@ -354,8 +362,10 @@ __global__ __launch_bounds__(256) void rmi_dprob_kernel(const float* __restrict_
                                                         const double* __restrict__ K1, const double* __restrict__ K2, float* __restrict__ dprob,
                                                         int H, int W, int C) {
     __shared__ double k1[81], k2[81];
+    __shared__ float lut[256];
     const int bc = blockIdx.z, n = bc / C, c = bc - n * C;
     if (threadIdx.x < 81) { k1[threadIdx.x] = K1[(long long)bc * 81 + threadIdx.x]; k2[threadIdx.x] = K2[(long long)bc * 81 + threadIdx.x]; }
+    lut[threadIdx.x] = (threadIdx.x < T.nf || threadIdx.x == IGN) ? la_of((int)threadIdx.x, c, T) : 0.f;
     __syncthreads();
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
@@ -369,7 +379,7 @@ __global__ __launch_bounds__(256) void rmi_dprob_kernel(const float* __restrict_
             const int yy = y + dy - 2, xx = x + dx - 2;
             const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
             pv[dy][dx] = ok ? P[(long long)yy * W + xx] : 0.f;
-            lv[dy][dx] = ok ? la_of(L[(long long)yy * W + xx], c, T) : 0.f;
+            lv[dy][dx] = ok ? lut[L[(long long)yy * W + xx]] : 0.f;
         }
     double acc = 0.0;
 #pragma unroll
@@ -522,7 +532,7 @@ extern "C" int sh_rmi_loss(const float* probs, const uint8_t* labels, const int*
     double* K1 = rmi + BC;
     double* K2 = K1 + (long long)BC * 81;
     rmi_gram_kernel<<<grid, 256, 0, st>>>(probs, labels, T, partials, H, W, C);
-    rmi_solve_kernel<<<(unsigned)sh_cdiv(BC, 64), 64, 0, st>>>(partials, parts, BC, rmi, K1, K2);
+    rmi_solve_kernel<<<(unsigned)BC, 192, 0, st>>>(partials, parts, BC, rmi, K1, K2);
     rmi_value_kernel<<<1, 64, 0, st>>>(rmi, N, C, rmi_out);
     if (dprob) {
         dim3 g2((unsigned)sh_cdiv(W, 64), (unsigned)sh_cdiv(H, 4), (unsigned)BC);

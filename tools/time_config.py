@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Step time + per-kernel breakdown of one of the BASELINE configs on the GPU (not the bench metric; a diagnosis aid).
+    python tools/time_config.py C4 [batch]      C2 | C4 (R101 3-level RMI, 7/3/2) | C5 (R101 2-level 20f/5c, 1024^2)"""
+import sys
+import time
+import torch
+sys.path.insert(0, ".")
+from seghiero_amd import ops
+from seghiero_amd.synthetic import make_batch
+from seghiero_amd.train_step import SegHieroTrainer
+
+CFGS = {
+    "C2": dict(depth=50, n_fine=9, coarse_to_fine_map=[[0, 3], [4, 6], [7], [8]], size=512, batch=16),
+    "C4": dict(depth=101, n_fine=7, coarse_to_fine_map=[[0], [1, 4], [5, 6]], super_coarse_to_coarse_map=[[0], [1, 6]], size=512, batch=16),
+    "C5": dict(depth=101, n_fine=20, coarse_to_fine_map=[[0, 3], [4, 7], [8, 11], [12, 15], [16, 19]], size=1024, batch=4),
+}
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "C4"
+    cfg = dict(CFGS[name])
+    size, batch = cfg.pop("size"), cfg.pop("batch")
+    if len(sys.argv) > 2:
+        batch = int(sys.argv[2])
+    torch.manual_seed(0)
+    tr = SegHieroTrainer(lr=0.01, device="cuda:0", **cfg)
+    tr.train()
+    img, lab = make_batch(batch, size, cfg["n_fine"], seed=0, device="cuda:0")
+    lab8 = ops.labels_u8(lab)
+    for _ in range(3):
+        tr.train_step(img, lab8, 0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        loss = tr.train_step(img, lab8, 0)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print(f"{name}: batch {batch} @ {size}^2: {dt * 1e3:.2f} ms/step = {batch / dt:.1f} images/s, loss {float(loss):.5f}, "
+          f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    with ops.profile() as prof:
+        tr.train_step(img, lab8, 0)
+    torch.cuda.synchronize()
+    for k, v in sorted(prof.rows.items(), key=lambda kv: -kv[1]["ms"])[:16]:
+        print(f"   {k:28s} {v['ms']:8.2f} ms  {v['calls']:5d} calls")
+
+
+if __name__ == "__main__":
+    main()
