@@ -367,36 +367,64 @@ __global__ __launch_bounds__(256) void rmi_dprob_kernel(const float* __restrict_
     if (threadIdx.x < 81) { k1[threadIdx.x] = K1[(long long)bc * 81 + threadIdx.x]; k2[threadIdx.x] = K2[(long long)bc * 81 + threadIdx.x]; }
     lut[threadIdx.x] = (threadIdx.x < T.nf || threadIdx.x == IGN) ? la_of((int)threadIdx.x, c, T) : 0.f;
     __syncthreads();
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= W || y >= H) return;
+    __shared__ double a1[25], a2[25];
+    if (threadIdx.x < 25) {
+        const int dy = (int)threadIdx.x / 5 - 2, dx = (int)threadIdx.x % 5 - 2;      // offset of the element from the pixel
+        double s1 = 0.0, s2 = 0.0;
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+                const int jy = dy + ky, jx = dx + kx;                                // element index inside window k
+                if (jy < 0 || jy > 2 || jx < 0 || jx > 2) continue;
+                s1 += k1[(ky * 3 + kx) * 9 + jy * 3 + jx]; s2 += k2[(ky * 3 + kx) * 9 + jy * 3 + jx];
+            }
+        a1[threadIdx.x] = s1; a2[threadIdx.x] = s2;
+    }
+    __syncthreads();
+    // the (64+4) x (4+4) neighbourhood of the block's pixels is staged once in LDS (2 loads per thread instead of 50)
+    __shared__ float tp[8][68], tl[8][68];
+    const int bx0 = blockIdx.x * 64 - 2, by0 = blockIdx.y * 4 - 2;
     const float* P = probs + (long long)bc * H * W;
     const uint8_t* L = labels + (long long)n * H * W;
+    for (int i = threadIdx.x; i < 8 * 68; i += 256) {
+        const int ry = i / 68, rx = i - ry * 68, yy = by0 + ry, xx = bx0 + rx;
+        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        tp[ry][rx] = ok ? P[(long long)yy * W + xx] : 0.f;
+        tl[ry][rx] = ok ? lut[L[(long long)yy * W + xx]] : 0.f;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lx, y = blockIdx.y * 4 + ly;
+    if (x >= W || y >= H) return;
     float pv[5][5], lv[5][5];
 #pragma unroll
     for (int dy = 0; dy < 5; ++dy)
 #pragma unroll
-        for (int dx = 0; dx < 5; ++dx) {
-            const int yy = y + dy - 2, xx = x + dx - 2;
-            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-            pv[dy][dx] = ok ? P[(long long)yy * W + xx] : 0.f;
-            lv[dy][dx] = ok ? lut[L[(long long)yy * W + xx]] : 0.f;
-        }
+        for (int dx = 0; dx < 5; ++dx) { pv[dy][dx] = tp[ly + dy][lx + dx]; lv[dy][dx] = tl[ly + dy][lx + dx]; }
     double acc = 0.0;
+    if (y >= 2 && x >= 2 && y < H - 2 && x < W - 2) {
+        // interior: all nine windows exist, so the double sum over (window k, element j) collapses to two 5x5 correlations
+        // with a1[d] = sum_{j-k=d} K1[k][j] (same for K2), built once per block
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+        for (int dy = 0; dy < 5; ++dy)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int wy = y - ky, wx = x - kx;            // window origin for which (y,x) is element (ky,kx)
-            if (wy < 0 || wx < 0 || wy >= H - 2 || wx >= W - 2) continue;
-            const int k = ky * 3 + kx;
+            for (int dx = 0; dx < 5; ++dx) acc += a1[dy * 5 + dx] * (double)lv[dy][dx] + a2[dy * 5 + dx] * (double)pv[dy][dx];
+    } else {
 #pragma unroll
-            for (int jy = 0; jy < 3; ++jy)
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int jx = 0; jx < 3; ++jx) {
-                    const int j = jy * 3 + jx;
-                    acc += k1[k * 9 + j] * (double)lv[2 - ky + jy][2 - kx + jx] + k2[k * 9 + j] * (double)pv[2 - ky + jy][2 - kx + jx];
-                }
-        }
+            for (int kx = 0; kx < 3; ++kx) {
+                const int wy = y - ky, wx = x - kx;            // window origin for which (y,x) is element (ky,kx)
+                if (wy < 0 || wx < 0 || wy >= H - 2 || wx >= W - 2) continue;
+                const int k = ky * 3 + kx;
+#pragma unroll
+                for (int jy = 0; jy < 3; ++jy)
+#pragma unroll
+                    for (int jx = 0; jx < 3; ++jx) {
+                        const int j = jy * 3 + jx;
+                        acc += k1[k * 9 + j] * (double)lv[2 - ky + jy][2 - kx + jx] + k2[k * 9 + j] * (double)pv[2 - ky + jy][2 - kx + jx];
+                    }
+            }
+    }
     dprob[((long long)bc * H + y) * W + x] = (float)acc;
 }
 

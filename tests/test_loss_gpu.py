@@ -231,3 +231,23 @@ def test_rmi_loss_fused_resize_matches_oracle(sa):
     r = zr.grad.numpy()
     np.testing.assert_allclose(zg.grad.cpu().numpy(), r, rtol=2e-3, atol=2e-3 * float(np.abs(r).max()))
     close(eg.grad, er.grad, 1e-4, 1e-8)
+
+
+def test_rmi_loss_wide_image_matches_oracle(sa):
+    """Several 64-column strips and 64-row chunks of Gram partials, and dprob blocks away from / at every border:
+    full-resolution logits (identity resize) at 140 x 200 against the oracle."""
+    _, loss, ops = sa
+    from oracle import losses as ol
+    g = torch.Generator().manual_seed(5)
+    z = 1.5 * torch.randn(1, 12, 140, 200, generator=g)
+    e = F.normalize(torch.randn(1, 16, 5, 7, generator=g), dim=1)
+    label = _blocky(g, 1, 140, 200, 7, cell=10)
+    zr, er = z.clone().requires_grad_(True), e.clone().requires_grad_(True)
+    ref = ol.RMIHieraTripletLoss(7, 3, 2, torch.tensor(F2M), torch.tensor(F2H))(torch.tensor([20000]), er, None, zr, label)
+    ref.backward()
+    zg, eg = z.to(DEV).requires_grad_(True), e.to(DEV).requires_grad_(True)
+    val = loss.RMIHieraTripletLoss(7, 3, 2, torch.tensor(F2M), torch.tensor(F2H)).to(DEV)(20000, eg, None, zg, label.to(DEV))
+    val.backward()
+    close(val, ref, 1e-5, 0)
+    r = zr.grad.numpy()
+    np.testing.assert_allclose(zg.grad.cpu().numpy(), r, rtol=2e-3, atol=2e-3 * float(np.abs(r).max()))
