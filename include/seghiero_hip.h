@@ -84,6 +84,10 @@ int sh_conv_fprop_x6(const float* x, int ldx, const float* w, const float* bias,
                      float* stat_partials, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                      int stride, int pad, int dil, float* workspace, int64_t workspace_bytes, void* stream);
 int sh_weight_transpose(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream);
+/* ... for n <= SH_WT_MAX weights in one launch (taps = KH*KW); the training step prepares all dgrad operands at once. */
+#define SH_WT_MAX 40
+int sh_weight_transpose_multi(int n, const float* const* w, float* const* wt, const int* cout, const int* taps,
+                              const int* cin, void* stream);
 int sh_conv_dgrad_x6(const float* dy, int lddy, const float* wt, const float* addend, int ldadd,
                      float* dx, int lddx, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                      int stride, int pad, int dil, int mode, float* workspace, int64_t workspace_bytes,

@@ -798,6 +798,46 @@ extern "C" int sh_weight_transpose(const float* w, float* wt, int Cout, int KH, 
     return sh_launch_status();
 }
 
+// The same for up to SH_WT_MAX weights in one launch (the step transposes all ~65 conv weights once, before backward).
+struct WtTab {
+    const float* w[SH_WT_MAX];
+    float* wt[SH_WT_MAX];
+    int cout[SH_WT_MAX], taps[SH_WT_MAX], cin[SH_WT_MAX];
+    long long start[SH_WT_MAX + 1];          // prefix sums of taps*cin*pad4(cout)
+    int n;
+};
+__global__ __launch_bounds__(256) void weight_transpose_multi_kernel(const WtTab T) {
+    const long long total = T.start[T.n];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        int lo = 0, hi = T.n - 1;                // binary search the owning tensor
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (T.start[mid] <= i) lo = mid; else hi = mid - 1; }
+        const long long e = i - T.start[lo];
+        const int Cout = T.cout[lo], Cin = T.cin[lo], CoutP = (Cout + 3) & ~3;
+        const int co = (int)(e % CoutP);
+        const long long q = e / CoutP;
+        const int ci = (int)(q % Cin), tap = (int)(q / Cin);
+        T.wt[lo][e] = co < Cout ? T.w[lo][((long long)co * T.taps[lo] + tap) * Cin + ci] : 0.f;
+    }
+}
+extern "C" int sh_weight_transpose_multi(int n, const float* const* w, float* const* wt, const int* cout, const int* taps, const int* cin,
+                                         void* stream) {
+    if (n <= 0 || n > SH_WT_MAX || !w || !wt || !cout || !taps || !cin) return SH_EINVAL;
+    WtTab T;
+    T.n = n;
+    long long acc = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!w[i] || !wt[i] || cout[i] <= 0 || taps[i] <= 0 || cin[i] <= 0) return SH_EINVAL;
+        T.w[i] = w[i]; T.wt[i] = wt[i]; T.cout[i] = cout[i]; T.taps[i] = taps[i]; T.cin[i] = cin[i];
+        T.start[i] = acc;
+        acc += (long long)taps[i] * cin[i] * ((cout[i] + 3) & ~3);
+    }
+    T.start[n] = acc;
+    long long g = sh_cdiv(acc, 256);
+    if (g > 8192) g = 8192;
+    weight_transpose_multi_kernel<<<(unsigned)g, 256, 0, (hipStream_t)stream>>>(T);
+    return sh_launch_status();
+}
+
 // Split-K reduce for fprop / dgrad: out[m][n] = sum_s slab[s][m][n] (+ bias[n] | + addend[m][n]); for fprop also the BN
 // statistics of the conv epilogue (centred (sum, M2) per 64 rows).  Block = 64 rows x 64 columns, thread = 4 rows x 4 columns.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, long long ldslab, int S, long long M, int Nn,

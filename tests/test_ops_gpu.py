@@ -316,3 +316,18 @@ def test_backbone_accepts_ingested_input(ops):
     # running stats were bumped once in each module from the same input: compare the features directly
     for u, v in zip(a, b):
         assert torch.equal(u, v)
+
+
+def test_weight_transpose_multi_matches_single(ops):
+    g = torch.Generator().manual_seed(9)
+    shapes = [(13, 16, 1, 1), (64, 32, 3, 3), (48, 256, 1, 1), (32, 8, 5, 5)] * 12      # 48 weights: two launches
+    ws = [wl(torch.randn(s, generator=g)) for s in shapes]
+    singles = [ops.weight_transpose(w) for w in ws]
+    ops.prepare_dgrad_weights(ws)
+    try:
+        for w, ref in zip(ws, singles):
+            got = ops.weight_transpose(w)
+            assert got.data_ptr() != ref.data_ptr() and torch.equal(got, ref)
+    finally:
+        ops.release_dgrad_weights()
+    assert ops.weight_transpose(ws[0]).data_ptr() not in [t.data_ptr() for _, t in ops._WT_CACHE.values()]
