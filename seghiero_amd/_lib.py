@@ -11,7 +11,7 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "seghiero_hip.h")
-LIBPATH = os.path.join(_HERE, "libseghiero_hip.so")
+LIBPATH = os.environ.get("SEGHIERO_LIB") or os.path.join(_HERE, "libseghiero_hip.so")      # SEGHIERO_LIB: kernel experiments
 
 _SCALARS = {
     "int": ctypes.c_int, "int64_t": ctypes.c_longlong, "long long": ctypes.c_longlong,

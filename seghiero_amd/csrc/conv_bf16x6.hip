@@ -960,7 +960,11 @@ static int launch_conv_x6(ConvQ& p, hipStream_t st) {
         // (measured: 12 waves of 192x256 instead: dgrad +8 % on 512->512 @128^2, fprop equal or worse -- not used)
         if (MODE == FPROP && x6_variant() == 7 && p.slab) return launch_x6<FPROP, 2, 2, 4, 4, 0, 0, 1>(p, st);      // instrumented
         // (measured: two 256x128 blocks per CU at 128 VGPRs are 20 % slower -- spills; three 128x128 blocks per CU: no change;
-        //  a persistent tile loop that requests the next tile's first K tile before the epilogue: slower main loop, more spills)
+        //  a persistent tile loop that requests the next tile's first K tile before the epilogue: slower main loop, more spills;
+        //  single-tap (1x1) and 32-bit-offset instantiations of this 128-VGPR kernel: no fewer in-loop scratch reloads, slower;
+        //  a 24-register fragment schedule (one A + one B triple live, five triple loads per K half): 4-7 % slower;
+        //  timing-only swap of each 32x32x16 MFMA for two 16x16x32: +21-26 % here but <= 5 % on the spill-free 128x128 kernel,
+        //  and a real 16x16 tiling needs twice the LDS fragment reads per flop -- not pursued)
         return launch_x6<MODE, 2, 2, 4, 4>(p, st);
     }
     if (N > 64 && sh_cdiv(M, 256) * sh_cdiv(N, 128) >= 512) return launch_x6<MODE, 2, 2, 4, 2>(p, st);
