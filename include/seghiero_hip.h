@@ -83,6 +83,12 @@ int64_t sh_conv_x6_workspace(int which /* 0 fprop, 1 dgrad */, int N, int H, int
 int sh_conv_fprop_x6(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
                      float* stat_partials, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                      int stride, int pad, int dil, float* workspace, int64_t workspace_bytes, void* stream);
+/* Inference forward with eval-mode BatchNorm (+ Bottleneck residual add) (+ ReLU) fused into the epilogue:
+ * out = [relu]( conv(x, w) * scale[co] + shift[co] [+ residual] ), scale / shift from sh_bn_eval_coefs.  Same operation
+ * order as sh_conv_fprop_x6 followed by sh_bn_act, so the result is bit-identical while y is never written or re-read. */
+int sh_conv_fprop_x6_act(const float* x, int ldx, const float* w, const float* scale, const float* shift,
+                         const float* residual, int ldr, int relu, float* out, int ldo, int N, int H, int W,
+                         int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, void* stream);
 int sh_weight_transpose(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream);
 /* ... for n <= SH_WT_MAX weights in one launch (taps = KH*KW); the training step prepares all dgrad operands at once. */
 #define SH_WT_MAX 40

@@ -32,6 +32,10 @@ struct ConvQ {
     int parity;             // dgrad of a stride-2 KxK conv: blockIdx.y = input-pixel parity class (only its taps are non-zero)
     int kchunk;
     int tiles_m, tiles_n, n_partials;
+    const float* act_scale; // ACT instantiations: per-output-channel scale / shift, optional residual (stride ldadd), ReLU flag
+    const float* act_shift;
+    const float* act_res;
+    int act_relu;
     int ksplit;             // fprop / dgrad split-K: blockIdx.y = K slice, raw accumulators go to slab[ksplit][M][ldslab]
     float* slab;
     long long ldslab;
@@ -89,7 +93,9 @@ __device__ __forceinline__ f32x16 mma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3
 // split to bf16 in registers on their way to LDS.
 // PROF: instrumented build for tools/bench_conv.py (SEGHIERO_X6_PROF=1): per-wave s_memtime totals of the main-loop phases
 // OCC: waves per SIMD the register budget is held to (0 = one resident block's worth, at least 2)
-template <int MODE, int TM, int TN, int WGM, int WGN, int OCC = 0, int SK = 0, int PROF = 0>      // SK: split-K instantiation (K slice = blockIdx.y)
+// ACT: inference epilogue out = [relu](acc * scale[n] + shift[n] [+ residual]) -- eval-mode BatchNorm (+ residual add + ReLU)
+//      fused into the convolution, in bn_act_kernel's own operation order (bit-identical to the unfused eval path)
+template <int MODE, int TM, int TN, int WGM, int WGN, int OCC = 0, int SK = 0, int PROF = 0, int ACT = 0>      // SK: split-K instantiation (K slice = blockIdx.y)
 __global__ __launch_bounds__(64 * WGM * WGN, OCC ? OCC : ((WGM * WGN) / 4 < 2 ? 2 : (WGM * WGN) / 4)) void conv_x6_kernel(const ConvQ p) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, BK = 32;
@@ -320,15 +326,21 @@ __global__ __launch_bounds__(64 * WGM * WGN, OCC ? OCC : ((WGM * WGN) / 4 < 2 ? 
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * 32 * TN + 32 * j + l31;
         const bool nok = n < p.Nn;
-        float bias = 0.f;
+        float bias = 0.f, a_sc = 1.f, a_sh = 0.f;
         if constexpr (MODE == FPROP) bias = (p.extra != nullptr && nok) ? p.extra[n] : 0.f;
+        if constexpr (ACT) { if (nok) { a_sc = p.act_scale[n]; a_sh = p.act_shift[n]; } }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 32 * TM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (m < Mc && nok) {
-                    if constexpr (MODE == FPROP) {
+                    if constexpr (MODE == FPROP && ACT) {
+                        float v = acc[i][j][r] * a_sc + a_sh;
+                        if (p.act_res != nullptr) v += p.act_res[(long long)m * p.ldadd + n];
+                        if (p.act_relu) v = fmaxf(v, 0.f);
+                        p.c[(long long)m * p.ldc + n] = v;
+                    } else if constexpr (MODE == FPROP) {
                         p.c[(long long)m * p.ldc + n] = acc[i][j][r] + bias;
                     } else {
                         float v = acc[i][j][r];
@@ -905,19 +917,19 @@ static int splitk_plan(long long M, long long N, long long K, int parity, int sc
     return S < 2 ? 1 : (int)S;
 }
 // ---------------------------------------------------------------------------------------- host side
-template <int MODE, int TM, int TN, int WGM, int WGN, int OCC = 0, int SK = 0, int PROF = 0>
+template <int MODE, int TM, int TN, int WGM, int WGN, int OCC = 0, int SK = 0, int PROF = 0, int ACT = 0>
 static int launch_x6(ConvQ& p, hipStream_t st) {
     constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
     constexpr size_t lds = 3 * (size_t)(BM + BN) * ROWB;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6_kernel<MODE, TM, TN, WGM, WGN, OCC, SK, PROF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6_kernel<MODE, TM, TN, WGM, WGN, OCC, SK, PROF, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     p.tiles_m = (int)sh_cdiv(p.M, BM);
     p.tiles_n = (int)sh_cdiv(p.Nn, BN);
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), p.parity ? 4u : (SK ? (unsigned)p.ksplit : 1u));
-    conv_x6_kernel<MODE, TM, TN, WGM, WGN, OCC, SK, PROF><<<grid, 64 * WGM * WGN, lds, st>>>(p);
+    conv_x6_kernel<MODE, TM, TN, WGM, WGN, OCC, SK, PROF, ACT><<<grid, 64 * WGM * WGN, lds, st>>>(p);
     if (SK) {
         dim3 rg((unsigned)sh_cdiv(p.M, 64), (unsigned)sh_cdiv(p.Nn, 64));
         splitk_reduce_kernel<<<rg, 256, 0, st>>>(p.slab, p.ldslab, p.ksplit, p.M, p.Nn, MODE == FPROP ? p.extra : nullptr,
@@ -981,6 +993,21 @@ static int launch_conv_x6(ConvQ& p, hipStream_t st) {
     if (TM == 1 && TN == 2) return launch_x6<MODE, 1, 2, 2, 2>(p, st);
     return launch_x6<MODE, 1, 1, 2, 2>(p, st);
 }
+// inference forward with the fused BN / residual / ReLU epilogue: the same tile rule on a reduced family (no split-K)
+static int launch_conv_x6_act(ConvQ& p, hipStream_t st) {
+    const long long M = p.M, N = p.Nn;
+    if (N > 128 && sh_cdiv(M, 256) * sh_cdiv(N, 256) >= 512) return launch_x6<FPROP, 2, 2, 4, 4, 0, 0, 0, 1>(p, st);
+    int TN = N <= 64 ? 1 : 2, TM = 2;
+    if (sh_cdiv(M, 128) * sh_cdiv(N, 64 * TN) < 512) {
+        TM = 1;
+        if (TN == 2 && sh_cdiv(M, 64) * sh_cdiv(N, 128) < 512) TN = 1;
+    }
+    if (M <= 64) TM = 1;
+    if (TM == 2 && TN == 2) return launch_x6<FPROP, 2, 2, 2, 2, 0, 0, 0, 1>(p, st);
+    if (TM == 2 && TN == 1) return launch_x6<FPROP, 2, 1, 2, 2, 0, 0, 0, 1>(p, st);
+    if (TM == 1 && TN == 2) return launch_x6<FPROP, 1, 2, 2, 2, 0, 0, 0, 1>(p, st);
+    return launch_x6<FPROP, 1, 1, 2, 2, 0, 0, 0, 1>(p, st);
+}
 static bool geom(ConvQ& p, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || dil <= 0 || pad < 0) return false;
     if (Cin % 4 != 0) return false;
@@ -1024,6 +1051,17 @@ extern "C" int sh_conv_fprop_x6(const float* x, int ldx, const float* w, const f
     p.n_partials = (int)sh_cdiv(p.M, 64);
     if ((ldy & 3) == 0 && ((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0)) use_splitk(p, workspace, workspace_bytes);
     return launch_conv_x6<FPROP>(p, (hipStream_t)stream);
+}
+extern "C" int sh_conv_fprop_x6_act(const float* x, int ldx, const float* w, const float* scale, const float* shift, const float* residual,
+                                    int ldr, int relu, float* out, int ldo, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                    int stride, int pad, int dil, void* stream) {
+    ConvQ p{};
+    if (!x || !w || !out || !scale || !shift || !geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil)) return SH_EINVAL;
+    if (ldx < Cin || ldo < Cout || (ldx & 3) || (residual && ldr < Cout)) return SH_EINVAL;
+    p.a = x; p.b = w; p.c = out; p.lda = ldx; p.ldc = ldo;
+    p.act_scale = scale; p.act_shift = shift; p.act_res = residual; p.ldadd = ldr; p.act_relu = relu;
+    p.M = N * p.Ho * p.Wo; p.Nn = Cout; p.K = KH * KW * Cin; p.Kc = Cin;
+    return launch_conv_x6_act(p, (hipStream_t)stream);
 }
 // wt = sh_weight_transpose(w): fp32 [KH*KW][Cin][pad4(Cout)]
 extern "C" int sh_conv_dgrad_x6(const float* dy, int lddy, const float* wt, const float* addend, int ldadd, float* dx, int lddx,

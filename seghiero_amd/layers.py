@@ -55,14 +55,22 @@ def cba_fwd(x, weight, geom, bn, relu, training, residual=None, out=None):
     o, _, kh, kw = weight.shape
     ho, wo = ops.conv_out_hw(h, w, kh, kw, s, p, d)
     ld = ops.pad4(o)
-    y = ops.new_act(n, o, ho, wo, x.device, ld=ld, zero=ld != o)
     m = n * ho * wo
-    partials = ops.conv_partials(m, o, x.device) if training else None
-    ops.conv_fprop(x, weight, None, y, partials, s, p, d)
-    coefs = _bn_coefs(bn, partials, m, training, o, x.device)
-    if out is None:
-        out = ops.new_act(n, o, ho, wo, x.device, ld=ld, zero=ld != o)
-    ops.bn_act(y, coefs, out, relu, residual)
+    if not training and ops.FUSE_EVAL and ops.CONV_IMPL == "x6":
+        # inference: eval-mode BN (+ residual) (+ ReLU) in the conv epilogue; y is never materialised
+        coefs = _bn_coefs(bn, None, m, False, o, x.device)
+        if out is None:
+            out = ops.new_act(n, o, ho, wo, x.device, ld=ld, zero=ld != o)
+        ops.conv_fprop_act(x, weight, coefs, out, relu, residual, s, p, d)
+        y = None
+    else:
+        y = ops.new_act(n, o, ho, wo, x.device, ld=ld, zero=ld != o)
+        partials = ops.conv_partials(m, o, x.device) if training else None
+        ops.conv_fprop(x, weight, None, y, partials, s, p, d)
+        coefs = _bn_coefs(bn, partials, m, training, o, x.device)
+        if out is None:
+            out = ops.new_act(n, o, ho, wo, x.device, ld=ld, zero=ld != o)
+        ops.bn_act(y, coefs, out, relu, residual)
     rec = CBARec()
     rec.x, rec.y, rec.out, rec.coefs, rec.relu, rec.geom, rec.weight = x, y, out, coefs, relu, geom, weight
     rec.has_res = residual is not None

@@ -165,6 +165,23 @@ def conv_fprop(x, weight, bias, y, partials, stride, pad, dil):
 SPLIT_K = os.environ.get("SEGHIERO_SPLITK", "1") != "0"      # debugging knob: 0 = never hand the conv kernels a split-K workspace
 
 
+FUSE_EVAL = os.environ.get("SEGHIERO_FUSE_EVAL", "1") != "0"      # inference: BN (+residual) (+ReLU) in the conv epilogue
+
+
+def conv_fprop_act(x, weight, coefs, out, relu, residual, stride, pad, dil):
+    """out = [relu](conv(x, weight) * scale + shift [+ residual]) in one kernel (eval-mode BN folded into the epilogue)."""
+    n, cin, h, w = x.shape
+    o, _, kh, kw = weight.shape
+    xp, ldx = pm(x)
+    op, ldo = pm(out)
+    rp, ldr = (None, 0) if residual is None else pm(residual)
+    ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
+    m = n * ho * wo
+    _call("sh_conv_fprop_x6_act", xp, ldx, w_ohwi(weight).data_ptr(), coefs[2].data_ptr(), coefs[3].data_ptr(), rp, ldr,
+          int(bool(relu)), op, ldo, n, h, w, cin, o, kh, kw, stride, pad, dil, _st(),
+          cost=(2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin + m * o + o * cin * kh * kw)))
+
+
 def _splitk_ws(which, n, h, w, cin, o, kh, kw, stride, pad, dil, mode, device):
     """(pointer, bytes) of the split-K slab workspace the x6 fprop / dgrad may use for this shape; (None, 0) = no split."""
     if not SPLIT_K:

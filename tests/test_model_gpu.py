@@ -291,3 +291,30 @@ def test_checkpoint_roundtrip_reference_format(sa, tmp_path):
     for p in ref_params:
         p.grad = torch.zeros_like(p)
     ref_opt.step()
+
+
+def test_eval_step_fused_bn_epilogue_is_bit_identical(sa):
+    """in eval mode BN (+ residual) (+ ReLU) runs in the conv epilogue (sh_conv_fprop_x6_act).  Same
+    operation order as conv -> bn_act, so with the split-K slices off (they change the summation order of a few convs) the
+    validation loss and the confusion counts are bit-identical to the unfused path; with them on, equal to 1e-5."""
+    from seghiero_amd import ops
+    from seghiero_amd.train_step import SegHieroTrainer
+    from seghiero_amd.synthetic import make_batch
+    torch.manual_seed(0)
+    tr = SegHieroTrainer(depth=50, n_fine=9, coarse_to_fine_map=[[0, 3], [4, 6], [7], [8]], lr=0.01, device=DEV)
+    img, lab = make_batch(2, 128, 9, seed=2, device=DEV)
+    tr.train_step(img, lab, 0)                       # move the running statistics off their initial values
+    tr.eval()
+    keep = (ops.FUSE_EVAL, ops.SPLIT_K)
+    try:
+        ops.FUSE_EVAL, ops.SPLIT_K = False, False
+        l0, c0 = tr.eval_step(img, lab, 0)
+        ops.FUSE_EVAL = True
+        l1, c1 = tr.eval_step(img, lab, 0)
+        ops.FUSE_EVAL, ops.SPLIT_K = False, True
+        l2, c2 = tr.eval_step(img, lab, 0)
+    finally:
+        ops.FUSE_EVAL, ops.SPLIT_K = keep
+    assert float(l0) == float(l1) and torch.equal(c0, c1)
+    assert abs(float(l2) - float(l1)) <= 1e-5 * abs(float(l1))
+    assert int(c1[1]) > 0
