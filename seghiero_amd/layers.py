@@ -86,7 +86,7 @@ def cba_bwd(rec, bn, dout, need_dx=True, addend=None, want_dres=False, scatter_i
     dy, dgamma, dbeta, dres = ops.bn_backward(dout, rec.out if mode == 1 else None, rec.y, rec.coefs, bn.weight,
                                               mode, want_dres)
     dw = torch.empty_like(rec.weight)
-    ops.conv_wgrad(rec.x, dy, dw, s, p, d)
+    ops.conv_wgrad(rec.x, dy, dw, s, p, d, side=True)
     dx = None
     if scatter_into is not None:
         ops.conv_dgrad(dy, rec.weight, scatter_into, s, p, d, mode=1)
@@ -120,7 +120,7 @@ def dw_bwd(rec, bn, dout, dx_accumulate_into=None):
     """-> (dx, dweight, dgamma, dbeta); with dx_accumulate_into the input gradient is added into that tensor."""
     dy, dgamma, dbeta, _ = ops.bn_backward(dout, None, rec.y, rec.coefs, bn.weight, 2)
     dw = torch.empty_like(rec.weight)
-    ops.dwconv_wgrad(rec.x, dy, dw, rec.dil)
+    ops.dwconv_wgrad(rec.x, dy, dw, rec.dil, side=True)
     if dx_accumulate_into is not None:
         ops.dwconv_dgrad(dy, rec.weight, dx_accumulate_into, rec.dil, accumulate=True)
         dx = dx_accumulate_into
@@ -147,7 +147,7 @@ def conv_bwd(x, weight, geom, dy, need_dx=True, addend=None):
     """dy must be NHWC with its padding lanes zeroed.  -> (dx, dweight)."""
     s, p, d = geom
     dw = torch.empty_like(weight)
-    ops.conv_wgrad(x, dy, dw, s, p, d)
+    ops.conv_wgrad(x, dy, dw, s, p, d, side=True)
     dx = None
     if need_dx:
         n, c, h, w = x.shape
@@ -177,12 +177,18 @@ class GradMap:
         if grad.shape != param.shape:
             grad = grad.reshape(param.shape)
         key = id(param)
-        self.g[key] = grad if key not in self.g else self.g[key] + grad
+        if key in self.g:
+            ops.join_wgrad()             # accumulating on the compute stream: the addends may come from the wgrad stream
+            grad = self.g[key] + grad
+        self.g[key] = grad
 
     def ordered(self, params):
+        ops.join_wgrad()                 # weight gradients run on a side stream (ops.conv_wgrad); order them before the consumers
         return tuple(self.g.get(id(p)) for p in params)
 
     def flush(self, params):
         """Hand the (final) gradients of `params` to the data-parallel exchange while backward continues (ddp.GradSync)."""
         from . import ddp
-        ddp.early_flush([(p, self.g.get(id(p))) for p in params])
+        if ddp._ACTIVE is not None:
+            ops.join_wgrad()
+            ddp.early_flush([(p, self.g.get(id(p))) for p in params])

@@ -271,7 +271,33 @@ def workspace(nbytes, device, tag="ws"):
     return buf
 
 
-def conv_wgrad(x, dy, dweight, stride, pad, dil):
+# Weight gradients run on a side HIP stream: dgrad (the critical path of backward) and the wgrad of the same layer only share
+# read-only inputs, so the two kernels can co-reside on a CU (98 KB + 61 KB of LDS) and fill each other's load / split /
+# epilogue phases and grid tails.  Every hand-scheduled backward node joins the side stream before it returns its gradients
+# (layers.GradMap.ordered / flush), so consumers of p.grad are ordered after the wgrads without knowing about the stream.
+WGRAD_ASYNC = os.environ.get("SEGHIERO_WGRAD_STREAM", "1") != "0"
+_WG_STREAMS = {}          # device index -> [stream, pending]
+
+
+def _wgrad_side(device):
+    ent = _WG_STREAMS.get(device.index)
+    if ent is None:
+        ent = [torch.cuda.Stream(device=device), False]
+        _WG_STREAMS[device.index] = ent
+    return ent
+
+
+def join_wgrad():
+    """Make the current stream wait for every weight gradient launched on the side stream so far."""
+    for idx, ent in _WG_STREAMS.items():
+        if ent[1]:
+            torch.cuda.current_stream(idx).wait_stream(ent[0])
+            ent[1] = False
+
+
+def conv_wgrad(x, dy, dweight, stride, pad, dil, side=False):
+    """dweight <- grad_weight.  side=True (the backward nodes): launched on the weight-gradient stream; the caller must
+    run join_wgrad() before anything consumes dweight."""
     n, cin, h, w = x.shape
     o, _, kh, kw = dweight.shape
     # tiny output-channel counts (cls_seg, aux head) stay on the f32-MFMA kernel
@@ -279,14 +305,28 @@ def conv_wgrad(x, dy, dweight, stride, pad, dil):
     need = LIB.raw("sh_conv_wgrad_x6_workspace" if x6 else "sh_conv_wgrad_workspace")(n, h, w, cin, o, kh, kw, stride, pad, dil)
     if need < 0:
         raise SegHieroHipError("sh_conv_wgrad_workspace rejected the geometry")
-    ws = workspace(need, x.device, "wgrad")
     xp, ldx = pm(x)
     dyp, lddy = pm(dy)
     ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
     m = n * ho * wo
-    _call("sh_conv_wgrad_x6" if x6 else "sh_conv_wgrad", xp, ldx, dyp, lddy, dweight.data_ptr(), ws.data_ptr(), n, h, w, cin, o, kh, kw,
-          stride, pad, dil, _st(),
-          cost=(2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin + m * o + o * cin * kh * kw)))
+    cost = (2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin + m * o + o * cin * kh * kw))
+    name = "sh_conv_wgrad_x6" if x6 else "sh_conv_wgrad"
+
+    def launch():
+        ws = workspace(need, x.device, "wgrad")          # only ever touched by wgrad kernels, which stay in one stream's order
+        _call(name, xp, ldx, dyp, lddy, dweight.data_ptr(), ws.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, _st(), cost=cost)
+
+    if not (side and WGRAD_ASYNC and x.is_cuda):
+        launch()
+        return
+    ent = _wgrad_side(x.device)
+    side = ent[0]
+    side.wait_stream(torch.cuda.current_stream(x.device))   # dy / x were produced on the compute stream
+    with torch.cuda.stream(side):
+        launch()
+    for t in (x, dy, dweight):
+        t.record_stream(side)                               # the allocator must not recycle them under the side stream
+    ent[1] = True
 
 
 def conv_partials(m, cout, device):
@@ -313,13 +353,27 @@ def dwconv_dgrad(dy, weight, dx, dil, accumulate=False):
     _call("sh_dwconv_dgrad", dyp, lddy, weight.data_ptr(), dxp, lddx, n, h, w, c, dil, int(accumulate), _st())
 
 
-def dwconv_wgrad(x, dy, dweight, dil):
+def dwconv_wgrad(x, dy, dweight, dil, side=False):
+    """side=True: on the weight-gradient stream (see conv_wgrad); join_wgrad() before dweight is consumed."""
     n, c, h, w = x.shape
     p = dw_partials_rows(n, h, w)
-    ws = workspace(p * 9 * c * 4, x.device, "dwwgrad")
     xp, ldx = pm(x)
     dyp, lddy = pm(dy)
-    _call("sh_dwconv_wgrad", xp, ldx, dyp, lddy, ws.data_ptr(), dweight.data_ptr(), n, h, w, c, dil, _st())
+
+    def launch():
+        ws = workspace(p * 9 * c * 4, x.device, "dwwgrad")
+        _call("sh_dwconv_wgrad", xp, ldx, dyp, lddy, ws.data_ptr(), dweight.data_ptr(), n, h, w, c, dil, _st())
+
+    if not (side and WGRAD_ASYNC and x.is_cuda):
+        launch()
+        return
+    ent = _wgrad_side(x.device)
+    ent[0].wait_stream(torch.cuda.current_stream(x.device))
+    with torch.cuda.stream(ent[0]):
+        launch()
+    for t in (x, dy, dweight):
+        t.record_stream(ent[0])
+    ent[1] = True
 
 
 # ----------------------------------------------------------------------------- batch norm
