@@ -33,15 +33,19 @@ def _call(name, *args, cost=None):
 class profile:
     """Context manager: per-kernel-family device time measured with HIP events recorded on the launch stream
     (torch's current stream), plus the algorithmic flops / bytes the callers declare.  Used by bench.py for the
-    roofline line; adds event overhead, so never wrap the timed region with it."""
+    roofline line; adds event overhead, so never wrap the timed region with it.  The weight-gradient side stream is switched
+    off inside the context: kernels that co-run share the CUs, which would inflate every per-kernel duration."""
 
     def __enter__(self):
-        global _PROF
+        global _PROF, WGRAD_ASYNC
         _PROF = []
+        self._async = WGRAD_ASYNC
+        WGRAD_ASYNC = False
         return self
 
     def __exit__(self, *exc):
-        global _PROF
+        global _PROF, WGRAD_ASYNC
+        WGRAD_ASYNC = self._async
         rec, _PROF = _PROF, None
         torch.cuda.synchronize()
         self.rows = {}
@@ -276,23 +280,38 @@ def workspace(nbytes, device, tag="ws"):
 # epilogue phases and grid tails.  Every hand-scheduled backward node joins the side stream before it returns its gradients
 # (layers.GradMap.ordered / flush), so consumers of p.grad are ordered after the wgrads without knowing about the stream.
 WGRAD_ASYNC = os.environ.get("SEGHIERO_WGRAD_STREAM", "1") != "0"
-_WG_STREAMS = {}          # device index -> [stream, pending]
+WGRAD_NSTREAMS = int(os.environ.get("SEGHIERO_WGRAD_NSTREAMS", "1"))
+_WG_STREAMS = {}          # device index -> [[streams], [pending flags], next]
+
+
+class _WgEnt:
+    def __init__(self, device):
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(max(1, WGRAD_NSTREAMS))]
+        self.pending = [False] * len(self.streams)
+        self.next = 0
+
+    def take(self):
+        k = self.next
+        self.next = (k + 1) % len(self.streams)
+        self.pending[k] = True
+        return k, self.streams[k]
 
 
 def _wgrad_side(device):
     ent = _WG_STREAMS.get(device.index)
     if ent is None:
-        ent = [torch.cuda.Stream(device=device), False]
+        ent = _WgEnt(device)
         _WG_STREAMS[device.index] = ent
     return ent
 
 
 def join_wgrad():
-    """Make the current stream wait for every weight gradient launched on the side stream so far."""
+    """Make the current stream wait for every weight gradient launched on the side stream(s) so far."""
     for idx, ent in _WG_STREAMS.items():
-        if ent[1]:
-            torch.cuda.current_stream(idx).wait_stream(ent[0])
-            ent[1] = False
+        for k, st in enumerate(ent.streams):
+            if ent.pending[k]:
+                torch.cuda.current_stream(idx).wait_stream(st)
+                ent.pending[k] = False
 
 
 def conv_wgrad(x, dy, dweight, stride, pad, dil, side=False):
@@ -312,21 +331,19 @@ def conv_wgrad(x, dy, dweight, stride, pad, dil, side=False):
     cost = (2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin + m * o + o * cin * kh * kw))
     name = "sh_conv_wgrad_x6" if x6 else "sh_conv_wgrad"
 
-    def launch():
-        ws = workspace(need, x.device, "wgrad")          # only ever touched by wgrad kernels, which stay in one stream's order
+    def launch(tag="wgrad"):
+        ws = workspace(need, x.device, tag)              # one workspace per stream: its kernels stay in that stream's order
         _call(name, xp, ldx, dyp, lddy, dweight.data_ptr(), ws.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, _st(), cost=cost)
 
     if not (side and WGRAD_ASYNC and x.is_cuda):
         launch()
         return
-    ent = _wgrad_side(x.device)
-    side = ent[0]
-    side.wait_stream(torch.cuda.current_stream(x.device))   # dy / x were produced on the compute stream
-    with torch.cuda.stream(side):
-        launch()
+    k, st = _wgrad_side(x.device).take()
+    st.wait_stream(torch.cuda.current_stream(x.device))     # dy / x were produced on the compute stream
+    with torch.cuda.stream(st):
+        launch("wgrad%d" % k)
     for t in (x, dy, dweight):
-        t.record_stream(side)                               # the allocator must not recycle them under the side stream
-    ent[1] = True
+        t.record_stream(st)                                 # the allocator must not recycle them under the side stream
 
 
 def conv_partials(m, cout, device):
@@ -360,20 +377,19 @@ def dwconv_wgrad(x, dy, dweight, dil, side=False):
     xp, ldx = pm(x)
     dyp, lddy = pm(dy)
 
-    def launch():
-        ws = workspace(p * 9 * c * 4, x.device, "dwwgrad")
+    def launch(tag="dwwgrad"):
+        ws = workspace(p * 9 * c * 4, x.device, tag)
         _call("sh_dwconv_wgrad", xp, ldx, dyp, lddy, ws.data_ptr(), dweight.data_ptr(), n, h, w, c, dil, _st())
 
     if not (side and WGRAD_ASYNC and x.is_cuda):
         launch()
         return
-    ent = _wgrad_side(x.device)
-    ent[0].wait_stream(torch.cuda.current_stream(x.device))
-    with torch.cuda.stream(ent[0]):
-        launch()
+    k, st = _wgrad_side(x.device).take()
+    st.wait_stream(torch.cuda.current_stream(x.device))
+    with torch.cuda.stream(st):
+        launch("dwwgrad%d" % k)
     for t in (x, dy, dweight):
-        t.record_stream(ent[0])
-    ent[1] = True
+        t.record_stream(st)
 
 
 # ----------------------------------------------------------------------------- batch norm

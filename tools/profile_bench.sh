@@ -3,6 +3,9 @@
 #  pass 1: rocprofv3 --kernel-trace --stats          -> per-kernel time
 #  pass 2/3: --pmc FETCH_SIZE / --pmc WRITE_SIZE      -> HBM-side bytes per dispatch (separate passes: TCC has 4 slots)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+# per-kernel durations and counters are taken with the weight-gradient side stream off (co-running kernels share the CUs and
+# inflate each other's durations); bench.py's own instrumented step does the same.  Throughput is reported with it on.
+export SEGHIERO_WGRAD_STREAM=0
 TAG=${1:-r01}; OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline > $OUT/trace.log 2>&1
