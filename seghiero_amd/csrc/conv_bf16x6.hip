@@ -8,7 +8,7 @@
 // at fp32-class accuracy (validated by the same parity tests as the f32 kernels, tests/test_ops_gpu.py).
 //
 // Structure: same implicit-GEMM tiling / loaders / epilogues as conv_gemm.hip.  Global fp32 -> registers -> split ->
-// three bf16 LDS planes per operand ([row][32 k] with 80-byte rows: conflict-free 16-byte fragment reads).  FPROP and
+// three bf16 LDS planes per operand ([row][32 k], 64-byte rows with an XOR-swizzled 16-byte chunk: conflict-free reads).  FPROP and
 // DGRAD have K-contiguous operands (DGRAD reads a per-step transposed weight copy [tap][ci][co]); WGRAD's operands are
 // pixel-major, so its planes are stored [k][m] and the fragments are read with ds_read_b64_tr_b16 (hardware transpose).
 #include "common.h"

@@ -196,14 +196,13 @@ def _splitk_ws(which, n, h, w, cin, o, kh, kw, stride, pad, dil, mode, device):
     return workspace(need, device, "splitk").data_ptr(), need
 
 
-_WT_CACHE = {}            # id(weight) -> (weight, transposed copy); buffers persist across steps
-_WT_VALID = False         # True only between prepare_dgrad_weights() and release_dgrad_weights() of one training step
+_WT_ACTIVE = None         # {id(weight): (weight, transposed copy)} of the training step in flight, else None
 
 
 def weight_transpose(weight):
     """[O,I,KH,KW] (OHWI memory) -> [KH*KW, I, pad4(O)] buffer: the K-contiguous B operand of the x6 dgrad."""
-    if _WT_VALID:
-        hit = _WT_CACHE.get(id(weight))
+    if _WT_ACTIVE is not None:
+        hit = _WT_ACTIVE.get(id(weight))
         if hit is not None and hit[0] is weight:
             return hit[1]
     o, i, kh, kw = weight.shape
@@ -212,18 +211,19 @@ def weight_transpose(weight):
     return wt
 
 
-def prepare_dgrad_weights(weights):
+def prepare_dgrad_weights(weights, cache):
     """Transpose all of `weights` (the dense conv weights a backward pass will run dgrad on) in a few launches instead of one
-    per layer.  The copies are handed out by weight_transpose() until release_dgrad_weights(); the caller guarantees that
-    the weights do not change in between (the training step: prepare -> forward -> backward -> release -> SGD)."""
-    global _WT_VALID
+    per layer.  `cache` is a dict owned by the caller (the trainer) that keeps the buffers across steps.  The copies are
+    handed out by weight_transpose() until release_dgrad_weights(); the caller guarantees that the weights do not change in
+    between (the training step: prepare -> forward -> backward -> release -> SGD)."""
+    global _WT_ACTIVE
     todo = []
     for w in weights:
-        hit = _WT_CACHE.get(id(w))
+        hit = cache.get(id(w))
         if hit is None or hit[0] is not w or hit[1].device != w.device:
             o, i, kh, kw = w.shape
             hit = (w, torch.empty((kh * kw, i, pad4(o)), device=w.device, dtype=torch.float32))
-            _WT_CACHE[id(w)] = hit
+            cache[id(w)] = hit
         todo.append(hit)
     cap = 40                                                   # SH_WT_MAX
     for a in range(0, len(todo), cap):
@@ -235,12 +235,12 @@ def prepare_dgrad_weights(weights):
         tp = (ctypes.c_int * k)(*[w.shape[2] * w.shape[3] for w, _ in chunk])
         ci = (ctypes.c_int * k)(*[w.shape[1] for w, _ in chunk])
         _call("sh_weight_transpose_multi", k, wa, ta, co, tp, ci, _st())
-    _WT_VALID = True
+    _WT_ACTIVE = cache
 
 
 def release_dgrad_weights():
-    global _WT_VALID
-    _WT_VALID = False
+    global _WT_ACTIVE
+    _WT_ACTIVE = None
 
 
 def conv_dgrad(dy, weight, dx, stride, pad, dil, addend=None, mode=0):

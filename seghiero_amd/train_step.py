@@ -72,6 +72,7 @@ class SegHieroTrainer:
             m.to(self.device)
         self.params = list(self.backbone.parameters()) + list(self.aspp_head.parameters()) + list(self.aux_head.parameters())
         # dense conv weights whose backward runs a dgrad (everything but the depthwise convs and the stem)
+        self._wt_cache = {}
         self._dgrad_weights = [m.weight for mod in (self.backbone, self.aspp_head, self.aux_head) for m in mod.modules()
                                if isinstance(m, nn.Conv2d) and m.groups == 1 and m is not self.backbone.stem_conv]
         self.optimizer = FusedSGD(self.params, lr=lr, momentum=0.9, weight_decay=1e-4)
@@ -126,7 +127,7 @@ class SegHieroTrainer:
         """One iteration of train.py:260-320.  Returns the (device) loss scalar; nothing is synchronised."""
         self.optimizer.zero_grad(set_to_none=True)
         if ops.CONV_IMPL == "x6":
-            ops.prepare_dgrad_weights(self._dgrad_weights)   # all dgrad operands in 2 launches; valid until the SGD step
+            ops.prepare_dgrad_weights(self._dgrad_weights, self._wt_cache)   # all dgrad operands in 2 launches; valid until SGD
         try:
             loss, _, _, _ = self.forward_loss(img, fine_mask, epoch)
             if self.grad_sync is not None:

@@ -323,11 +323,12 @@ def test_weight_transpose_multi_matches_single(ops):
     shapes = [(13, 16, 1, 1), (64, 32, 3, 3), (48, 256, 1, 1), (32, 8, 5, 5)] * 12      # 48 weights: two launches
     ws = [wl(torch.randn(s, generator=g)) for s in shapes]
     singles = [ops.weight_transpose(w) for w in ws]
-    ops.prepare_dgrad_weights(ws)
+    cache = {}
+    ops.prepare_dgrad_weights(ws, cache)
     try:
         for w, ref in zip(ws, singles):
             got = ops.weight_transpose(w)
             assert got.data_ptr() != ref.data_ptr() and torch.equal(got, ref)
     finally:
         ops.release_dgrad_weights()
-    assert ops.weight_transpose(ws[0]).data_ptr() not in [t.data_ptr() for _, t in ops._WT_CACHE.values()]
+    assert ops.weight_transpose(ws[0]).data_ptr() not in [t.data_ptr() for _, t in cache.values()]
