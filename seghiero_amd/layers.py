@@ -86,7 +86,8 @@ def cba_bwd(rec, bn, dout, need_dx=True, addend=None, want_dres=False, scatter_i
     dy, dgamma, dbeta, dres = ops.bn_backward(dout, rec.out if mode == 1 else None, rec.y, rec.coefs, bn.weight,
                                               mode, want_dres)
     dw = torch.empty_like(rec.weight)
-    ops.conv_wgrad(rec.x, dy, dw, s, p, d, side=True)
+    if not ops.WGRAD_AFTER_DGRAD:
+        ops.conv_wgrad(rec.x, dy, dw, s, p, d, side=True)
     dx = None
     if scatter_into is not None:
         ops.conv_dgrad(dy, rec.weight, scatter_into, s, p, d, mode=1)
@@ -95,6 +96,10 @@ def cba_bwd(rec, bn, dout, need_dx=True, addend=None, want_dres=False, scatter_i
         n, c, h, w = rec.x.shape
         dx = ops.new_act(n, c, h, w, rec.x.device)
         ops.conv_dgrad(dy, rec.weight, dx, s, p, d, addend=addend)
+    if ops.WGRAD_AFTER_DGRAD:
+        # enqueued after the dgrad: the side stream then starts this (MFMA-bound) wgrad when the dgrad has finished, i.e.
+        # next to the HBM-bound BatchNorm backward of the previous layer instead of next to another MFMA-bound kernel
+        ops.conv_wgrad(rec.x, dy, dw, s, p, d, side=True)
     return dx, dw, dgamma, dbeta, dres
 
 

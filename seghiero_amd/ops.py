@@ -281,6 +281,7 @@ def workspace(nbytes, device, tag="ws"):
 # (layers.GradMap.ordered / flush), so consumers of p.grad are ordered after the wgrads without knowing about the stream.
 WGRAD_ASYNC = os.environ.get("SEGHIERO_WGRAD_STREAM", "1") != "0"
 WGRAD_NSTREAMS = int(os.environ.get("SEGHIERO_WGRAD_NSTREAMS", "1"))
+WGRAD_AFTER_DGRAD = os.environ.get("SEGHIERO_WGRAD_AFTER_DGRAD", "1") != "0"
 _WG_STREAMS = {}          # device index -> [[streams], [pending flags], next]
 
 
