@@ -1097,6 +1097,7 @@ static WgX6Plan wgrad_plan_x6(int Cout, long long Nn, long long npix) {
     // measured (tools/bench_conv.py): 128x256 helps the narrow-Cout shapes, 256x256 on 1024 threads does not help wgrad
     g.wgm = Cout <= 64 ? 1 : 2;
     g.wgn = (Nn >= 256 && Cout <= 128) ? 4 : 2;
+    if (Nn <= 64 && Cout >= 128) { g.wgn = 1; g.wgm = Cout >= 256 ? 4 : 2; }      // layer1's 64-channel inputs: 64-wide N tile
     const long long tiles = sh_cdiv(Cout, 64 * g.wgm) * sh_cdiv(Nn, 64 * g.wgn);
     // K slices: the grid should be a whole number of "rounds" of 512 resident blocks (2 per CU) -- measured
     // (tools/wg_target_sweep.sh): 640 blocks cost as much as 1024, e.g. 512->512 @128^2: 1143 us at 640 vs 878 us at 512 --
@@ -1166,7 +1167,9 @@ extern "C" int sh_conv_wgrad_x6(const float* x, int ldx, const float* dy, int ld
     p.scatter = g.per_xcd;              // (field reused) block -> (slice, tile) mapping, see the kernel
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (g.wgm == 2 && g.wgn == 4) rc = launch_wgrad_x6<2, 4>(p, g.splits, st);
+    if (g.wgm == 4 && g.wgn == 1) rc = launch_wgrad_x6<4, 1>(p, g.splits, st);
+    else if (g.wgm == 2 && g.wgn == 1) rc = launch_wgrad_x6<2, 1>(p, g.splits, st);
+    else if (g.wgm == 2 && g.wgn == 4) rc = launch_wgrad_x6<2, 4>(p, g.splits, st);
     else if (g.wgm == 1 && g.wgn == 4) rc = launch_wgrad_x6<1, 4>(p, g.splits, st);
     else if (g.wgm == 1 && g.wgn == 2) rc = launch_wgrad_x6<1, 2>(p, g.splits, st);
     else rc = launch_wgrad_x6<2, 2>(p, g.splits, st);

@@ -321,7 +321,7 @@ def conv_wgrad(x, dy, dweight, stride, pad, dil, side=False):
     n, cin, h, w = x.shape
     o, _, kh, kw = dweight.shape
     # tiny output-channel counts (cls_seg, aux head) stay on the f32-MFMA kernel
-    x6 = CONV_IMPL == "x6" and o >= 32 and cin * kh * kw >= 128
+    x6 = CONV_IMPL == "x6" and o >= 32 and (cin * kh * kw >= 128 or (cin * kh * kw == 64 and o >= 128))
     need = LIB.raw("sh_conv_wgrad_x6_workspace" if x6 else "sh_conv_wgrad_workspace")(n, h, w, cin, o, kh, kw, stride, pad, dil)
     if need < 0:
         raise SegHieroHipError("sh_conv_wgrad_workspace rejected the geometry")
