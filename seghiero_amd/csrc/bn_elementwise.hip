@@ -30,8 +30,25 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
         y[i] = x[(n * HW + hw) * Cpad + c];
     }
 }
+// the image path (C <= 4 -> Cpad = 4): one thread per pixel, C coalesced plane reads, one 16-byte store
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ x, float* __restrict__ y, int C, long long HW,
+                                                            long long npix) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+        const long long n = i / HW, hw = i - n * HW;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const float* src = x + n * C * HW + hw;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < C) v[c] = src[(long long)c * HW];
+        st4(y + i * 4, v);
+    }
+}
 extern "C" int sh_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int Cpad, void* stream) {
     if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || Cpad < C) return SH_EINVAL;
+    if (Cpad == 4 && ((uintptr_t)y & 15) == 0) {
+        const long long npix = (long long)N * H * W;
+        nchw_to_nhwc4_kernel<<<grid_for(npix), 256, 0, (hipStream_t)stream>>>(x, y, C, (long long)H * W, npix);
+        return sh_launch_status();
+    }
     const long long total = (long long)N * H * W * Cpad;
     nchw_to_nhwc_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>(x, y, C, (long long)H * W, Cpad, total);
     return sh_launch_status();
@@ -50,6 +67,10 @@ __global__ __launch_bounds__(256) void fill_kernel(float* p, float v, long long 
 __global__ __launch_bounds__(256) void axpy_kernel(float* y, const float* x, float a, long long n) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] += a * x[i];
 }
+__global__ __launch_bounds__(256) void axpy4_kernel(float* y, const float* x, float a, long long n4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
+        st4(y + i * 4, ld4(y + i * 4) + a * ld4(x + i * 4));
+}
 extern "C" int sh_fill(float* p, float v, int64_t n, void* stream) {
     if (!p || n < 0) return SH_EINVAL;
     if (n == 0) return SH_OK;
@@ -59,7 +80,8 @@ extern "C" int sh_fill(float* p, float v, int64_t n, void* stream) {
 extern "C" int sh_axpy(float* y, const float* x, float a, int64_t n, void* stream) {
     if (!y || !x || n < 0) return SH_EINVAL;
     if (n == 0) return SH_OK;
-    axpy_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(y, x, a, n);
+    if ((n & 3) == 0 && (((uintptr_t)y | (uintptr_t)x) & 15) == 0) axpy4_kernel<<<grid_for(n / 4), 256, 0, (hipStream_t)stream>>>(y, x, a, n / 4);
+    else axpy_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(y, x, a, n);
     return sh_launch_status();
 }
 

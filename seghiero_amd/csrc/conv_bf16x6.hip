@@ -815,20 +815,35 @@ struct WtTab {
     const float* w[SH_WT_MAX];
     float* wt[SH_WT_MAX];
     int cout[SH_WT_MAX], taps[SH_WT_MAX], cin[SH_WT_MAX];
-    long long start[SH_WT_MAX + 1];          // prefix sums of taps*cin*pad4(cout)
+    long long start[SH_WT_MAX + 1];          // prefix sums of the 32x32 tile counts
     int n;
 };
+// one block = one 32 (co) x 32 (ci) tile of one tap of one weight, staged through LDS so that both the reads (ci fastest)
+// and the writes (co fastest) are coalesced; T.start[] counts tiles
 __global__ __launch_bounds__(256) void weight_transpose_multi_kernel(const WtTab T) {
-    const long long total = T.start[T.n];
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        int lo = 0, hi = T.n - 1;                // binary search the owning tensor
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (T.start[mid] <= i) lo = mid; else hi = mid - 1; }
-        const long long e = i - T.start[lo];
-        const int Cout = T.cout[lo], Cin = T.cin[lo], CoutP = (Cout + 3) & ~3;
-        const int co = (int)(e % CoutP);
-        const long long q = e / CoutP;
-        const int ci = (int)(q % Cin), tap = (int)(q / Cin);
-        T.wt[lo][e] = co < Cout ? T.w[lo][((long long)co * T.taps[lo] + tap) * Cin + ci] : 0.f;
+    __shared__ float tile[32][33];
+    const long long b = blockIdx.x;
+    int lo = 0, hi = T.n - 1;                // binary search the owning tensor
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (T.start[mid] <= b) lo = mid; else hi = mid - 1; }
+    const int Cout = T.cout[lo], Cin = T.cin[lo], taps = T.taps[lo], CoutP = (Cout + 3) & ~3;
+    const int tco = (CoutP + 31) / 32, tci = (Cin + 31) / 32;
+    long long e = b - T.start[lo];
+    const int ci0 = (int)(e % tci) * 32; e /= tci;
+    const int co0 = (int)(e % tco) * 32;
+    const int tap = (int)(e / tco);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* w = T.w[lo];
+    float* wt = T.wt[lo];
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        tile[r][tx] = (co < Cout && ci < Cin) ? w[((long long)co * taps + tap) * Cin + ci] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        if (ci < Cin && co < CoutP) wt[((long long)tap * Cin + ci) * CoutP + co] = tile[tx][r];
     }
 }
 extern "C" int sh_weight_transpose_multi(int n, const float* const* w, float* const* wt, const int* cout, const int* taps, const int* cin,
@@ -841,12 +856,11 @@ extern "C" int sh_weight_transpose_multi(int n, const float* const* w, float* co
         if (!w[i] || !wt[i] || cout[i] <= 0 || taps[i] <= 0 || cin[i] <= 0) return SH_EINVAL;
         T.w[i] = w[i]; T.wt[i] = wt[i]; T.cout[i] = cout[i]; T.taps[i] = taps[i]; T.cin[i] = cin[i];
         T.start[i] = acc;
-        acc += (long long)taps[i] * cin[i] * ((cout[i] + 3) & ~3);
+        acc += (long long)taps[i] * sh_cdiv((cout[i] + 3) & ~3, 32) * sh_cdiv(cin[i], 32);
     }
     T.start[n] = acc;
-    long long g = sh_cdiv(acc, 256);
-    if (g > 8192) g = 8192;
-    weight_transpose_multi_kernel<<<(unsigned)g, 256, 0, (hipStream_t)stream>>>(T);
+    if (acc >= (1ll << 31)) return SH_EINVAL;
+    weight_transpose_multi_kernel<<<(unsigned)acc, 256, 0, (hipStream_t)stream>>>(T);
     return sh_launch_status();
 }
 

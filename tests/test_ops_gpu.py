@@ -332,3 +332,16 @@ def test_weight_transpose_multi_matches_single(ops):
     finally:
         ops.release_dgrad_weights()
     assert ops.weight_transpose(ws[0]).data_ptr() not in [t.data_ptr() for _, t in cache.values()]
+
+
+def test_layout_and_axpy_helpers(ops):
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(3, 3, 17, 23, generator=g)
+    y = ops.new_act(3, 4, 17, 23, DEV)
+    ops._call("sh_nchw_to_nhwc", x.to(DEV).data_ptr(), y.data_ptr(), 3, 3, 17, 23, 4, ops._st())
+    assert torch.equal(y[:, :3].cpu(), x) and float(y[:, 3].abs().max()) == 0.0
+    for n in (1024, 1001):                      # 16-byte path and scalar path
+        a, b = torch.randn(n, generator=g), torch.randn(n, generator=g)
+        ag = a.to(DEV)
+        ops._call("sh_axpy", ag.data_ptr(), b.to(DEV).data_ptr(), 0.5, n, ops._st())
+        assert torch.equal(ag.cpu(), a + 0.5 * b)
