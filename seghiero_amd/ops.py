@@ -266,8 +266,9 @@ _WS = {}
 
 
 def workspace(nbytes, device, tag="ws"):
-    """Grow-only scratch buffer per (device, tag); safe because every user runs on the one compute stream."""
-    key = (device, tag)
+    """Grow-only scratch buffer per (device, tag, launch stream): kernels of one stream run in order, so a buffer is never
+    shared by kernels that may overlap (the weight-gradient stream gets its own)."""
+    key = (device, tag, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
