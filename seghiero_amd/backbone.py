@@ -109,6 +109,7 @@ def _all_bns(mod):
 class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mod, x, *params):
+        ctx.set_materialize_grads(False)      # an unused stage output (c2 in SegHiero) gets None, not a zero tensor to convert and add
         training = mod.training
         n, cin, hh, ww = x.shape
         if cin == 4:                                                   # already ingested (seghiero_amd.ingest): NHWC4, 4th channel 0
