@@ -32,39 +32,47 @@ __device__ __forceinline__ int coarse_of(int f, const H2Tab& T) {
 template <int MAXC, bool GRAD>
 __device__ __forceinline__ void hiera2_pixel(const float (&z)[MAXC], int f, int c, const H2Tab& T, float af, float ac, float b,
                                              float (&out)[4], float (&g)[MAXC]) {
+    // Register arrays only take compile-time indices, so every label-dependent access is a select chain over the channels.
+    // The chains are kept to the few that are needed -- pick(idx) reads p[idx], add_at(idx, v) adds to g[idx] -- and the
+    // label-independent part of each term is one static loop; the order of every floating-point sum is the reference's.
     const float eps = 1e-8f;
     const int nf = T.nf, nc = T.nc;
     float p[MAXC];
 #pragma unroll
     for (int j = 0; j < MAXC; ++j) p[j] = j < nf + nc ? sigmoidf_(z[j]) : 0.f;
+    auto pick = [&](int idx) {
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j) v = (j == idx) ? p[j] : v;
+        return v;
+    };
+    auto add_at = [&](int idx, float v) {
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j) g[j] = (j == idx) ? g[j] + v : g[j];
+    };
     out[0] = out[1] = out[2] = out[3] = 0.f;
     if (f != IGN) {
+        int bi = -1;
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) bi = (k == f && k < nf) ? (int)T.bucket_of[k] : bi;
+        const int tj = bi >= 0 ? nf + bi : -1;
+        const float pf = pick(f), tt = bi >= 0 ? pick(tj) : 2.f;
+        const bool s_is_min = (bi < 0) || (pf <= tt);
+        const float m = s_is_min ? pf : tt;
+        const float term_f = -logf(m + eps);
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < MAXC; ++k) {
             if (k < nf) {
-                const float s = p[k];
-                if (k == f) {
-                    const int bi = T.bucket_of[k];
-                    float tt = 2.f; int tj = -1;
-#pragma unroll
-                    for (int j = 0; j < MAXC; ++j) if (bi >= 0 && j == nf + bi) { tt = p[j]; tj = j; }
-                    const bool s_is_min = (bi < 0) || (s <= tt);
-                    const float m = s_is_min ? s : tt;
-                    acc += -logf(m + eps);
-                    if (GRAD) {
-                        const float d = -af / (m + eps);
-                        if (s_is_min) g[k] += d * s * (1.f - s);
-                        else {
-#pragma unroll
-                            for (int j = 0; j < MAXC; ++j) if (j == tj) g[j] += d * tt * (1.f - tt);
-                        }
-                    }
-                } else {
-                    acc += -logf(1.f - s + eps);
-                    if (GRAD) g[k] += af / (1.f - s + eps) * s * (1.f - s);
-                }
+                const float s = p[k], om = 1.f - s + eps;
+                const bool isf = k == f;
+                acc += isf ? term_f : -logf(om);
+                if (GRAD) g[k] += isf ? 0.f : af / om * s * (1.f - s);
             }
+        }
+        if (GRAD) {
+            const float d = -af / (m + eps);
+            add_at(s_is_min ? f : tj, s_is_min ? d * pf * (1.f - pf) : d * tt * (1.f - tt));
         }
         out[0] = acc;
         out[2] = softmax_ce<MAXC, GRAD>(z, 0, nf, f, b, g);
@@ -72,29 +80,20 @@ __device__ __forceinline__ void hiera2_pixel(const float (&z)[MAXC], int f, int 
     if (c != IGN) {
         float acc = 0.f;
         for (int i = 0; i < nc; ++i) {
-            float ti = 0.f;
-#pragma unroll
-            for (int j = 0; j < MAXC; ++j) if (j == nf + i) ti = p[j];
+            const float ti = pick(nf + i);
             if (i == c) {
                 acc += -logf(ti + eps);
-                if (GRAD) {
-                    const float d = -ac / (ti + eps) * ti * (1.f - ti);
-#pragma unroll
-                    for (int j = 0; j < MAXC; ++j) if (j == nf + i) g[j] += d;
-                }
+                if (GRAD) add_at(nf + i, -ac / (ti + eps) * ti * (1.f - ti));
             } else {
                 // max over [fine channels of bucket i ..., coarse channel i], first maximum wins (torch.max tie rule)
                 float best = -INFINITY; int bj = -1;
+                const int bs = T.bs[i], be = T.be[i];
 #pragma unroll
                 for (int j = 0; j < MAXC; ++j)
-                    if (j < nf && j >= T.bs[i] && j < T.be[i] && p[j] > best) { best = p[j]; bj = j; }
+                    if (j < nf && j >= bs && j < be && p[j] > best) { best = p[j]; bj = j; }
                 if (ti > best) { best = ti; bj = nf + i; }
                 acc += -logf(1.f - best + eps);
-                if (GRAD) {
-                    const float d = ac / (1.f - best + eps) * best * (1.f - best);
-#pragma unroll
-                    for (int j = 0; j < MAXC; ++j) if (j == bj) g[j] += d;
-                }
+                if (GRAD) add_at(bj, ac / (1.f - best + eps) * best * (1.f - best));
             }
         }
         out[1] = acc;
