@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=CFG["batch"])
+    ap.add_argument("--syncbn", action="store_true",
+                    help="N > 1: BatchNorm statistics over all ranks (BASELINE configs[2] variant; default = per-rank statistics, "
+                         "the weak-scaling setting of SURVEY 8d)")
     args = ap.parse_args()
 
     from seghiero_amd import ddp, ops
@@ -79,6 +82,7 @@ def main():
     if world > 1:
         ddp.broadcast_module_state(list(tr.modules().values()))
         tr.grad_sync = ddp.GradSync(tr.params)
+        ops.SYNC_BN = bool(args.syncbn)
     tr.train()
     img, lab = make_batch(args.batch, CFG["size"], CFG["n_fine"], seed=rank, device=dev)
     lab8 = ops.labels_u8(lab)                       # the loader contract is i64 labels; convert once, outside the loop
@@ -154,7 +158,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: ResNet-50 + DepthwiseSeparableASPPContrastHead + 2-level HieraTripletLoss "
                                "+ aux head, 9 fine / 4 coarse, 512x512 synthetic, fwd+loss+bwd+SGD",
-                   "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+                   "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                   "parallelism": f"dp{world}" + ("" if world == 1 else (" + SyncBN" if args.syncbn else " (per-rank BatchNorm statistics)"))},
         "loss": round(loss_val, 5), "roofline": roof, "kernel_ms_per_step": breakdown,
     }
     if world == 1 and not args.no_cpu_baseline:
