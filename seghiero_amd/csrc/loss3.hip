@@ -290,61 +290,102 @@ __device__ void mm9(const double* A, const double* B, double* Cm, bool tA, bool 
             Cm[i * 9 + j] = s;
         }
 }
-// one thread per (image, channel): out rmi[bc], K1[bc][81], K2[bc][81]
-__global__ void rmi_solve_kernel(const double* __restrict__ partials, int nparts, int BC, double* __restrict__ rmi, double* __restrict__ K1,
-                                 double* __restrict__ K2) {
-    // one block (192 threads) per (image, channel): the Gram partials are summed entry-parallel (same order over the
-    // parts as a serial loop), then one thread runs the 9x9 algebra
-    __shared__ double e[GRAM_ENTRIES];
-    const int bc = blockIdx.x;
-    if (threadIdx.x < GRAM_ENTRIES) {
-        double a = 0.0;
-        for (int pp = 0; pp < nparts; ++pp) a += partials[((long long)bc * nparts + pp) * GRAM_ENTRIES + threadIdx.x];
-        e[threadIdx.x] = a;
+// ---- block-parallel 9x9 algebra in LDS (81+ threads; every element goes through the same operation sequence as the serial
+//      inv9 / mm9 above, so the results are bit-identical to a one-thread evaluation)
+__device__ void inv9_par(const double* A, double* Ai, double (*a)[18], int* piv_s, int t) {      // a: LDS [9][18]
+    if (t < 162) { const int i = t / 18, j = t % 18; a[i][j] = j < 9 ? A[i * 9 + j] : (i == j - 9 ? 1.0 : 0.0); }
+    __syncthreads();
+    for (int c = 0; c < 9; ++c) {
+        if (t == 0) {
+            int piv = c; double best = fabs(a[c][c]);
+            for (int r = c + 1; r < 9; ++r) if (fabs(a[r][c]) > best) { best = fabs(a[r][c]); piv = r; }
+            *piv_s = piv;
+        }
+        __syncthreads();
+        const int piv = *piv_s;
+        if (piv != c && t < 18) { const double tmp = a[c][t]; a[c][t] = a[piv][t]; a[piv][t] = tmp; }
+        __syncthreads();
+        const double d = 1.0 / a[c][c];
+        __syncthreads();
+        if (t < 18) a[c][t] *= d;
+        __syncthreads();
+        const int r = t / 18, j = t % 18;
+        double f = 0.0, v = 0.0, pc = 0.0;
+        bool upd = false;
+        if (t < 162) { f = a[r][c]; v = a[r][j]; pc = a[c][j]; upd = r != c && f != 0.0; }
+        __syncthreads();                                 // every old value is read before any element is rewritten
+        if (upd) a[r][j] = v - f * pc;
+        __syncthreads();
+    }
+    if (t < 81) Ai[t] = a[t / 9][9 + t % 9];
+    __syncthreads();
+}
+__device__ void mm9_par(const double* A, const double* B, double* Cm, bool tA, bool tB, int t) {
+    if (t < 81) {
+        const int i = t / 9, j = t % 9;
+        double s = 0;
+        for (int k = 0; k < 9; ++k) s += (tA ? A[k * 9 + i] : A[i * 9 + k]) * (tB ? B[j * 9 + k] : B[k * 9 + j]);
+        Cm[t] = s;
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    const double alpha = (double)1e-3f;              // f32 1e-3 promoted to f64, as `diag_eye * _POS_ALPHA` does
-    double Spp[81], Slp[81], Sll[81];
-    { int k = 0; for (int i = 0; i < 9; ++i) for (int j = i; j < 9; ++j) { Spp[i * 9 + j] = Spp[j * 9 + i] = e[k]; Sll[i * 9 + j] = Sll[j * 9 + i] = e[126 + k]; ++k; } }
-    for (int k = 0; k < 81; ++k) Slp[k] = e[45 + k];
-    double A[81], M[81], T1[81], T2[81], V[81];
-    for (int k = 0; k < 81; ++k) A[k] = Spp[k];
-    for (int i = 0; i < 9; ++i) A[i * 9 + i] += alpha;
-    inv9(A, M);
-    mm9(Slp, M, T1, false, false);                   // Slp * M
-    mm9(T1, Slp, T2, false, true);                   // Slp * M * Slp^T
-    for (int k = 0; k < 81; ++k) V[k] = Sll[k] - T2[k];
-    for (int i = 0; i < 9; ++i) V[i * 9 + i] += alpha;
-    // Cholesky V = L L^T ; rmi = 0.5 * 2 * sum log(L_ii + 1e-8)
-    double Lc[81];
-    for (int k = 0; k < 81; ++k) Lc[k] = 0.0;
-    double logdet = 0.0;
-    for (int j = 0; j < 9; ++j) {
-        double s = V[j * 9 + j];
-        for (int k = 0; k < j; ++k) s -= Lc[j * 9 + k] * Lc[j * 9 + k];
-        const double d = sqrt(s);
-        Lc[j * 9 + j] = d;
-        logdet += log(d + 1e-8);
-        for (int i = j + 1; i < 9; ++i) {
-            double t = V[i * 9 + j];
-            for (int k = 0; k < j; ++k) t -= Lc[i * 9 + k] * Lc[j * 9 + k];
-            Lc[i * 9 + j] = t / d;
-        }
+}
+// one block (192 threads) per (image, channel): out rmi[bc], K1[bc][81], K2[bc][81]
+__global__ __launch_bounds__(192) void rmi_solve_kernel(const double* __restrict__ partials, int nparts, int BC, double* __restrict__ rmi,
+                                                        double* __restrict__ K1, double* __restrict__ K2) {
+    __shared__ double e[GRAM_ENTRIES];
+    __shared__ double Slp[81], A[81], M[81], T1[81], T2[81], V[81], G0[81], Lc[81];
+    __shared__ double aug[9][18];
+    __shared__ int piv_s;
+    const int bc = blockIdx.x, t = threadIdx.x;
+    if (t < GRAM_ENTRIES) {            // Gram partials summed entry-parallel, in the serial order over the parts
+        double acc = 0.0;
+        for (int pp = 0; pp < nparts; ++pp) acc += partials[((long long)bc * nparts + pp) * GRAM_ENTRIES + t];
+        e[t] = acc;
     }
-    rmi[bc] = 0.5 * 2.0 * logdet;
+    __syncthreads();
+    const double alpha = (double)1e-3f;              // f32 1e-3 promoted to f64, as `diag_eye * _POS_ALPHA` does
+    if (t < 81) {
+        const int i = t / 9, j = t % 9, lo = i < j ? i : j, hi = i < j ? j : i;
+        const int k = lo * 9 - lo * (lo - 1) / 2 + (hi - lo);      // index of (lo, hi) in the packed upper triangle
+        A[t] = e[k] + (i == j ? alpha : 0.0);                       // Spp + alpha I
+        V[t] = e[126 + k];                                           // Sll (T2 is subtracted below)
+        Slp[t] = e[45 + t];
+    }
+    __syncthreads();
+    inv9_par(A, M, aug, &piv_s, t);
+    mm9_par(Slp, M, T1, false, false, t);                // Slp * M
+    mm9_par(T1, Slp, T2, false, true, t);                // Slp * M * Slp^T
+    if (t < 81) V[t] = V[t] - T2[t] + ((t / 9 == t % 9) ? alpha : 0.0);
+    __syncthreads();
+    if (t == 0) {                                         // Cholesky V = L L^T ; rmi = 0.5 * 2 * sum log(L_ii + 1e-8)
+        for (int k = 0; k < 81; ++k) Lc[k] = 0.0;
+        double logdet = 0.0;
+        for (int j = 0; j < 9; ++j) {
+            double s2 = V[j * 9 + j];
+            for (int k = 0; k < j; ++k) s2 -= Lc[j * 9 + k] * Lc[j * 9 + k];
+            const double d = sqrt(s2);
+            Lc[j * 9 + j] = d;
+            logdet += log(d + 1e-8);
+            for (int i = j + 1; i < 9; ++i) {
+                double tt = V[i * 9 + j];
+                for (int k = 0; k < j; ++k) tt -= Lc[i * 9 + k] * Lc[j * 9 + k];
+                Lc[i * 9 + j] = tt / d;
+            }
+        }
+        rmi[bc] = 0.5 * 2.0 * logdet;
+    }
+    __syncthreads();
     // backward matrices: G0 = (V_a + alpha I)^-1 ; d(0.5 logdet)/dV_a = 0.5 G0
     //   K1 = -2 M Slp^T (0.5 G0) = -M Slp^T G0 ;  K2 = 2 M Slp^T (0.5 G0) Slp M = M Slp^T G0 Slp M
-    double G0[81];
-    inv9(V, G0);
-    mm9(M, Slp, T1, false, true);                    // M * Slp^T
-    mm9(T1, G0, T2, false, false);                   // M Slp^T G0
-    for (int k = 0; k < 81; ++k) K1[(long long)bc * 81 + k] = -T2[k];
-    mm9(T2, Slp, T1, false, false);                  // M Slp^T G0 Slp
-    mm9(T1, M, T2, false, false);
-    for (int k = 0; k < 81; ++k) K2[(long long)bc * 81 + k] = T2[k];
+    inv9_par(V, G0, aug, &piv_s, t);
+    mm9_par(M, Slp, T1, false, true, t);                 // M * Slp^T
+    mm9_par(T1, G0, T2, false, false, t);                // M Slp^T G0
+    if (t < 81) K1[(long long)bc * 81 + t] = -T2[t];
+    __syncthreads();
+    mm9_par(T2, Slp, T1, false, false, t);               // M Slp^T G0 Slp
+    mm9_par(T1, M, T2, false, false, t);
+    if (t < 81) K2[(long long)bc * 81 + t] = T2[t];
 }
-// rmi_loss = sum_c mean_b(rmi[b][c]) / 9, cast to f32 after the mean like the reference (:514-517)
 __global__ void rmi_value_kernel(const double* __restrict__ rmi, int B, int C, float* __restrict__ out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         float total = 0.f;
