@@ -421,52 +421,80 @@ __global__ __launch_bounds__(256) void rmi_dprob_kernel(const float* __restrict_
         a1[threadIdx.x] = s1; a2[threadIdx.x] = s2;
     }
     __syncthreads();
-    // the (64+4) x (4+4) neighbourhood of the block's pixels is staged once in LDS (2 loads per thread instead of 50)
-    __shared__ float tp[8][68], tl[8][68];
-    const int bx0 = blockIdx.x * 64 - 2, by0 = blockIdx.y * 4 - 2;
+    // block = 256 columns x 4 rows, thread = 4 consecutive pixels of one row.  The (256+4) x (4+4) neighbourhood is staged once
+    // in LDS; a thread reads its 5 x 8 window with 16-byte LDS reads and each correlation coefficient once for its 4 pixels.
+    constexpr int TW = 264;                                  // 256 + 4 halo columns, padded to a multiple of 4 floats
+    __shared__ __attribute__((aligned(16))) float tp[8][TW], tl[8][TW];
+    const int bx0 = blockIdx.x * 256 - 2, by0 = blockIdx.y * 4 - 2;
     const float* P = probs + (long long)bc * H * W;
     const uint8_t* L = labels + (long long)n * H * W;
-    for (int i = threadIdx.x; i < 8 * 68; i += 256) {
-        const int ry = i / 68, rx = i - ry * 68, yy = by0 + ry, xx = bx0 + rx;
-        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+    for (int i = threadIdx.x; i < 8 * TW; i += 256) {
+        const int ry = i / TW, rx = i - ry * TW, yy = by0 + ry, xx = bx0 + rx;
+        const bool ok = rx < 260 && yy >= 0 && yy < H && xx >= 0 && xx < W;
         tp[ry][rx] = ok ? P[(long long)yy * W + xx] : 0.f;
         tl[ry][rx] = ok ? lut[L[(long long)yy * W + xx]] : 0.f;
     }
     __syncthreads();
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
-    const int x = blockIdx.x * 64 + lx, y = blockIdx.y * 4 + ly;
-    if (x >= W || y >= H) return;
-    float pv[5][5], lv[5][5];
+    const int x0 = blockIdx.x * 256 + 4 * lx, y = blockIdx.y * 4 + ly;
+    if (x0 >= W || y >= H) return;
+    float pv[5][8], lv[5][8];
 #pragma unroll
-    for (int dy = 0; dy < 5; ++dy)
+    for (int dy = 0; dy < 5; ++dy) {
+        const f32x4 p0 = ld4(&tp[ly + dy][4 * lx]), p1 = ld4(&tp[ly + dy][4 * lx + 4]);
+        const f32x4 l0 = ld4(&tl[ly + dy][4 * lx]), l1 = ld4(&tl[ly + dy][4 * lx + 4]);
 #pragma unroll
-        for (int dx = 0; dx < 5; ++dx) { pv[dy][dx] = tp[ly + dy][lx + dx]; lv[dy][dx] = tl[ly + dy][lx + dx]; }
-    double acc = 0.0;
-    if (y >= 2 && x >= 2 && y < H - 2 && x < W - 2) {
+        for (int e = 0; e < 4; ++e) { pv[dy][e] = p0[e]; pv[dy][4 + e] = p1[e]; lv[dy][e] = l0[e]; lv[dy][4 + e] = l1[e]; }
+    }
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const bool rows_in = y >= 2 && y < H - 2;
+    if (rows_in && x0 >= 2 && x0 + 3 < W - 2) {
         // interior: all nine windows exist, so the double sum over (window k, element j) collapses to two 5x5 correlations
         // with a1[d] = sum_{j-k=d} K1[k][j] (same for K2), built once per block
 #pragma unroll
         for (int dy = 0; dy < 5; ++dy)
 #pragma unroll
-            for (int dx = 0; dx < 5; ++dx) acc += a1[dy * 5 + dx] * (double)lv[dy][dx] + a2[dy * 5 + dx] * (double)pv[dy][dx];
+            for (int dx = 0; dx < 5; ++dx) {
+                const double c1 = a1[dy * 5 + dx], c2 = a2[dy * 5 + dx];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] += c1 * (double)lv[dy][q + dx] + c2 * (double)pv[dy][q + dx];
+            }
     } else {
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int q = 0; q < 4; ++q) {
+            const int x = x0 + q;
+            if (x >= W) continue;
+            if (rows_in && x >= 2 && x < W - 2) {
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int wy = y - ky, wx = x - kx;            // window origin for which (y,x) is element (ky,kx)
-                if (wy < 0 || wx < 0 || wy >= H - 2 || wx >= W - 2) continue;
-                const int k = ky * 3 + kx;
+                for (int dy = 0; dy < 5; ++dy)
 #pragma unroll
-                for (int jy = 0; jy < 3; ++jy)
-#pragma unroll
-                    for (int jx = 0; jx < 3; ++jx) {
-                        const int j = jy * 3 + jx;
-                        acc += k1[k * 9 + j] * (double)lv[2 - ky + jy][2 - kx + jx] + k2[k * 9 + j] * (double)pv[2 - ky + jy][2 - kx + jx];
-                    }
+                    for (int dx = 0; dx < 5; ++dx) acc[q] += a1[dy * 5 + dx] * (double)lv[dy][q + dx] + a2[dy * 5 + dx] * (double)pv[dy][q + dx];
+                continue;
             }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int wy = y - ky, wx = x - kx;        // window origin for which (y,x) is element (ky,kx)
+                    if (wy < 0 || wx < 0 || wy >= H - 2 || wx >= W - 2) continue;
+                    const int k = ky * 3 + kx;
+#pragma unroll
+                    for (int jy = 0; jy < 3; ++jy)
+#pragma unroll
+                        for (int jx = 0; jx < 3; ++jx) {
+                            const int j = jy * 3 + jx;
+                            acc[q] += k1[k * 9 + j] * (double)lv[2 - ky + jy][q + 2 - kx + jx] + k2[k * 9 + j] * (double)pv[2 - ky + jy][q + 2 - kx + jx];
+                        }
+                }
+        }
     }
-    dprob[((long long)bc * H + y) * W + x] = (float)acc;
+    float* dst = dprob + ((long long)bc * H + y) * W + x0;
+    if (x0 + 3 < W && (((uintptr_t)dst) & 15) == 0) {
+        st4(dst, f32x4{(float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]});
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (x0 + q < W) dst[q] = (float)acc[q];
+    }
 }
 
 // ------------------------------------------------------------------------------------------ tiled backward
@@ -604,7 +632,7 @@ extern "C" int sh_rmi_loss(const float* probs, const uint8_t* labels, const int*
     rmi_solve_kernel<<<(unsigned)BC, 192, 0, st>>>(partials, parts, BC, rmi, K1, K2);
     rmi_value_kernel<<<1, 64, 0, st>>>(rmi, N, C, rmi_out);
     if (dprob) {
-        dim3 g2((unsigned)sh_cdiv(W, 64), (unsigned)sh_cdiv(H, 4), (unsigned)BC);
+        dim3 g2((unsigned)sh_cdiv(W, 256), (unsigned)sh_cdiv(H, 4), (unsigned)BC);
         rmi_dprob_kernel<<<g2, 256, 0, st>>>(probs, labels, T, K1, K2, dprob, H, W, C);
     }
     return sh_launch_status();
