@@ -103,7 +103,11 @@ def _block_bwd(blk, saved, dout, gm):
 
 
 def _all_bns(mod):
-    return [m for m in mod.modules() if isinstance(m, nn.BatchNorm2d)]
+    bns = mod.__dict__.get("_bn_list")           # the module tree is fixed after construction: walk it once
+    if bns is None:
+        bns = [m for m in mod.modules() if isinstance(m, nn.BatchNorm2d)]
+        mod.__dict__["_bn_list"] = bns
+    return bns
 
 
 class _BackboneFn(torch.autograd.Function):

@@ -128,7 +128,10 @@ class _HeadFn(torch.autograd.Function):
         logits = L.conv_fwd(xin, mod.cls_seg.weight, mod.cls_seg.bias, G1)
         R["cls_in"] = xin
         if training:
-            L.bump_bn_counters([m for m in mod.modules() if isinstance(m, nn.BatchNorm2d)])
+            bns = mod.__dict__.get("_bn_list")
+            if bns is None:
+                bns = mod.__dict__["_bn_list"] = [m for m in mod.modules() if isinstance(m, nn.BatchNorm2d)]
+            L.bump_bn_counters(bns)
         ctx.mod, ctx.R, ctx.params, ctx.training = mod, R, params, training
         ctx.hw = (h, w)
         ctx.c1_needs = c1 is not None and torch.is_tensor(c1) and ctx.needs_input_grad[1]

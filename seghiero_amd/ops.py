@@ -60,7 +60,8 @@ class profile:
 
 
 def _st():
-    return torch.cuda.current_stream().cuda_stream
+    # raw hipStream_t of torch's current stream on the current device (the C call: no Stream object is built per launch)
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def _require_gpu(t):
@@ -268,7 +269,8 @@ _WS = {}
 def workspace(nbytes, device, tag="ws"):
     """Grow-only scratch buffer per (device, tag, launch stream): kernels of one stream run in order, so a buffer is never
     shared by kernels that may overlap (the weight-gradient stream gets its own)."""
-    key = (device, tag, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    key = (device, tag, torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device())
+           if device.type == "cuda" else 0)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
