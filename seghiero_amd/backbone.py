@@ -169,7 +169,7 @@ class _BackboneFn(torch.autograd.Function):
                 continue
             d = _block_bwd(blk, saved[idx], d, gm)
             if idx == 0 or blocks[idx - 1][0] != li:                      # first block of a stage: the stage's gradients are final
-                gm.flush(list(layers[li].parameters()))
+                gm.flush(L.params_of(layers[li]))
         if d is not None:
             x4, wpad, s_rec, pool_idx, (sh, sw) = ctx.stem
             dpool = ops.maxpool_bwd(pool_idx, d, sh, sw)
@@ -227,4 +227,4 @@ class ResNetBackbone(nn.Module):
         if x.dim() != 4 or (x.shape[1] != 3 and not ingested):
             raise ValueError("expected input of shape [B, 3, H, W] (or the NHWC4 tensor made by seghiero_amd.ingest)")
         ops._require_gpu(x)
-        return _BackboneFn.apply(self, x, *self.parameters())
+        return _BackboneFn.apply(self, x, *L.params_of(self))

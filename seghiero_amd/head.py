@@ -239,7 +239,7 @@ class DepthwiseSeparableASPPContrastHead(nn.Module):
         ops._require_gpu(inputs[-1])
         self.step += 1
         c1 = inputs[0] if self.c1_bottleneck is not None else None
-        return _HeadFn.apply(self, c1, inputs[-1], *self.parameters())
+        return _HeadFn.apply(self, c1, inputs[-1], *L.params_of(self))
 
 
 # ----------------------------------------------------------------------------- aux head (train.py:169-173)
@@ -277,4 +277,4 @@ class AuxHead(nn.Sequential):
 
     def forward(self, c3):
         ops._require_gpu(c3)
-        return _AuxFn.apply(self, c3, *self.parameters())
+        return _AuxFn.apply(self, c3, *L.params_of(self))

@@ -29,6 +29,14 @@ def to_native_layout(module):
     return module
 
 
+def params_of(mod):
+    """list(mod.parameters()), walked once per module (the parameter set of these modules is fixed after construction)."""
+    ps = mod.__dict__.get("_param_list")
+    if ps is None:
+        ps = mod.__dict__["_param_list"] = list(mod.parameters())
+    return ps
+
+
 def bump_bn_counters(bns):
     """num_batches_tracked += 1 for all train-mode BN layers of one forward, in one launch."""
     ctrs = [b.num_batches_tracked for b in bns if b.num_batches_tracked is not None]

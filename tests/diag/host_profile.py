@@ -15,6 +15,7 @@ lab8 = ops.labels_u8(lab)
 for _ in range(5):
     tr.train_step(img, lab8, 0)
 torch.cuda.synchronize()
+torch.autograd.set_multithreading_enabled(False)      # backward in this thread, so cProfile sees it
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(20):
@@ -22,4 +23,4 @@ for _ in range(20):
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(22)
+st.sort_stats("tottime").print_stats(30)
