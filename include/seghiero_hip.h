@@ -126,14 +126,15 @@ int sh_bn_finalize(const float* partials, int n_partials, int C, double count, c
                    float* running_var, float* mean, float* invstd, float* scale, float* shift,
                    int rows_per_partial, void* stream);
 /* SyncBN building blocks (cross-GPU BatchNorm is new functionality): reduce the partials to f64 per-channel
- * sums sq[2][C] on each rank (forward: sum x, sum x^2 from the centred partials; backward, rows_per_partial = 0: sum g,
- * sum g*xhat), all-reduce them over RCCL on the host side, then finalize on the global sums / count. */
+ * sums on each rank -- sq is double[2*C + 1] = {sum x [C], sum x^2 [C], local pixel count} (forward, from the centred
+ * partials) or {sum g [C], sum g*xhat [C], count} (backward, rows_per_partial = 0) -- all-reduce the vector over RCCL on
+ * the host side, then finalize on the global sums and the global count sq[2*C] (ranks may hold different pixel counts). */
 int sh_bn_reduce_partials(const float* partials, int n_partials, int C, double count, int rows_per_partial, double* sq,
                           void* stream);
-int sh_bn_finalize_sq(const double* sq, int C, double count, const float* gamma, const float* beta, float eps,
+int sh_bn_finalize_sq(const double* sq, int C, const float* gamma, const float* beta, float eps,
                       float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
                       float* scale, float* shift, void* stream);
-int sh_bn_bwd_finalize_sq(const double* local_sq, const double* global_sq, int C, double count, float* dgamma,
+int sh_bn_bwd_finalize_sq(const double* local_sq, const double* global_sq, int C, float* dgamma,
                           float* dbeta, float* c1, float* c2, void* stream);
 /* Eval-mode coefficients from the running statistics. */
 int sh_bn_eval_coefs(const float* gamma, const float* beta, const float* running_mean,
@@ -228,14 +229,19 @@ int sh_combine_loss(const float* main_loss, const float* trip_out, const float* 
  * terms (:523-526).  f2m_host / f2h_host: HOST int32[n_fine] fine->mid / fine->high maps.
  *   sums (device double[8]) <- {bce_f, bce_m, bce_h, ce_f, ce_m, ce_h, n_valid, n_pixels}
  *   loss_out (device float[1]) <- 0.5*5*(bce_f/(nv*nf)+bce_m/(nv*nm)+bce_h/(nv*nh)) + (ce_f+ce_m+ce_h)/npix
- *   probs (optional): planar f32 [N][C][H][W] <- sigmoid(z)*valid + 1e-6 (the RMI input, :496). */
+ *   probs (optional): planar f32 [N][C][H][W] <- sigmoid(z)*valid + 1e-6 (the RMI input, :496).
+ *   mid_out / high_out (optional, both or neither): uint8 [N][H][W] <- the target maps of _prepare_targets_three_level
+ *   (:21-63): 255 where the fine label is 255, else fine_to_mid[f] / fine_to_high[f]. */
 int sh_hiera3_loss_fwd(const float* logits, int ldl, const uint8_t* labels, const int* f2m_host, const int* f2h_host,
                        int n_fine, int n_mid, int n_high, double* sums, float* loss_out, float* partials, float* probs,
-                       int N, int h, int w, int H, int W, void* stream);
+                       uint8_t* mid_out, uint8_t* high_out, int N, int h, int w, int H, int W, void* stream);
 /* RMI lower bound (:292-317, :479-517): per (image, channel) f64 9x9 Gram matrices over the 3x3 windows, inverse, Schur
  * complement, Cholesky log-det; rmi_out (device float[1]) <- sum_c mean_b(0.5*logdet)/9.  dprob (optional, planar like
  * probs) <- d(0.5*logdet_{b,c})/dP (the 1/(9N) and lambda factors are applied by sh_hiera3_loss_bwd's rmi_coef). */
 int64_t sh_rmi_workspace(int N, int C, int H, int W);
+/* Byte offset inside that workspace of the f64 [N][C] per-(image, channel) values rmi_now = 0.5*logdet (:513) left by
+ * sh_rmi_loss (parity tests read them back and compare with the reference's own f64 values). */
+int64_t sh_rmi_values_offset(int N, int C, int H, int W);
 int sh_rmi_loss(const float* probs, const uint8_t* labels, const int* f2m_host, const int* f2h_host, int n_fine, int n_mid,
                 int n_high, void* workspace, float* rmi_out, float* dprob, int N, int H, int W, void* stream);
 /* dlogits [N,h,w,lddl] <- gscale*gscale_dev[0] * d(loss_out + rmi_coef * <dprob, P>)/d(logits)  (tiled gather form). */

@@ -174,7 +174,7 @@ class _BackboneFn(torch.autograd.Function):
             x4, wpad, s_rec, pool_idx, (sh, sw) = ctx.stem
             dpool = ops.maxpool_bwd(pool_idx, d, sh, sw)
             _, dwp, dg, db, _ = L.cba_bwd(s_rec, mod.stem_bn, dpool, need_dx=False)
-            dw = torch.empty_like(mod.stem_conv.weight)
+            dw = L.new_grad(mod.stem_conv.weight)
             ops.join_wgrad()                                               # dwp comes from the weight-gradient stream
             ops._call("sh_nhwc_to_nchw", dwp.data_ptr(), dw.data_ptr(), dw.shape[0], 3, 7, 7, 4, ops._st())
             gm.put(mod.stem_conv.weight, dw); gm.put(mod.stem_bn.weight, dg); gm.put(mod.stem_bn.bias, db)

@@ -455,8 +455,11 @@ extern "C" int sh_bn_bwd_apply(const float* dout, int lddo, const float* out, in
 // side all-reduces them over RCCL, and the finalize kernels run on the global sums.
 //   forward : sq[0][c] = sum x, sq[1][c] = sum x^2 (assembled from the centred partials in f64)
 //   backward: sq[0][c] = sum g, sq[1][c] = sum g*xhat
+//   sq[2*C] = this rank's pixel count: after the all-reduce it is the global count the finalize kernels divide by, so ranks
+//   may hold different numbers of pixels (torch.nn.SyncBatchNorm all-gathers the counts for the same reason)
 __global__ __launch_bounds__(256) void bn_reduce_partials_kernel(const float* __restrict__ partials, int P, int C, int R, long long M,
                                                                  double* __restrict__ sq) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) sq[2 * C] = (double)M;      // the local count travels with the sums
     reduce_partials_4ch(partials, P, C, blockIdx.x * 4, R, M, [&](int c, double s, double q) { sq[c] = s; sq[C + c] = q; });
 }
 extern "C" int sh_bn_reduce_partials(const float* partials, int n_partials, int C, double count, int rows_per_partial, double* sq,
@@ -466,11 +469,12 @@ extern "C" int sh_bn_reduce_partials(const float* partials, int n_partials, int 
                                                                                        (long long)count, sq);
     return sh_launch_status();
 }
-__global__ __launch_bounds__(256) void bn_finalize_sq_kernel(const double* __restrict__ sq, int C, double count, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void bn_finalize_sq_kernel(const double* __restrict__ sq, int C, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps, float momentum, float* running_mean,
                                                              float* running_var, float* mean, float* invstd, float* scale, float* shift) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
+    const double count = sq[2 * C];
     const double mu = sq[c] / count;
     double var = sq[C + c] / count - mu * mu;
     if (var < 0) var = 0;
@@ -484,27 +488,28 @@ __global__ __launch_bounds__(256) void bn_finalize_sq_kernel(const double* __res
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
 }
-extern "C" int sh_bn_finalize_sq(const double* sq, int C, double count, const float* gamma, const float* beta, float eps, float momentum,
+extern "C" int sh_bn_finalize_sq(const double* sq, int C, const float* gamma, const float* beta, float eps, float momentum,
                                  float* running_mean, float* running_var, float* mean, float* invstd, float* scale, float* shift,
                                  void* stream) {
-    if (!sq || C <= 0 || count <= 0 || !mean || !invstd || !scale || !shift) return SH_EINVAL;
-    bn_finalize_sq_kernel<<<(unsigned)sh_cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(sq, C, count, gamma, beta, eps, momentum, running_mean,
+    if (!sq || C <= 0 || !mean || !invstd || !scale || !shift) return SH_EINVAL;
+    bn_finalize_sq_kernel<<<(unsigned)sh_cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(sq, C, gamma, beta, eps, momentum, running_mean,
                                                                                       running_var, mean, invstd, scale, shift);
     return sh_launch_status();
 }
 // dgamma / dbeta from the LOCAL sums (DDP sums them over ranks later), c1 / c2 from the GLOBAL sums and count
 __global__ __launch_bounds__(256) void bn_bwd_finalize_sq_kernel(const double* __restrict__ local_sq, const double* __restrict__ global_sq, int C,
-                                                                 double count, float* dgamma, float* dbeta, float* c1, float* c2) {
+                                                                 float* dgamma, float* dbeta, float* c1, float* c2) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
+    const double count = global_sq[2 * C];
     if (dbeta) dbeta[c] = (float)local_sq[c];
     if (dgamma) dgamma[c] = (float)local_sq[C + c];
     c1[c] = (float)(global_sq[c] / count);
     c2[c] = (float)(global_sq[C + c] / count);
 }
-extern "C" int sh_bn_bwd_finalize_sq(const double* local_sq, const double* global_sq, int C, double count, float* dgamma, float* dbeta,
+extern "C" int sh_bn_bwd_finalize_sq(const double* local_sq, const double* global_sq, int C, float* dgamma, float* dbeta,
                                      float* c1, float* c2, void* stream) {
-    if (!local_sq || !global_sq || C <= 0 || count <= 0 || !c1 || !c2) return SH_EINVAL;
-    bn_bwd_finalize_sq_kernel<<<(unsigned)sh_cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(local_sq, global_sq, C, count, dgamma, dbeta, c1, c2);
+    if (!local_sq || !global_sq || C <= 0 || !c1 || !c2) return SH_EINVAL;
+    bn_bwd_finalize_sq_kernel<<<(unsigned)sh_cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(local_sq, global_sq, C, dgamma, dbeta, c1, c2);
     return sh_launch_status();
 }

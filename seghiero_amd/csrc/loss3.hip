@@ -127,6 +127,7 @@ __device__ __forceinline__ void hiera3_pixel(const float (&z)[MAXC], int tf, con
 template <int MAXC>
 __global__ __launch_bounds__(256) void hiera3_fwd_kernel(const float* __restrict__ logits, long long ldl, const uint8_t* __restrict__ labels,
                                                          const H3Tab T, float* __restrict__ partials, float* __restrict__ probs,
+                                                         uint8_t* __restrict__ mid_out, uint8_t* __restrict__ high_out,
                                                          int h, int w, int H, int W, float sy, float sx, long long total) {
     const bool identity = (h == H && w == W);
     const int C = T.nf + T.nm + T.nh;
@@ -137,6 +138,10 @@ __global__ __launch_bounds__(256) void hiera3_fwd_kernel(const float* __restrict
         const long long i = base + it * 256 + threadIdx.x;
         if (i >= total) break;
         const int f = labels[i];
+        if (mid_out) {     // the target maps of _prepare_targets_three_level (:21-63): 255 stays 255, else gather through the maps
+            mid_out[i] = f == IGN ? (uint8_t)IGN : (uint8_t)T.f2m[f];
+            high_out[i] = f == IGN ? (uint8_t)IGN : (uint8_t)T.f2h[f];
+        }
         const int ox = (int)(i % W);
         const long long q = i / W;
         const int oy = (int)(q % H);
@@ -590,18 +595,19 @@ static bool make_tab3(H3Tab& T, const int* f2m, const int* f2h, int nf, int nm, 
 }
 
 extern "C" int sh_hiera3_loss_fwd(const float* logits, int ldl, const uint8_t* labels, const int* f2m_host, const int* f2h_host, int n_fine,
-                                  int n_mid, int n_high, double* sums, float* loss_out, float* partials, float* probs, int N, int h, int w,
-                                  int H, int W, void* stream) {
+                                  int n_mid, int n_high, double* sums, float* loss_out, float* partials, float* probs, uint8_t* mid_out,
+                                  uint8_t* high_out, int N, int h, int w, int H, int W, void* stream) {
     H3Tab T;
     if (!logits || !labels || !sums || !loss_out || !partials || N <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SH_EINVAL;
+    if ((mid_out == nullptr) != (high_out == nullptr)) return SH_EINVAL;
     if (!make_tab3(T, f2m_host, f2h_host, n_fine, n_mid, n_high) || ldl < n_fine + n_mid + n_high) return SH_EINVAL;
     const long long total = (long long)N * H * W;
     const int nblk = (int)sh_cdiv(total, LOSS_PIX_PER_BLOCK);
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
     hipStream_t st = (hipStream_t)stream;
     const int C = n_fine + n_mid + n_high;
-    if (C <= 16) hiera3_fwd_kernel<16><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, probs, h, w, H, W, sy, sx, total);
-    else hiera3_fwd_kernel<32><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, probs, h, w, H, W, sy, sx, total);
+    if (C <= 16) hiera3_fwd_kernel<16><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, probs, mid_out, high_out, h, w, H, W, sy, sx, total);
+    else hiera3_fwd_kernel<32><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, probs, mid_out, high_out, h, w, H, W, sy, sx, total);
     int rc = sh_launch_status();
     if (rc != SH_OK) return rc;
     hiera3_finalize_kernel<<<1, 256, 0, st>>>(partials, nblk, (double)total, n_fine, n_mid, n_high, sums, loss_out);
@@ -612,6 +618,13 @@ extern "C" int64_t sh_rmi_workspace(int N, int C, int H, int W) {
     if (N <= 0 || C <= 0 || H < 3 || W < 3) return SH_EINVAL;
     const long long parts = sh_cdiv(W - 2, 64) * sh_cdiv(H - 2, GRAM_ROWS);
     return (int64_t)((long long)N * C * parts * GRAM_ENTRIES * 8 + (long long)N * C * (1 + 81 + 81) * 8 + 64);
+}
+// byte offset, inside the sh_rmi_loss workspace, of the f64 [N][C] values rmi_now = 0.5 * logdet (rmi_hiera_triplet_loss.py:513)
+// that sh_rmi_loss leaves behind -- read back by the parity tests against the reference's own per-channel values
+extern "C" int64_t sh_rmi_values_offset(int N, int C, int H, int W) {
+    if (N <= 0 || C <= 0 || H < 3 || W < 3) return SH_EINVAL;
+    const long long parts = sh_cdiv(W - 2, 64) * sh_cdiv(H - 2, GRAM_ROWS);
+    return (int64_t)((long long)N * C * parts * GRAM_ENTRIES * 8);
 }
 // probs: planar [N][C][H][W] from sh_hiera3_loss_fwd.  workspace: sh_rmi_workspace bytes.  rmi_out: device float[1] = RMI term
 // (sum_c mean_b 0.5*logdet / 9).  dprob (optional): planar [N][C][H][W] <- d(rmi_out * 9 * N)/dP, i.e. WITHOUT the 1/(9N) factor.

@@ -32,7 +32,49 @@ def init_from_env(backend=None):
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if dist.is_initialized():
+        init_small_group()
     return rank, local, world
+
+
+# Latency-class collectives (SyncBN statistics: 2 x 69 per step, each a few KB; the 4-byte triplet class_count MIN-reduce)
+# get a process group -- i.e. an RCCL communicator and internal stream -- of their own, so that a stat reduction on the
+# critical path of forward / backward never queues behind a 32 MB gradient bucket of the default group.
+_SMALL = None
+FORCE_COLLECTIVES = False      # tests: run every collective even at world size 1 (executes the RCCL calls on a one-GPU box)
+
+
+def init_small_group():
+    """Collective: every rank must call it (init_from_env and GradSync.__init__ do)."""
+    global _SMALL
+    if _SMALL is None and dist.is_available() and dist.is_initialized():
+        _SMALL = dist.new_group()
+    return _SMALL
+
+
+def small_group():
+    return _SMALL
+
+
+def shutdown():
+    global _SMALL, _ACTIVE
+    _SMALL = None
+    _ACTIVE = None
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def collectives_on():
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
+
+
+def all_reduce_small(t, op=None):
+    """All-reduce of a latency-critical small tensor on the small-message group (falls back to the default group)."""
+    return all_reduce(t, op=op, group=_SMALL)
 
 
 def _via_host(group=None):
@@ -68,6 +110,13 @@ def broadcast_module_state(modules, src=0):
 _ACTIVE = None          # the GradSync that is collecting gradients of the backward pass in flight (set by begin())
 
 
+def grad_buffer(p):
+    """Where a backward node should write the gradient of parameter `p`: its slice of the active GradSync arena, else None."""
+    if _ACTIVE is not None and id(p) in _ACTIVE.views and id(p) not in _ACTIVE._in_arena:
+        return _ACTIVE.grad_view(p)
+    return None
+
+
 def early_flush(pairs):
     """Called from inside the hand-scheduled backward nodes with (parameter, final gradient) pairs: lets the gradient
     exchange of finished buckets start while the rest of the backward is still running.  No-op without an active sync."""
@@ -86,6 +135,9 @@ class GradSync:
     def __init__(self, params, bucket_mb=32.0, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.on = dist.is_initialized() and (self.world > 1 or FORCE_COLLECTIVES)
+        if dist.is_initialized():
+            init_small_group()
         # backward produces gradients roughly in reverse parameter order
         self.order = list(reversed(list(params)))
         dev = self.order[0].device
@@ -111,7 +163,13 @@ class GradSync:
     def begin(self):
         global _ACTIVE
         self._in_arena, self._launched, self._works = set(), set(), []
-        _ACTIVE = self if self.world > 1 else None
+        _ACTIVE = self if self.on else None
+
+    def grad_view(self, p):
+        """The arena slice of parameter `p` shaped / strided like `p`: the backward kernels write weight gradients straight
+        into it (layers.new_grad), so nothing is copied when the bucket leaves."""
+        o, n = self.views[id(p)]
+        return self.flat[o:o + n].as_strided(p.shape, p.stride())
 
     def _stage(self, pairs):
         srcs, dsts = [], []
@@ -119,13 +177,15 @@ class GradSync:
             if g is None or id(p) not in self.views or id(p) in self._in_arena:
                 continue
             o, n = self.views[id(p)]
+            self._in_arena.add(id(p))
+            if g.data_ptr() == self.flat.data_ptr() + 4 * o and g.shape == p.shape and g.stride() == p.stride():
+                continue                                  # already written in place by the backward kernels
             if g.shape != p.shape:
                 g = g.reshape(p.shape)
             if g.stride() != p.stride():
                 g = torch.empty_like(p).copy_(g)
             srcs.append(g.as_strided((n,), (1,)) if not g.is_contiguous() else g.reshape(-1))
             dsts.append(self.flat[o:o + n])
-            self._in_arena.add(id(p))
         if srcs:
             torch._foreach_copy_(dsts, srcs)
 
@@ -143,7 +203,7 @@ class GradSync:
             self._works.append(all_reduce(buf, group=self.group, async_op=True))
 
     def early(self, pairs):
-        if self.world == 1:
+        if not self.on:
             return
         self._stage(pairs)
         for bi, (_, _, plist) in enumerate(self.buckets):
@@ -154,7 +214,7 @@ class GradSync:
         """All-reduce (sum) every gradient in place; returns the scale (1/world) the optimizer must apply."""
         global _ACTIVE
         _ACTIVE = None
-        if self.world == 1:
+        if not self.on:
             return 1.0
         self._stage([(p, p.grad) for p in params])
         for bi, (_, _, plist) in enumerate(self.buckets):

@@ -85,6 +85,14 @@ def cba_fwd(x, weight, geom, bn, relu, training, residual=None, out=None):
     return out, rec
 
 
+def new_grad(param):
+    """Output buffer for the gradient of `param`: its slice of the data-parallel gradient arena when an exchange is in
+    flight (ddp.GradSync: the all-reduce then needs no staging copy), else a fresh tensor laid out like the parameter."""
+    from . import ddp
+    buf = ddp.grad_buffer(param)
+    return torch.empty_like(param) if buf is None else buf
+
+
 def cba_bwd(rec, bn, dout, need_dx=True, addend=None, want_dres=False, scatter_into=None):
     """-> (dx, dweight, dgamma, dbeta, dres).  `addend` is summed into dx by the dgrad epilogue;
     `scatter_into` (1x1 strided convs) accumulates the result into an existing dx instead."""
@@ -93,7 +101,7 @@ def cba_bwd(rec, bn, dout, need_dx=True, addend=None, want_dres=False, scatter_i
     mode = 0 if not rec.relu else (1 if rec.has_res else 2)
     dy, dgamma, dbeta, dres = ops.bn_backward(dout, rec.out if mode == 1 else None, rec.y, rec.coefs, bn.weight,
                                               mode, want_dres)
-    dw = torch.empty_like(rec.weight)
+    dw = new_grad(rec.weight)
     if not ops.WGRAD_AFTER_DGRAD:
         ops.conv_wgrad(rec.x, dy, dw, s, p, d, side=True)
     dx = None
@@ -132,7 +140,7 @@ def dw_fwd(x, weight, dil, bn, training):
 def dw_bwd(rec, bn, dout, dx_accumulate_into=None):
     """-> (dx, dweight, dgamma, dbeta); with dx_accumulate_into the input gradient is added into that tensor."""
     dy, dgamma, dbeta, _ = ops.bn_backward(dout, None, rec.y, rec.coefs, bn.weight, 2)
-    dw = torch.empty_like(rec.weight)
+    dw = new_grad(rec.weight)
     ops.dwconv_wgrad(rec.x, dy, dw, rec.dil, side=True)
     if dx_accumulate_into is not None:
         ops.dwconv_dgrad(dy, rec.weight, dx_accumulate_into, rec.dil, accumulate=True)
@@ -159,7 +167,7 @@ def conv_fwd(x, weight, bias, geom):
 def conv_bwd(x, weight, geom, dy, need_dx=True, addend=None):
     """dy must be NHWC with its padding lanes zeroed.  -> (dx, dweight)."""
     s, p, d = geom
-    dw = torch.empty_like(weight)
+    dw = new_grad(weight)
     ops.conv_wgrad(x, dy, dw, s, p, d, side=True)
     dx = None
     if need_dx:

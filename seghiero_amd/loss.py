@@ -151,7 +151,7 @@ class _Hiera2Fn(torch.autograd.Function):
             # hiera_triplet_loss.py:193-198: the term counts only if EVERY rank produced triplets
             from . import ddp
             ready = trip[1:2].clone()
-            ddp.all_reduce(ready, op=torch.distributed.ReduceOp.MIN)
+            ddp.all_reduce_small(ready, op=torch.distributed.ReduceOp.MIN)
         factor = triplet_factor(step, 80000)
         total = ops.combine_loss(main, trip, ready, factor, mod.loss_weight)
         ctx.save_for_backward(logits, emb, label8, sums, trip, ws)
@@ -215,10 +215,6 @@ def three_level_triplet_tables(upper_ids, lower_ids):
     return masks, torch.tensor(_bitset(ok), dtype=torch.int64)
 
 
-class _RMITripletFn(_TripletFn):
-    pass
-
-
 class RMITreeTripletLoss(nn.Module):
     """``TreeTripletLoss`` of reference ``models/loss/rmi_tree_triplet_loss.py:5-70`` (3-level variant)."""
 
@@ -242,6 +238,18 @@ class RMITreeTripletLoss(nn.Module):
         return (None, cnt) if n == 0 else (loss, cnt)
 
 
+def prepare_targets_three_level(targets, fine_to_mid, fine_to_high):
+    """``_prepare_targets_three_level`` of reference ``rmi_hiera_triplet_loss.py:21-63`` evaluated by the HIP loss kernel
+    (the same code path ``RMIHieraTripletLoss.forward`` uses internally): -> (fine, mid, high) int64 maps, 255 = ignore."""
+    l8 = ops.labels_u8(targets)
+    f2m = [int(v) for v in fine_to_mid.tolist()]
+    f2h = [int(v) for v in fine_to_high.tolist()]
+    nf, nm, nh = len(f2m), max(f2m) + 1, max(f2h) + 1
+    z = ops.new_act(l8.shape[0], nf + nm + nh, 1, 1, l8.device, zero=True)
+    _, _, _, (mid, high) = ops.hiera3_fwd(z, l8, nf, nm, nh, f2m, f2h, want_probs=False, want_targets=True)
+    return targets, mid.long(), high.long()
+
+
 class _Hiera3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cls_score, embedding, label8, mod, step):
@@ -260,7 +268,7 @@ class _Hiera3Fn(torch.autograd.Function):
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             from . import ddp
             ready = trip[1:2].clone()
-            ddp.all_reduce(ready, op=torch.distributed.ReduceOp.MIN)
+            ddp.all_reduce_small(ready, op=torch.distributed.ReduceOp.MIN)
         factor = triplet_factor(step, 160000 if nf > 15 else 60000)
         total = ops.combine_loss(main, trip, ready, factor, lw)
         ctx.save_for_backward(logits, emb, label8, sums, trip, ws, dprob if dprob is not None else sums)

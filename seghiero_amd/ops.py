@@ -401,24 +401,28 @@ SYNC_BN = False       # True: BatchNorm statistics (forward and backward) are al
 
 
 def _sync_on():
-    return SYNC_BN and torch.distributed.is_available() and torch.distributed.is_initialized() and \
-        torch.distributed.get_world_size() > 1
+    if not SYNC_BN:
+        return False
+    from . import ddp
+    return ddp.collectives_on()
 
 
 def _all_reduce_sq(sq):
+    """Sum the f64 vector [sum, sum-of-squares (or sum g*xhat), local count] over the ranks, on the small-message group."""
     from . import ddp
-    ddp.all_reduce(sq)
+    ddp.all_reduce_small(sq)
     return sq
 
 
 def bn_finalize(partials, count, gamma, beta, eps, momentum, running_mean, running_var, c, device, rows=64):
     coefs = torch.empty((4, c), device=device, dtype=torch.float32)      # mean, invstd, scale, shift
     if _sync_on():
-        sq = torch.empty((2 * c,), device=device, dtype=torch.float64)
+        # sq = [sum x (C), sum x^2 (C), local count]: the count travels with the sums, so ranks may hold different numbers of
+        # pixels (uneven last batch, different crops) -- torch.nn.SyncBatchNorm all-gathers the counts for the same reason
+        sq = torch.empty((2 * c + 1,), device=device, dtype=torch.float64)
         _call("sh_bn_reduce_partials", partials.data_ptr(), partials.shape[0], c, float(count), rows, sq.data_ptr(), _st())
         _all_reduce_sq(sq)
-        total = float(count) * torch.distributed.get_world_size()       # equal per-rank counts (same batch / crop per rank)
-        _call("sh_bn_finalize_sq", sq.data_ptr(), c, total, None if gamma is None else gamma.data_ptr(),
+        _call("sh_bn_finalize_sq", sq.data_ptr(), c, None if gamma is None else gamma.data_ptr(),
               None if beta is None else beta.data_ptr(), eps, momentum,
               None if running_mean is None else running_mean.data_ptr(),
               None if running_var is None else running_var.data_ptr(),
@@ -476,10 +480,10 @@ def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None):
           coefs[3].data_ptr(), partials.data_ptr(), m, c, relu, _st())
     red = torch.empty((4, c), device=dev, dtype=torch.float32)           # dgamma, dbeta, c1, c2
     if _sync_on():
-        local = torch.empty((2 * c,), device=dev, dtype=torch.float64)
+        local = torch.empty((2 * c + 1,), device=dev, dtype=torch.float64)
         _call("sh_bn_reduce_partials", partials.data_ptr(), p, c, float(m), 0, local.data_ptr(), _st())
         glob = _all_reduce_sq(local.clone())
-        _call("sh_bn_bwd_finalize_sq", local.data_ptr(), glob.data_ptr(), c, float(m) * torch.distributed.get_world_size(),
+        _call("sh_bn_bwd_finalize_sq", local.data_ptr(), glob.data_ptr(), c,
               red[0].data_ptr(), red[1].data_ptr(), red[2].data_ptr(), red[3].data_ptr(), _st())
     else:
         _call("sh_bn_bwd_finalize", partials.data_ptr(), p, c, None if gamma is None else gamma.data_ptr(),
@@ -739,8 +743,8 @@ def _ints(values):
     return (ctypes.c_int * max(len(vals), 1))(*vals)
 
 
-def hiera3_fwd(logits, labels8, n_fine, n_mid, n_high, f2m, f2h, want_probs):
-    """-> (loss_rest[1] f32, sums[8] f64, probs planar [N,C,H,W] or None)."""
+def hiera3_fwd(logits, labels8, n_fine, n_mid, n_high, f2m, f2h, want_probs, want_targets=False):
+    """-> (loss_rest[1] f32, sums[8] f64, probs planar [N,C,H,W] or None[, (mid u8, high u8) target maps])."""
     n, c, h, w = logits.shape
     _, H, W = labels8.shape
     lp, ldl = pm(logits)
@@ -750,8 +754,13 @@ def hiera3_fwd(logits, labels8, n_fine, n_mid, n_high, f2m, f2h, want_probs):
     sums = torch.empty((8,), device=dev, dtype=torch.float64)
     loss = torch.empty((1,), device=dev, dtype=torch.float32)
     probs = torch.empty((n, c, H, W), device=dev, dtype=torch.float32) if want_probs else None
+    mid = torch.empty_like(labels8) if want_targets else None
+    high = torch.empty_like(labels8) if want_targets else None
     _call("sh_hiera3_loss_fwd", lp, ldl, labels8.data_ptr(), _ints(f2m), _ints(f2h), n_fine, n_mid, n_high, sums.data_ptr(),
-          loss.data_ptr(), partials.data_ptr(), None if probs is None else probs.data_ptr(), n, h, w, H, W, _st())
+          loss.data_ptr(), partials.data_ptr(), None if probs is None else probs.data_ptr(),
+          None if mid is None else mid.data_ptr(), None if high is None else high.data_ptr(), n, h, w, H, W, _st())
+    if want_targets:
+        return loss, sums, probs, (mid, high)
     return loss, sums, probs
 
 
@@ -765,6 +774,13 @@ def rmi_loss(probs, labels8, n_fine, n_mid, n_high, f2m, f2h, want_grad):
     _call("sh_rmi_loss", probs.data_ptr(), labels8.data_ptr(), _ints(f2m), _ints(f2h), n_fine, n_mid, n_high, ws.data_ptr(),
           out.data_ptr(), None if dprob is None else dprob.data_ptr(), n, H, W, _st())
     return out, dprob
+
+
+def rmi_values(n, c, H, W, device):
+    """f64 [n, c] rmi_now = 0.5*logdet per (image, channel) left in the workspace by the last rmi_loss call on this stream."""
+    off = LIB.raw("sh_rmi_values_offset")(n, c, H, W)
+    ws = workspace(LIB.raw("sh_rmi_workspace")(n, c, H, W), device, "rmi")
+    return ws[off:off + 8 * n * c].view(torch.float64).reshape(n, c).clone()
 
 
 def hiera3_bwd(logits, labels8, n_fine, n_mid, n_high, f2m, f2h, sums, dprob, rmi_coef, gscale_dev, gscale):

@@ -12,6 +12,9 @@ these fusions (results unchanged):
 
 ``step`` passed to the loss is the EPOCH, as in the reference (``train.py:287``).
 """
+import os
+import re
+
 import torch
 import torch.nn as nn
 
@@ -43,9 +46,59 @@ def aux_ce_loss(aux_logits, label):
     return _AuxCEFn.apply(aux_logits, ops.labels_u8(label))
 
 
+def load_config(path):
+    """``yaml.safe_load`` of a reference-format config file (``train.py:104-105``)."""
+    import yaml
+    with open(path, "r") as f:
+        return yaml.safe_load(f)
+
+
 class SegHieroTrainer:
+    @classmethod
+    def from_config(cls, cfg, depth=None, device=None, grad_sync=None, head_kw=None):
+        """Build the trainer from the reference's YAML config surface -- the dict ``yaml.safe_load`` returns, or a path.
+
+        Consumes exactly the keys ``train.py`` reads for the model / loss / optimizer (``:137-143, 182, 199, 203-233, 243``):
+        ``classes.{fine_names, coarse_names, super_coarse_names, coarse_to_fine_map, super_coarse_to_coarse_map}``,
+        ``training.{lr, fine_weight, rmi_radius, rmi_pool_way, rmi_pool_size, rmi_pool_stride, device}``; 2- vs 3-level
+        by the presence of ``classes.super_coarse_names`` (``:139``).  ``training.{batch_size, epochs}`` and ``output.*``
+        are kept on the instance (``cfg``) for the caller's loop and ``checkpoint_path``.
+        The reference hard-codes ResNet-101 (``:155``) and ignores ``model.pretrained_model``; here ``depth`` (argument)
+        wins, else a ``resnet-<N>`` value of ``model.pretrained_model`` is honoured, else 101 -- the example config's
+        ``resnet-101`` gives the reference's model."""
+        if isinstance(cfg, (str, os.PathLike)):
+            cfg = load_config(cfg)
+        classes, training = cfg["classes"], cfg["training"]
+        n_fine, n_coarse = len(classes["fine_names"]), len(classes["coarse_names"])
+        has_super = "super_coarse_names" in classes
+        if len(classes["coarse_to_fine_map"]) != n_coarse:
+            raise ValueError("classes.coarse_to_fine_map must have one entry per coarse name")
+        if has_super and len(classes["super_coarse_to_coarse_map"]) != len(classes["super_coarse_names"]):
+            raise ValueError("classes.super_coarse_to_coarse_map must have one entry per super-coarse name")
+        if depth is None:
+            m = re.fullmatch(r"resnet-?(\d+)", str(cfg.get("model", {}).get("pretrained_model", "")).strip().lower())
+            depth = int(m.group(1)) if m else 101
+        if device is None:
+            device = training.get("device", "cuda")
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        rmi = {k: training.get(k, d) for k, d in (("rmi_radius", 3), ("rmi_pool_way", 0), ("rmi_pool_size", 3),
+                                                  ("rmi_pool_stride", 3))}
+        tr = cls(depth=depth, n_fine=n_fine, coarse_to_fine_map=classes["coarse_to_fine_map"], lr=training["lr"],
+                 fine_weight=training.get("fine_weight", 1.0), device=device, head_kw=head_kw, grad_sync=grad_sync,
+                 super_coarse_to_coarse_map=classes["super_coarse_to_coarse_map"] if has_super else None, **rmi)
+        tr.cfg = cfg
+        return tr
+
+    def checkpoint_path(self, epoch):
+        """``<output.checkpoint_dir>/<output.project_name>_epoch_<epoch>_best.pth`` (``train.py:430-433``)."""
+        out = self.cfg["output"]
+        return os.path.join(out["checkpoint_dir"], f"{out['project_name']}_epoch_{epoch}_best.pth")
+
     def __init__(self, depth=50, n_fine=9, coarse_to_fine_map=((0, 3), (4, 6), (7,), (8,)), lr=0.01, fine_weight=1.0,
-                 device="cuda:0", head_kw=None, grad_sync=None, super_coarse_to_coarse_map=None, rmi_radius=3):
+                 device="cuda:0", head_kw=None, grad_sync=None, super_coarse_to_coarse_map=None, rmi_radius=3,
+                 rmi_pool_way=0, rmi_pool_size=3, rmi_pool_stride=3):
         """``super_coarse_to_coarse_map`` given -> 3-level model + RMIHieraTripletLoss (train.py:202-233), else the
         2-level HieraTripletLoss (train.py:176-200)."""
         cfg_map = [list(x) for x in coarse_to_fine_map]
@@ -67,6 +120,8 @@ class SegHieroTrainer:
         else:   # train.py:226-233: loss_weight_lambda = training.fine_weight, loss_weight = 1.0
             self.hiera_loss_fn = RMIHieraTripletLoss(n_fine, self.n_coarse, self.n_super, build_fine_to_coarse_map(cfg_map, n_fine),
                                                      build_fine_to_super_map(sup_map, n_fine), rmi_radius=rmi_radius,
+                                                     rmi_pool_way=rmi_pool_way, rmi_pool_size=rmi_pool_size,
+                                                     rmi_pool_stride=rmi_pool_stride,
                                                      loss_weight_lambda=fine_weight, loss_weight=1.0)
         for m in (self.backbone, self.aspp_head, self.aux_head, self.hiera_loss_fn):
             m.to(self.device)
@@ -77,6 +132,7 @@ class SegHieroTrainer:
                                if isinstance(m, nn.Conv2d) and m.groups == 1 and m is not self.backbone.stem_conv]
         self.optimizer = FusedSGD(self.params, lr=lr, momentum=0.9, weight_decay=1e-4)
         self.grad_sync = grad_sync
+        self.cfg = None
 
     def modules(self):
         return {"backbone": self.backbone, "aspp_head": self.aspp_head, "aux_head": self.aux_head}

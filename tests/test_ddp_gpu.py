@@ -22,15 +22,16 @@ def _run(lo, hi, sync):
     from seghiero_amd.head import DepthwiseSeparableASPPContrastHead
     ops.SYNC_BN = sync
     torch.manual_seed(0)
-    bb = ResNetBackbone(depth=18).to("cuda:0").train()
-    head = DepthwiseSeparableASPPContrastHead(**HEAD_KW).to("cuda:0").train()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    bb = ResNetBackbone(depth=18).to(dev).train()
+    head = DepthwiseSeparableASPPContrastHead(**HEAD_KW).to(dev).train()
     g = torch.Generator().manual_seed(7)
     x = torch.randn(B, 3, S, S, generator=g)
-    x = x[lo:hi].to("cuda:0")                                    # the trunk never differentiates the image (stem dgrad skipped)
+    x = x[lo:hi].to(dev)                                         # the trunk never differentiates the image (stem dgrad skipped)
     logits, emb = head(bb(x))
     gl = torch.randn(B, *logits.shape[1:], generator=g)          # fixed per-image output weights of the full batch
     ge = torch.randn(B, *emb.shape[1:], generator=g)
-    ((logits * gl[lo:hi].to("cuda:0")).sum() + (emb * ge[lo:hi].to("cuda:0")).sum()).backward()
+    ((logits * gl[lo:hi].to(dev)).sum() + (emb * ge[lo:hi].to(dev)).sum()).backward()
     torch.cuda.synchronize()
     named = list(bb.named_parameters()) + list(head.named_parameters())
     return dict(logits=logits.detach().cpu().numpy(), emb=emb.detach().cpu().numpy(),
@@ -38,15 +39,27 @@ def _run(lo, hi, sync):
                 rm=bb.layer4[1].bn2.running_mean.cpu().numpy(), rv=head.sep_bottleneck[1].bn_pw.running_var.cpu().numpy())
 
 
-def _worker(rank, world, port, q):
+def _backends():
+    """gloo with both ranks on cuda:0 (host-staged rehearsal, runs on the one-GPU box) and, where the node has two GPUs,
+    RCCL ("nccl") with one device per rank."""
+    return ["gloo"] + (["nccl"] if torch.cuda.device_count() >= 2 else [])
+
+
+def _env(rank, world, port, backend):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      LOCAL_RANK=str(rank) if backend == "nccl" else "0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+
+
+def _worker(rank, world, port, q, backend="gloo", cuts=None):
+    _env(rank, world, port, backend)
     import torch.distributed as dist
     from seghiero_amd import ddp
-    ddp.init_from_env(backend="gloo")
-    n = B // world
+    ddp.init_from_env(backend=backend)
+    cuts = cuts or [r * (B // world) for r in range(world + 1)]
     try:
-        out = _run(rank * n, (rank + 1) * n, sync=True)
+        out = _run(cuts[rank], cuts[rank + 1], sync=True)
     except Exception as e:                                       # report instead of leaving the parent to time out
         import traceback
         out = "rank %d failed: %s\n%s" % (rank, e, traceback.format_exc())
@@ -61,14 +74,19 @@ def _rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
-def test_syncbn_two_ranks_equals_full_batch():
+@pytest.mark.parametrize("backend,cuts", [("gloo", None), ("gloo", [0, 3, 4]), ("nccl", None)])
+def test_syncbn_two_ranks_equals_full_batch(backend, cuts):
+    """cuts = [0, 3, 4]: rank 0 holds three images and rank 1 one -- the pixel counts travel with the sums, so uneven
+    shards give the full-batch statistics too."""
     if not torch.cuda.is_available():
         pytest.skip("needs the MI355X")
+    if backend not in _backends():
+        pytest.skip("two ranks over RCCL need two GPUs (RCCL refuses two ranks on one device)")
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29800 + os.getpid() % 150
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29800 + os.getpid() % 150 + (3 if cuts else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend, cuts)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=240) for _ in procs)
@@ -91,32 +109,33 @@ def test_syncbn_two_ranks_equals_full_batch():
     assert tot < 5e-4 and worst < 5e-3, (tot, worst)
 
 
-TR_KW = dict(depth=18, n_fine=4, coarse_to_fine_map=[[0, 1], [2, 3]], lr=0.01, device="cuda:0",
+TR_KW = dict(depth=18, n_fine=4, coarse_to_fine_map=[[0, 1], [2, 3]], lr=0.01,
              head_kw=dict(c1_channels=16, aspp_channels=32, dilations=(1, 2, 3, 4), proj_dim=16))
 
 
-def _train(n_steps, sync):
-    from seghiero_amd import ddp
+def _train(n_steps, sync, syncbn=False):
+    from seghiero_amd import ddp, ops
     from seghiero_amd.synthetic import make_batch
     from seghiero_amd.train_step import SegHieroTrainer
     torch.manual_seed(0)
-    tr = SegHieroTrainer(**TR_KW)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ops.SYNC_BN = syncbn
+    tr = SegHieroTrainer(device=dev, **TR_KW)
     if sync:
         ddp.broadcast_module_state(list(tr.modules().values()))
         tr.grad_sync = ddp.GradSync(tr.params, bucket_mb=4.0)
-    img, lab = make_batch(2, 64, 4, seed=5, device="cuda:0")
+    img, lab = make_batch(2, 64, 4, seed=5, device=dev)
     losses = [float(tr.train_step(img, lab, 0)) for _ in range(n_steps)]
     torch.cuda.synchronize()
     launched = len(tr.grad_sync.buckets) if sync else 0
     return losses, [p.detach().cpu().numpy().copy() for p in tr.params], launched
 
 
-def _ddp_worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _ddp_worker(rank, world, port, q, backend="gloo"):
+    _env(rank, world, port, backend)
     import torch.distributed as dist
     from seghiero_amd import ddp
-    ddp.init_from_env(backend="gloo")
+    ddp.init_from_env(backend=backend)
     try:
         out = _train(2, sync=True)
     except Exception as e:
@@ -128,14 +147,17 @@ def _ddp_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_ddp_two_ranks_same_batch_equals_single_rank():
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_ddp_two_ranks_same_batch_equals_single_rank(backend):
     if not torch.cuda.is_available():
         pytest.skip("needs the MI355X")
+    if backend not in _backends():
+        pytest.skip("two ranks over RCCL need two GPUs (RCCL refuses two ranks on one device)")
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29400 + os.getpid() % 150
-    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q, backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=240) for _ in procs)
@@ -150,3 +172,56 @@ def test_ddp_two_ranks_same_batch_equals_single_rank():
         assert l2 == losses, (rank, l2, losses)
         for a, b in zip(p2, params):
             np.testing.assert_array_equal(a, b)
+
+
+# ---------------------------------------------------------------- the RCCL code path itself, on the one-GPU box
+def _rccl_world1_worker(port, q):
+    """One rank, backend "nccl" (= RCCL): with ddp.FORCE_COLLECTIVES every collective of the N > 1 step is issued for real --
+    bucketed gradient all-reduce with async_op on the side stream straight from the arena views, the f64 SyncBN
+    all-reduces (sums + count) and the class_count MIN-reduce on the small-message group, the parameter broadcast."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        import torch.distributed as dist
+        from seghiero_amd import ddp
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        ddp.init_small_group()
+        ddp.FORCE_COLLECTIVES = True
+        assert dist.get_backend() == "nccl" and dist.get_backend(ddp.small_group()) == "nccl"
+        t = torch.tensor([3.0, 5.0, 7.0], device="cuda:0", dtype=torch.float64)
+        ddp.all_reduce_small(t)                                         # f64 SUM through RCCL
+        r = torch.tensor([2.0], device="cuda:0")
+        ddp.all_reduce_small(r[0:1], op=dist.ReduceOp.MIN)               # MIN on a 1-element slice
+        assert t.tolist() == [3.0, 5.0, 7.0] and r.item() == 2.0
+        out = {"plain": _train(2, sync=True), "syncbn": _train(2, sync=True, syncbn=True)}
+        torch.cuda.synchronize()
+        ddp.shutdown()
+    except Exception as e:
+        import traceback
+        out = "rccl worker failed: %s\n%s" % (e, traceback.format_exc())
+    q.put(out)
+
+
+def test_rccl_backend_world1_runs_every_collective_of_the_step():
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1_worker, args=(29250 + os.getpid() % 150, q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(60)
+    assert not isinstance(res, str), res
+    losses, params, _ = _train(2, sync=False)
+    l2, p2, nb = res["plain"]
+    assert nb >= 3
+    assert l2 == losses                                  # an all-reduce over one rank is the identity: bit-equal training
+    for a, b in zip(p2, params):
+        np.testing.assert_array_equal(a, b)
+    # SyncBN finalizes from f64 global sums instead of the local centred partials: same statistics up to fp32 rounding
+    l3, p3, _ = res["syncbn"]
+    np.testing.assert_allclose(l3, losses, rtol=2e-5)
+    tot = _rel(np.concatenate([a.ravel() for a in p3]), np.concatenate([b.ravel() for b in params]))
+    assert tot < 1e-4, tot

@@ -53,6 +53,27 @@ def test_coarse_targets_bit_exact_g2(sa, tag):
 
 
 @pytest.mark.parametrize("tag", ["even", "odd"])
+def test_three_level_targets_bit_exact_g2(sa, tag):
+    """a14: the mid / high target maps of `_prepare_targets_three_level` (rmi_hiera_triplet_loss.py:21-63) as the HIP
+    kernel derives them, bit-exact against the reference's own output (G2)."""
+    _, loss, ops = sa
+    g = load_golden("g2_targets")
+    f2m, f2h = [0, 1, 1, 1, 1, 2, 2], [0, 1, 1, 1, 1, 1, 1]
+    l8 = T(g[f"{tag}_lab7"]).to(DEV)
+    n, h, w = l8.shape
+    z = ops.new_act(n, 12, h, w, DEV, zero=True)
+    _, _, _, (mid, high) = ops.hiera3_fwd(z, l8, 7, 3, 2, f2m, f2h, want_probs=False, want_targets=True)
+    assert mid.dtype == torch.uint8 and high.dtype == torch.uint8
+    assert np.array_equal(mid.cpu().numpy(), g[f"{tag}_mid"])
+    assert np.array_equal(high.cpu().numpy(), g[f"{tag}_high"])
+    # the module-level helper (same name as the reference's) returns int64 maps like the reference does
+    tf, tm, th = loss.prepare_targets_three_level(lab(g[f"{tag}_lab7"]).to(DEV), torch.tensor(f2m), torch.tensor(f2h))
+    assert tm.dtype == torch.int64 and np.array_equal(tm.cpu().numpy(), g[f"{tag}_mid"].astype(np.int64))
+    assert np.array_equal(th.cpu().numpy(), g[f"{tag}_high"].astype(np.int64))
+    assert np.array_equal(tf.cpu().numpy(), g[f"{tag}_lab7"].astype(np.int64))
+
+
+@pytest.mark.parametrize("tag", ["even", "odd"])
 def test_hiera_bce_and_ce_g4(sa, tag):
     _, loss, ops = sa
     g = load_golden("g4_two_level_parts")
@@ -198,6 +219,24 @@ def test_rmi_hiera_triplet_loss_g6(sa, tag, lam, step):
     ref = g[f"{key}_dz"]
     np.testing.assert_allclose(z.grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * float(np.abs(ref).max()))
     close(e.grad, g[f"{key}_demb"], 1e-4, 1e-8)
+
+
+@pytest.mark.parametrize("tag", ["even", "odd"])
+def test_rmi_per_channel_values_g6(sa, tag):
+    """The f64 core of the RMI term (Gram -> inverse -> Schur complement -> Cholesky log-det, :498-513): per-(image, channel)
+    rmi_now read back from the kernels' workspace against the reference's own f64 values (G6 `*_rmi_now`)."""
+    _, loss, ops = sa
+    g = load_golden("g6_rmi_hiera_triplet_loss")
+    z = ops.to_nhwc(T(g[f"{tag}_z"]).to(DEV))
+    l8 = T(g[f"{tag}_lab"]).to(DEV)
+    n, c, H, W = z.shape
+    _, _, probs = ops.hiera3_fwd(z, l8, 7, 3, 2, F2M, F2H, want_probs=True)
+    ops.rmi_loss(probs, l8, 7, 3, 2, F2M, F2H, want_grad=False)
+    got = ops.rmi_values(n, c, H, W, z.device).cpu().numpy()
+    ref = g[f"{tag}_rmi_now"]
+    assert got.dtype == np.float64 and ref.dtype == np.float64
+    # probs are f32 sigmoid values (1 ulp apart between libm implementations) feeding near-singular f64 Gram matrices
+    np.testing.assert_allclose(got, ref, rtol=1e-6, atol=0)
 
 
 def test_rmi_triplet_g7(sa):

@@ -195,6 +195,21 @@ def test_g6_rmi_hiera_triplet_loss(golden, tag, lam, step):
     np.testing.assert_allclose(e.grad.numpy(), g[f"{key}_demb"], rtol=1e-5, atol=1e-8)
 
 
+@pytest.mark.parametrize("tag", ["even", "odd"])
+def test_g6_rmi_now_per_channel_f64(golden, tag):
+    """The oracle's f64 per-(image, channel) rmi_now against the reference's own values (rmi_hiera_triplet_loss.py:513)."""
+    g = golden("g6_rmi_hiera_triplet_loss")
+    f2m, f2h = torch.tensor([0, 1, 1, 1, 1, 2, 2]), torch.tensor([0, 1, 1, 1, 1, 1, 1])
+    label = lab(g[f"{tag}_lab"])
+    tf, tm, th = losses.prepare_targets_three_level(label, f2m, f2h)
+    probs = torch.sigmoid(T(g[f"{tag}_z"]))
+    _, (oh_f, oh_m, oh_h) = losses.losses_hiera_three_level(probs, tf, tm, th, 7, 3, 2, f2m, f2h)
+    valid = torch.cat([(t != 255).unsqueeze(1).float().expand(-1, n, -1, -1) for t, n in ((tf, 7), (tm, 3), (th, 2))], 1)
+    _, rmi = losses.rmi_lower_bound(torch.cat([oh_f, oh_m, oh_h], 1), probs * valid + 1e-6, 3)
+    assert rmi.dtype == torch.float64
+    np.testing.assert_allclose(rmi.numpy(), g[f"{tag}_rmi_now"], rtol=1e-9, atol=0)
+
+
 def test_g7_rmi_triplet(golden):
     g = golden("g7_rmi_triplet")
     trip = losses.RMITreeTripletLoss(7, [1, 2, 3, 4], [5, 6])

@@ -221,6 +221,12 @@ def g5():
     save("g5_hiera_triplet_loss", **out)
 
 
+def _rec(orig, seen, m):
+    out = orig(m)
+    seen.append(out.detach().clone())
+    return out
+
+
 # ------------------------------------------------------------------ G6/G7 3-level RMI loss + triplet
 def g6():
     g = torch.Generator().manual_seed(6)
@@ -229,6 +235,11 @@ def g6():
     out = {}
     for lam in (0.0, 0.5):
         loss_fn = ref_h3.RMIHieraTripletLoss(7, 3, 2, f2m, f2h, loss_weight_lambda=lam)
+        # record rmi_now = 0.5 * log_det_by_cholesky(...) per (image, channel) in f64 (:509-513): harness-side wrapper of the
+        # bound method, the reference code itself runs unchanged
+        seen = []
+        orig_logdet = loss_fn.log_det_by_cholesky
+        loss_fn.log_det_by_cholesky = lambda m, _o=orig_logdet, _s=seen: _rec(_o, _s, m)
         for tag, (h, w, eh, ew) in {"even": (64, 64, 8, 8), "odd": (45, 37, 5, 4)}.items():
             gg = torch.Generator().manual_seed(60 + h)
             lab = blocky_labels(gg, 2, h, w, 7)
@@ -242,6 +253,8 @@ def g6():
                 val.backward()
                 key = f"{tag}_lam{lam}_s{step}"
                 out.update({f"{key}_loss": npy(val), f"{key}_dz": npy(z.grad), f"{key}_demb": npy(e.grad)})
+                assert seen[-1].dtype == torch.float64 and tuple(seen[-1].shape) == (2, 12)
+                out[f"{tag}_rmi_now"] = npy(0.5 * seen[-1])          # f64 [B, C]; independent of lambda and step
     save("g6_rmi_hiera_triplet_loss", **out)
     # G7: 3-level triplet alone
     trip = RefTriplet3(num_classes=7, upper_ids=[1, 2, 3, 4], lower_ids=[5, 6])
