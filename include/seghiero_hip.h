@@ -26,6 +26,7 @@ extern "C" {
 #define SH_OK 0
 #define SH_EINVAL (-1)
 #define SH_ELAUNCH (-2)
+#define SH_EUNSUPPORTED (-3)   /* fused entry points only: no fused instantiation for this geometry, nothing launched */
 
 /* library / device info ------------------------------------------------------------------- */
 int sh_abi_version(void);                       /* bumps when a signature changes */
@@ -89,6 +90,14 @@ int sh_conv_fprop_x6(const float* x, int ldx, const float* w, const float* bias,
 int sh_conv_fprop_x6_act(const float* x, int ldx, const float* w, const float* scale, const float* shift,
                          const float* residual, int ldr, int relu, float* out, int ldo, int N, int H, int W,
                          int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, void* stream);
+/* Training forward reading its input THROUGH the producer's BatchNorm + ReLU: x is the RAW output of the previous convolution
+ * and the loader applies relu(x * in_scale[c] + in_shift[c]) (sh_bn_act's own operation order; zero padding stays zero), so the
+ * activated tensor of every conv -> BN -> ReLU -> conv chain (models/backbone/resnet.py:65-73,
+ * models/head/sep_aspp_contrast_head.py:56-61, 180-184) is never written or re-read.  in_scale / in_shift: [Cin], 16-byte aligned.
+ * SH_EUNSUPPORTED = no fused instantiation for this geometry (run sh_bn_act, then sh_conv_fprop_x6). */
+int sh_conv_fprop_x6_aff(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* w,
+                         const float* bias, float* y, int ldy, float* stat_partials, int N, int H, int W, int Cin, int Cout,
+                         int KH, int KW, int stride, int pad, int dil, float* workspace, int64_t workspace_bytes, void* stream);
 int sh_weight_transpose(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream);
 /* ... for n <= SH_WT_MAX weights in one launch (taps = KH*KW); the training step prepares all dgrad operands at once. */
 #define SH_WT_MAX 40
@@ -98,11 +107,26 @@ int sh_conv_dgrad_x6(const float* dy, int lddy, const float* wt, const float* ad
                      float* dx, int lddx, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                      int stride, int pad, int dil, int mode, float* workspace, int64_t workspace_bytes,
                      void* stream);
+/* Input gradient + the front half of the BatchNorm backward of the layer that produced the conv's input (conv -> BN [-> ReLU]
+ * -> this conv): stores g = relumask(y_prev*scale + shift) * (dx [+ addend]) instead of dx and emits (sum g, sum g*xhat) per 64
+ * rows into stat_partials[ceil(N*H*W/64)][2][Cin], i.e. what sh_bn_bwd_reduce would compute from dx and y_prev in a separate
+ * pass (torch.nn.BatchNorm2d backward of resnet.py:65-73 / sep_aspp_contrast_head.py:56-61); finish with sh_bn_bwd_finalize and
+ * sh_bn_bwd_apply(relu = 0) on g.  y_prev: raw output of the producer conv [N*H*W][ldyp]; mean / invstd / scale / shift: its
+ * BatchNorm coefficients [Cin]; relu: 0 / 1.  Stride-1 geometries only; SH_EUNSUPPORTED otherwise. */
+int sh_conv_dgrad_x6_bnb(const float* dy, int lddy, const float* wt, const float* addend, int ldadd, float* g, int ldg,
+                         const float* y_prev, int ldyp, const float* mean, const float* invstd, const float* scale,
+                         const float* shift, int relu, float* stat_partials, int N, int H, int W, int Cin, int Cout,
+                         int KH, int KW, int stride, int pad, int dil, float* workspace, int64_t workspace_bytes, void* stream);
 int64_t sh_conv_wgrad_x6_workspace(int N, int H, int W, int Cin, int Cout, int KH, int KW,
                                    int stride, int pad, int dil);
 int sh_conv_wgrad_x6(const float* x, int ldx, const float* dy, int lddy, float* dw, float* workspace,
                      int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                      int dil, void* stream);
+/* ... of a conv whose input is read through the producer's BatchNorm + ReLU (see sh_conv_fprop_x6_aff): x = raw output of
+ * the previous convolution, loader applies relu(x * in_scale[c] + in_shift[c]).  SH_EUNSUPPORTED: output width < 16. */
+int sh_conv_wgrad_x6_aff(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* dy, int lddy,
+                         float* dw, float* workspace, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                         int stride, int pad, int dil, void* stream);
 
 /* depthwise 3x3 (groups = C), stride 1, padding = dilation ---------------------------------- */
 /* Replaces DepthwiseSeparableConv.depthwise (models/head/sep_aspp_contrast_head.py:43-46, :56).

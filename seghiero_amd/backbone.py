@@ -74,7 +74,8 @@ def _block_fwd(blk, x, training):
     h = x
     for i, (conv, bn) in enumerate(chain):
         last = i == len(chain) - 1
-        h, rec = L.cba_fwd(h, conv.weight, L.conv_geom(conv), bn, True, training, residual=idt if last else None)
+        # inner convs hand their BatchNorm + ReLU to the next conv's loader (Lazy); the block output (+ identity) is materialised
+        h, rec = L.cba_fwd(h, conv.weight, L.conv_geom(conv), bn, True, training, residual=idt if last else None, lazy=not last)
         recs.append(rec)
     return h, (recs, ds_rec)
 

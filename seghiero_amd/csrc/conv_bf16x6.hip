@@ -11,79 +11,7 @@
 // three bf16 LDS planes per operand ([row][32 k], 64-byte rows with an XOR-swizzled 16-byte chunk: conflict-free reads).  FPROP and
 // DGRAD have K-contiguous operands (DGRAD reads a per-step transposed weight copy [tap][ci][co]); WGRAD's operands are
 // pixel-major, so its planes are stored [k][m] and the fragments are read with ds_read_b64_tr_b16 (hardware transpose).
-#include "common.h"
-#include <stdlib.h>
-
-enum { FPROP = 0, DGRAD = 1 };
-
-struct ConvQ {
-    const float* a;
-    const float* b;
-    float* c;
-    const float* extra;     // fprop: bias[Cout] ; dgrad: addend[M][ldadd]
-    float* partials;
-    long long lda, ldb, ldc, ldadd;
-    int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, dil;
-    int M, Nn, K, Kc;       // Kc = channels per tap along K (Cin for fprop, padded Cout for dgrad)
-    int Kp;                 // row length (in k) of the pre-split B planes (multiple of 32)
-    int Kreal;              // channels actually present per tap in the A rows (dgrad: pad4(Cout); fprop: Cin)
-    long long bplane;       // elements per B plane
-    int scatter, sH, sW, sstride;
-    int parity;             // dgrad of a stride-2 KxK conv: blockIdx.y = input-pixel parity class (only its taps are non-zero)
-    int kchunk;
-    int tiles_m, tiles_n, n_partials;
-    const float* act_scale; // ACT instantiations: per-output-channel scale / shift, optional residual (stride ldadd), ReLU flag
-    const float* act_shift;
-    const float* act_res;
-    int act_relu;
-    int ksplit;             // fprop / dgrad split-K: blockIdx.y = K slice, raw accumulators go to slab[ksplit][M][ldslab]
-    float* slab;
-    long long ldslab;
-};
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-
-// exact 3-way split of 4 floats -> three packed bf16x4 (8 bytes each)
-__device__ __forceinline__ void split4(const f32x4 v, u32x2& p1, u32x2& p2, u32x2& p3) {
-    unsigned h1[4], h2[4], h3[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const unsigned u = __float_as_uint(v[j]);
-        const float r1 = v[j] - __uint_as_float(u & 0xffff0000u);
-        const unsigned u2 = __float_as_uint(r1);
-        const float r2 = r1 - __uint_as_float(u2 & 0xffff0000u);
-        h1[j] = u; h2[j] = u2; h3[j] = __float_as_uint(r2);
-    }
-    // perm(S0, S1, 0x07060302) = (S0 & 0xffff0000) | (S1 >> 16): element j in the low half, j+1 in the high half
-    p1[0] = __builtin_amdgcn_perm(h1[1], h1[0], 0x07060302u); p1[1] = __builtin_amdgcn_perm(h1[3], h1[2], 0x07060302u);
-    p2[0] = __builtin_amdgcn_perm(h2[1], h2[0], 0x07060302u); p2[1] = __builtin_amdgcn_perm(h2[3], h2[2], 0x07060302u);
-    p3[0] = __builtin_amdgcn_perm(h3[1], h3[0], 0x07060302u); p3[1] = __builtin_amdgcn_perm(h3[3], h3[2], 0x07060302u);
-}
-
-// LDS rows of a K-contiguous plane are 64 bytes (32 bf16) with the 16-byte k-chunk XOR-swizzled by (row >> 2) & 3: the 16
-// lanes of every ds_read_b128 lane group ({0-3,12-15,20-27}, ...) then cover all 64 banks once, and the ds_write_b64 of 16
-// consecutive lanes (2 rows) covers the 32 store banks once -- conflict-free without padding (20 % less LDS than 80-byte rows).
-#define ROWB 64
-#define ROWB_G 80          // gemm_x6_kernel keeps padded rows (64 data + 16 pad)
-
-// six-product accumulate of one 32x32 tile over K=16
-__device__ __forceinline__ f32x16 mma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c) {
-    c = mfma_bf16(a[2], b[0], c);      // smallest terms first
-    c = mfma_bf16(a[0], b[2], c);
-    c = mfma_bf16(a[1], b[1], c);
-    c = mfma_bf16(a[1], b[0], c);
-    c = mfma_bf16(a[0], b[1], c);
-    c = mfma_bf16(a[0], b[0], c);
-    return c;
-}
+#include "conv_x6.h"
 
 // ============================================================================================ FPROP / DGRAD
 // Block = WGM x WGN waves, each wave TM x TN MFMA tiles of 32x32: block tile (32*TM*WGM) x (32*TN*WGN).
@@ -865,10 +793,13 @@ extern "C" int sh_weight_transpose_multi(int n, const float* const* w, float* co
 }
 
 // Split-K reduce for fprop / dgrad: out[m][n] = sum_s slab[s][m][n] (+ bias[n] | + addend[m][n]); for fprop also the BN
-// statistics of the conv epilogue (centred (sum, M2) per 64 rows).  Block = 64 rows x 64 columns, thread = 4 rows x 4 columns.
+// statistics of the conv epilogue (centred (sum, M2) per 64 rows); for dgrad optionally the front half of the producer layer's
+// BatchNorm backward (BNB: g = relumask * dx stored, (sum g, sum g*xhat) per 64 rows -> partials, see conv_x6p.hip).
+// Block = 64 rows x 64 columns, thread = 4 rows x 4 columns.
+struct BnbQ { const float* y; long long ldy; const float* mean; const float* invstd; const float* scale; const float* shift; int relu; };
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, long long ldslab, int S, long long M, int Nn,
                                                             const float* __restrict__ bias, const float* __restrict__ addend, long long ldadd,
-                                                            float* __restrict__ out, long long ldc, float* __restrict__ partials) {
+                                                            float* __restrict__ out, long long ldc, float* __restrict__ partials, const BnbQ bnb) {
     __shared__ float red[16][64];
     __shared__ float colmean[64];
     const int t = threadIdx.x, cq = t & 15, rl = t >> 4;
@@ -877,6 +808,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     const int npr = (int)(M - row0 < 64 ? M - row0 : 64);
     f32x4 v[4];
     const bool nok = n < Nn;                 // Nn % 4 == 0 on this path
+    f32x4 gq = {0.f, 0.f, 0.f, 0.f};
+    f32x4 b_mu = gq, b_is = gq, b_sc = gq, b_sh = gq;
+    if (bnb.y != nullptr && nok) { b_mu = ld4(bnb.mean + n); b_is = ld4(bnb.invstd + n); b_sc = ld4(bnb.scale + n); b_sh = ld4(bnb.shift + n); }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const long long m = row0 + rl + 16 * k;
@@ -886,6 +820,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             f32x4 o = v[k];
             if (bias) o += ld4(bias + n);
             if (addend) o += ld4(addend + m * ldadd + n);
+            if (bnb.y != nullptr) {
+                const f32x4 yv = ld4(bnb.y + m * bnb.ldy + n);
+                if (bnb.relu) {
+                    const f32x4 a = yv * b_sc + b_sh;                    // the forward's own arithmetic (bn_act_kernel)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (!(a[j] > 0.f)) o[j] = 0.f;
+                }
+                v[k] = o;                                                // statistics of g, not of the raw sum
+                gq += o * ((yv - b_mu) * b_is);
+            }
             st4(out + m * ldc + n, o);
         }
     }
@@ -903,12 +847,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
     __syncthreads();
     f32x4 q = {0.f, 0.f, 0.f, 0.f};
+    if (bnb.y != nullptr) q = gq;                              // BNB: plain sum of g * xhat
+    else {
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (row0 + rl + 16 * k < M) {
+        for (int k = 0; k < 4; ++k)
+            if (row0 + rl + 16 * k < M) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const float d = v[k][j] - colmean[cq * 4 + j]; q[j] += d * d; }
-        }
+                for (int j = 0; j < 4; ++j) { const float d = v[k][j] - colmean[cq * 4 + j]; q[j] += d * d; }
+            }
+    }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) red[rl][cq * 4 + j] = q[j];
@@ -919,6 +866,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         for (int k = 0; k < 16; ++k) a += red[k][t];
         partials[((long long)blockIdx.x * 2 + 1) * Nn + blockIdx.y * 64 + t] = a;
     }
+}
+// reduce launch shared with conv_x6p.hip
+int sh_x6_splitk_reduce(const ConvQ& p, int mode, hipStream_t st) {
+    dim3 rg((unsigned)sh_cdiv(p.M, 64), (unsigned)sh_cdiv(p.Nn, 64));
+    BnbQ bnb{p.bnb_y, p.bnb_ldy, p.bnb_mean, p.bnb_invstd, p.bnb_scale, p.bnb_shift, p.bnb_relu};
+    splitk_reduce_kernel<<<rg, 256, 0, st>>>(p.slab, p.ldslab, p.ksplit, p.M, p.Nn, mode == FPROP ? p.extra : nullptr,
+                                             mode == DGRAD ? p.extra : nullptr, p.ldadd, p.c, p.ldc,
+                                             (mode == FPROP || p.bnb_y != nullptr) ? p.partials : nullptr, bnb);
+    return sh_launch_status();
 }
 // K slices for an under-filled grid: the mid-network shapes (M*N small, K long) give < 2 blocks per CU with 128x128 tiles.
 static int splitk_plan(long long M, long long N, long long K, int parity, int scatter) {
@@ -944,11 +900,7 @@ static int launch_x6(ConvQ& p, hipStream_t st) {
     p.tiles_n = (int)sh_cdiv(p.Nn, BN);
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), p.parity ? 4u : (SK ? (unsigned)p.ksplit : 1u));
     conv_x6_kernel<MODE, TM, TN, WGM, WGN, OCC, SK, PROF, ACT><<<grid, 64 * WGM * WGN, lds, st>>>(p);
-    if (SK) {
-        dim3 rg((unsigned)sh_cdiv(p.M, 64), (unsigned)sh_cdiv(p.Nn, 64));
-        splitk_reduce_kernel<<<rg, 256, 0, st>>>(p.slab, p.ldslab, p.ksplit, p.M, p.Nn, MODE == FPROP ? p.extra : nullptr,
-                                                 MODE == DGRAD ? p.extra : nullptr, p.ldadd, p.c, p.ldc, MODE == FPROP ? p.partials : nullptr);
-    }
+    if (SK) return sh_x6_splitk_reduce(p, MODE, st);
     return sh_launch_status();
 }
 static int x6_variant() { static int v = -1; if (v < 0) { const char* e = getenv("SEGHIERO_X6_VARIANT"); v = e ? atoi(e) : 0; } return v; }
@@ -1054,6 +1006,24 @@ static void use_splitk(ConvQ& p, float* workspace, int64_t workspace_bytes) {
     const int S = splitk_plan(p.M, p.Nn, p.K, p.parity, p.scatter);
     if (S > 1 && workspace && workspace_bytes >= (int64_t)S * p.M * p.Nn * 4) { p.ksplit = S; p.slab = workspace; p.ldslab = p.Nn; }
 }
+// byte extents of the operands for the buffer descriptors of the pipelined kernels; false = too large for 32-bit offsets
+static bool operand_extents(ConvQ& p, int mode) {
+    long long a, b;
+    if (mode == FPROP) { a = ((long long)p.N * p.H * p.W - 1) * p.lda + p.Cin; b = (long long)p.Cout * p.K; }
+    else { a = ((long long)p.N * p.Ho * p.Wo - 1) * p.lda + p.Kc; b = (long long)p.KH * p.KW * p.Cin * p.Kc; }
+    if (a * 4 >= (1ll << 31) || b * 4 >= (1ll << 31)) return false;
+    p.a_bytes = (unsigned)(a * 4); p.b_bytes = (unsigned)(b * 4);
+    return true;
+}
+// pipelined kernel (conv_x6p.hip) where it has an instantiation for the shape, else conv_x6_kernel
+static int launch_fprop_any(ConvQ& p, hipStream_t st) {
+    if (operand_extents(p, FPROP)) { const int rc = sh_x6p_launch(FPROP, p, st); if (rc != SH_X6P_NO) return rc; }
+    return launch_conv_x6<FPROP>(p, st);
+}
+static int launch_dgrad_any(ConvQ& p, hipStream_t st) {
+    if (operand_extents(p, DGRAD)) { const int rc = sh_x6p_launch(DGRAD, p, st); if (rc != SH_X6P_NO) return rc; }
+    return launch_conv_x6<DGRAD>(p, st);
+}
 extern "C" int sh_conv_fprop_x6(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, float* stat_partials,
                                 int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil,
                                 float* workspace, int64_t workspace_bytes, void* stream) {
@@ -1064,7 +1034,26 @@ extern "C" int sh_conv_fprop_x6(const float* x, int ldx, const float* w, const f
     p.M = N * p.Ho * p.Wo; p.Nn = Cout; p.K = KH * KW * Cin; p.Kc = Cin;
     p.n_partials = (int)sh_cdiv(p.M, 64);
     if ((ldy & 3) == 0 && ((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0)) use_splitk(p, workspace, workspace_bytes);
-    return launch_conv_x6<FPROP>(p, (hipStream_t)stream);
+    return launch_fprop_any(p, (hipStream_t)stream);
+}
+// The same convolution reading its input through the producer's BatchNorm + ReLU: x holds the RAW output of the previous
+// convolution and the loader applies relu(x * in_scale[c] + in_shift[c]) on the way to LDS (zero padding stays zero), so the
+// activated tensor of conv -> BN -> ReLU -> conv chains (models/backbone/resnet.py:65-73, sep_aspp_contrast_head.py:56-61,180-184)
+// is never materialised.  SH_EUNSUPPORTED: this geometry has no fused instantiation (caller applies sh_bn_act first).
+extern "C" int sh_conv_fprop_x6_aff(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* w, const float* bias,
+                                    float* y, int ldy, float* stat_partials, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                    int stride, int pad, int dil, float* workspace, int64_t workspace_bytes, void* stream) {
+    ConvQ p{};
+    if (!x || !w || !y || !in_scale || !in_shift || !geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil)) return SH_EINVAL;
+    if (ldx < Cin || ldy < Cout || (ldx & 3) || (((uintptr_t)in_scale | (uintptr_t)in_shift) & 15)) return SH_EINVAL;
+    p.a = x; p.b = w; p.c = y; p.extra = bias; p.partials = stat_partials; p.lda = ldx; p.ldc = ldy;
+    p.M = N * p.Ho * p.Wo; p.Nn = Cout; p.K = KH * KW * Cin; p.Kc = Cin;
+    p.n_partials = (int)sh_cdiv(p.M, 64);
+    p.aff_scale = in_scale; p.aff_shift = in_shift;
+    if ((ldy & 3) == 0 && ((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0)) use_splitk(p, workspace, workspace_bytes);
+    if (!operand_extents(p, FPROP)) return SH_EUNSUPPORTED;
+    const int rc = sh_x6p_launch(FPROP, p, (hipStream_t)stream);
+    return rc == SH_X6P_NO ? SH_EUNSUPPORTED : rc;
 }
 extern "C" int sh_conv_fprop_x6_act(const float* x, int ldx, const float* w, const float* scale, const float* shift, const float* residual,
                                     int ldr, int relu, float* out, int ldo, int N, int H, int W, int Cin, int Cout, int KH, int KW,
@@ -1102,7 +1091,34 @@ extern "C" int sh_conv_dgrad_x6(const float* dy, int lddy, const float* wt, cons
     } else return SH_EINVAL;
     if ((lddx & 3) == 0 && ((uintptr_t)dx & 15) == 0 && (!addend || ((ldadd & 3) == 0 && ((uintptr_t)addend & 15) == 0)))
         use_splitk(p, workspace, workspace_bytes);
-    return launch_conv_x6<DGRAD>(p, (hipStream_t)stream);
+    return launch_dgrad_any(p, (hipStream_t)stream);
+}
+// Input gradient + the front half of the BatchNorm backward of the layer that PRODUCED the conv's input (conv -> BN [-> ReLU] -> this
+// conv): instead of dx the kernel stores g = relumask(y_prev * scale + shift) * (dx [+ addend]) and emits (sum g, sum g * xhat) per
+// 64 rows into stat_partials[ceil(M/64)][2][Cin] -- the statistics pass of that BatchNorm's backward (sh_bn_bwd_reduce) and its
+// re-read of dx and y disappear; sh_bn_bwd_finalize + sh_bn_bwd_apply(relu = 0) on g finish the job.
+// y_prev: raw output of the producer conv [N*H*W][ldyp]; mean / invstd / scale / shift: its BatchNorm coefficients [Cin].
+// SH_EUNSUPPORTED: no fused instantiation for this geometry (strided KxK / scatter); the caller runs the unfused sequence.
+extern "C" int sh_conv_dgrad_x6_bnb(const float* dy, int lddy, const float* wt, const float* addend, int ldadd, float* g, int ldg,
+                                    const float* y_prev, int ldyp, const float* mean, const float* invstd, const float* scale,
+                                    const float* shift, int relu, float* stat_partials, int N, int H, int W, int Cin, int Cout,
+                                    int KH, int KW, int stride, int pad, int dil, float* workspace, int64_t workspace_bytes, void* stream) {
+    ConvQ p{};
+    if (!dy || !wt || !g || !y_prev || !mean || !invstd || !scale || !shift || !stat_partials ||
+        !geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil)) return SH_EINVAL;
+    const int CoutP = (Cout + 3) & ~3;
+    if (lddy < CoutP || (lddy & 3) || ldg < Cin || ldyp < Cin || (addend && ldadd < Cin)) return SH_EINVAL;
+    if (stride != 1) return SH_EUNSUPPORTED;
+    p.a = dy; p.b = wt; p.c = g; p.extra = addend; p.ldadd = ldadd; p.lda = lddy; p.ldc = ldg;
+    p.Nn = Cin; p.Kc = CoutP; p.K = KH * KW * CoutP; p.M = N * H * W;
+    p.partials = stat_partials; p.n_partials = (int)sh_cdiv(p.M, 64);
+    p.bnb_y = y_prev; p.bnb_ldy = ldyp; p.bnb_mean = mean; p.bnb_invstd = invstd; p.bnb_scale = scale; p.bnb_shift = shift; p.bnb_relu = relu;
+    const bool al = ((ldg | ldyp) & 3) == 0 && (((uintptr_t)g | (uintptr_t)y_prev | (uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)scale |
+                                                 (uintptr_t)shift) & 15) == 0 && (!addend || ((ldadd & 3) == 0 && ((uintptr_t)addend & 15) == 0));
+    if (al) use_splitk(p, workspace, workspace_bytes);
+    if (!operand_extents(p, DGRAD)) return SH_EUNSUPPORTED;
+    const int rc = sh_x6p_launch(DGRAD, p, (hipStream_t)stream);
+    return rc == SH_X6P_NO ? SH_EUNSUPPORTED : rc;
 }
 
 struct WgX6Plan { int wgm, wgn, splits, kchunk, per_xcd; };
@@ -1169,26 +1185,47 @@ static int launch_wgrad_x6(ConvQ& p, int splits, hipStream_t st) {
     conv_wgrad_x6_kernel<WGM, WGN><<<grid, 64 * WGM * WGN, lds, st>>>(p);
     return sh_launch_status();
 }
-extern "C" int sh_conv_wgrad_x6(const float* x, int ldx, const float* dy, int lddy, float* dw, float* workspace, int N, int H, int W,
-                                int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, void* stream) {
+static int wgrad_x6_any(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* dy, int lddy, float* dw,
+                        float* workspace, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, void* stream) {
     ConvQ p{};
     if (!x || !dy || !dw || !workspace || !geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil)) return SH_EINVAL;
     if (lddy < ((Cout + 3) & ~3) || (lddy & 3) || ldx < Cin || (ldx & 3)) return SH_EINVAL;
     p.a = dy; p.b = x; p.c = workspace; p.lda = lddy; p.ldb = ldx;
     p.M = Cout; p.Nn = KH * KW * Cin; p.K = N * p.Ho * p.Wo;
+    p.aff_scale = in_scale; p.aff_shift = in_shift;
     const WgX6Plan g = wgrad_plan_x6(Cout, p.Nn, p.K);
     p.kchunk = g.kchunk;
     p.scatter = g.per_xcd;              // (field reused) block -> (slice, tile) mapping, see the kernel
     hipStream_t st = (hipStream_t)stream;
-    int rc;
-    if (g.wgm == 4 && g.wgn == 1) rc = launch_wgrad_x6<4, 1>(p, g.splits, st);
-    else if (g.wgm == 2 && g.wgn == 1) rc = launch_wgrad_x6<2, 1>(p, g.splits, st);
-    else if (g.wgm == 2 && g.wgn == 4) rc = launch_wgrad_x6<2, 4>(p, g.splits, st);
-    else if (g.wgm == 1 && g.wgn == 4) rc = launch_wgrad_x6<1, 4>(p, g.splits, st);
-    else if (g.wgm == 1 && g.wgn == 2) rc = launch_wgrad_x6<1, 2>(p, g.splits, st);
-    else rc = launch_wgrad_x6<2, 2>(p, g.splits, st);
+    int rc = SH_X6P_NO;
+    const long long ab = (((long long)p.K - 1) * lddy + ((Cout + 3) & ~3)) * 4, bb = (((long long)N * H * W - 1) * ldx + Cin) * 4;
+    if (ab < (1ll << 31) && bb < (1ll << 31)) {
+        p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
+        rc = sh_x6p_wgrad_launch(p, g.wgm, g.wgn, g.splits, st);
+    }
+    if (rc == SH_X6P_NO) {
+        if (in_scale) return SH_EUNSUPPORTED;
+        if (g.wgm == 4 && g.wgn == 1) rc = launch_wgrad_x6<4, 1>(p, g.splits, st);
+        else if (g.wgm == 2 && g.wgn == 1) rc = launch_wgrad_x6<2, 1>(p, g.splits, st);
+        else if (g.wgm == 2 && g.wgn == 4) rc = launch_wgrad_x6<2, 4>(p, g.splits, st);
+        else if (g.wgm == 1 && g.wgn == 4) rc = launch_wgrad_x6<1, 4>(p, g.splits, st);
+        else if (g.wgm == 1 && g.wgn == 2) rc = launch_wgrad_x6<1, 2>(p, g.splits, st);
+        else rc = launch_wgrad_x6<2, 2>(p, g.splits, st);
+    }
     if (rc != SH_OK) return rc;
     const long long n = (long long)Cout * p.Nn, n4 = n / 4;
     slab_reduce_x6_kernel<<<(unsigned)sh_cdiv(n4, 64), 256, 0, st>>>(workspace, dw, n4, n, g.splits);
     return sh_launch_status();
+}
+extern "C" int sh_conv_wgrad_x6(const float* x, int ldx, const float* dy, int lddy, float* dw, float* workspace, int N, int H, int W,
+                                int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, void* stream) {
+    return wgrad_x6_any(x, ldx, nullptr, nullptr, dy, lddy, dw, workspace, N, H, W, Cin, Cout, KH, KW, stride, pad, dil, stream);
+}
+// Weight gradient of a conv whose input is read THROUGH the producer's BatchNorm + ReLU (see sh_conv_fprop_x6_aff): x holds the raw
+// output of the previous convolution, the loader applies relu(x * in_scale[c] + in_shift[c]).  SH_EUNSUPPORTED: output width < 16.
+extern "C" int sh_conv_wgrad_x6_aff(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* dy, int lddy,
+                                    float* dw, float* workspace, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                                    int pad, int dil, void* stream) {
+    if (!in_scale || !in_shift || (((uintptr_t)in_scale | (uintptr_t)in_shift) & 15)) return SH_EINVAL;
+    return wgrad_x6_any(x, ldx, in_scale, in_shift, dy, lddy, dw, workspace, N, H, W, Cin, Cout, KH, KW, stride, pad, dil, stream);
 }

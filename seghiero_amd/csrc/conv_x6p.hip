@@ -1,0 +1,675 @@
+// Software-pipelined fprop / dgrad kernels of the "6 x bf16 split" convolution path (see conv_bf16x6.hip for the arithmetic).
+//
+// Why a second main loop.  conv_x6_kernel stages one K=32 tile at a time through a single LDS buffer: every wave computes,
+// barrier, every wave waits for its global loads, splits fp32 -> 3 x bf16 and stores, barrier.  Measured with s_memtime
+// (round 1): the matrix pipe idles 38 % of the K loop -- all waves of the block are in the split / store phase (pure
+// VALU + LDS writes) at the same time, and both barriers and the load wait are exposed.  Here a K=32 tile is handled as two
+// K=16 half-tiles that live in the two k-halves of the SAME LDS image (same 64-byte rows, same swizzle family, no extra LDS):
+//
+//     phase j :  split + store half-tile j+1 (registers -> LDS half (j+1)&1)      VALU + ds_write
+//                issue the global loads of half-tile j+3 (-> the register set just freed)   VMEM
+//                ds_read fragments of half-tile j (LDS half j&1), TM*TN*6 MFMAs            LDS + MFMA
+//                ONE barrier
+//
+// The three streams of a phase are independent, so they sit in one basic block and interleave: the split of the next half-tile
+// runs in the issue shadow of this half-tile's MFMAs (an MFMA holds the vector issue port 8 of its 32 cycles), global loads
+// have two full phases to land, and there is one barrier per K=16 instead of two per K=32.
+// Loader mapping: thread = (row, 16-byte k chunk of a half-tile); the two half-tiles of a 128-byte line are fetched by the
+// same thread in consecutive phases.
+//
+// Fused BatchNorm hooks (the reason the loaders go through registers at all):
+//   AFF : A operand = relu(x * scale[c] + shift[c]) applied in the loader -- the producer's train-mode BatchNorm + ReLU
+//         (reference: every conv -> BN -> ReLU -> conv chain, models/backbone/resnet.py:65-73, sep_aspp_contrast_head.py:56-61),
+//         so the activated tensor is never written or re-read; zero padding stays an exact zero AFTER the activation.
+//   EPI == 1 : fprop epilogue emits the centred BatchNorm (sum, M2) partials per 64 rows (as conv_x6_kernel).
+//   EPI == 2 : dgrad epilogue is the front half of the BatchNorm backward of the producer layer: g = relumask * dx is stored and
+//              (sum g, sum g * xhat) per 64 rows are emitted, so no separate statistics pass reads dx and y again.
+#include "conv_x6.h"
+
+// 16-byte k-chunk swizzle of a 64-byte LDS row: (row>>2)&3 keeps the 16 lanes of every ds_read_b128 lane group on distinct
+// banks (as in conv_x6_kernel); the extra (row & 2) term swaps the two k-halves on every other row pair so that the 16 lanes of
+// a ds_write_b64 group -- 4 consecutive rows x the 4 chunks-halves of ONE k-half -- cover all 32 store banks once.
+__device__ __forceinline__ int swz_row(int row) { return ((row >> 2) & 3) ^ (row & 2); }
+
+// TAP: 0 = 1x1 (one tap), 1 = KxK with Kc % 16 == 0 (a half-tile never straddles taps: scalar tap math, switched by a block-uniform
+// branch at the start of a phase), 2 = general (per-lane tap; stem 7x7 with 4 channels)
+template <int MODE, int TM, int TN, int WGM, int WGN, int WPS, int AFF, int EPI, int SK, int TAP>
+__global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const ConvQ p) {
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
+    constexpr int A_PLANE = BM * ROWB, B_PLANE = BN * ROWB;      // bytes
+    constexpr int RPP = NT / 4;                                  // rows covered per loader pass (4 lanes x 16 B per half-tile row)
+    constexpr int NA = BM / RPP, NB = BN / RPP;
+    static_assert(BM % RPP == 0 && BN % RPP == 0 && RPP % 64 == 0, "tile / thread-count mismatch");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const As = smem;
+    unsigned char* const Bs = smem + 3 * A_PLANE;
+    float* const coef = reinterpret_cast<float*>(smem + 3 * (A_PLANE + B_PLANE));     // AFF: scale[Kc], shift[Kc]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WGN, wn = wave % WGN, l31 = lane & 31, h = lane >> 5;
+    const unsigned nblk = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+    const unsigned bid = xcd_remap(blockIdx.x, nblk);
+    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    int cy = 0, cx = 0, Hc = p.H, Wc = p.W, oy0 = 0, ox0 = 0, ntw = p.KW, Mc = p.M, Kt = p.K;
+    if constexpr (MODE == DGRAD) {
+        if (p.parity) {                                              // stride-2 KxK dgrad by input-parity class (see conv_x6_kernel)
+            cy = blockIdx.y >> 1; cx = blockIdx.y & 1;
+            oy0 = (cy + p.pad) & 1; ox0 = (cx + p.pad) & 1;
+            Hc = (p.H - oy0 + 1) >> 1; Wc = (p.W - ox0 + 1) >> 1;
+            const int nth = (p.KH - cy + 1) >> 1;
+            ntw = (p.KW - cx + 1) >> 1;
+            Mc = p.N * Hc * Wc; Kt = nth * ntw * p.Kc;
+            if (m0 >= Mc) return;                                    // block-uniform, before any barrier
+        }
+    }
+    int q_begin = 0, q_end = (Kt + 15) >> 4;                         // half-tiles of K=16
+    if constexpr (SK) {
+        const int per = ((q_end + p.ksplit - 1) / p.ksplit + 1) & ~1;            // whole K=32 tiles per slice
+        q_begin = min(q_end, (int)blockIdx.y * per); q_end = min(q_end, q_begin + per);
+    }
+    const int klim = min(Kt, 16 * q_end);                            // loads at k >= klim return zeros (per-lane compare: no scalar branch)
+    const int nq = (q_end - q_begin + 1) & ~1;                       // whole K=32 tiles: an odd tail half-tile is followed by a zero one
+    constexpr bool single_tap = TAP == 0, tap_uniform = TAP <= 1;
+
+    // Operands are fetched with raw buffer loads: 32-bit byte offsets against a wave-uniform descriptor, and an offset beyond
+    // num_records (padded taps, rows >= M, the K tail) returns zeros in hardware -- no branch and no select around any load, so
+    // a whole phase stays one basic block.  (The host side routes tensors of 2 GiB or more to conv_x6_kernel.)
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, p.b_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int kc = t & 3, r0 = t >> 2;
+    int a_y[NA], a_x[NA], a_nb[NA];
+    int b_row[NB];                                               // element offset of the B row (< 2^29)
+    unsigned b_ok[NB];                                           // validity as all-ones / zero masks: offsets are formed with
+    int cur_tap = -1;                                            // AND / OR only, nothing the compiler can turn into a branch
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int m = m0 + r0 + RPP * i;
+        if (m < Mc) {
+            if constexpr (MODE == FPROP) {
+                const int ow = m % p.Wo, q = m / p.Wo, oh = q % p.Ho, n = q / p.Ho;
+                a_y[i] = oh * p.stride - p.pad; a_x[i] = ow * p.stride - p.pad; a_nb[i] = n * p.H * p.W;
+            } else {
+                const int iwc = m % Wc, q = m / Wc, ihc = q % Hc, n = q / Hc;
+                const int ih = p.parity ? 2 * ihc + oy0 : ihc, iw = p.parity ? 2 * iwc + ox0 : iwc;
+                a_y[i] = ih + p.pad; a_x[i] = iw + p.pad; a_nb[i] = n * p.Ho * p.Wo;
+            }
+        } else { a_y[i] = -(1 << 28); a_x[i] = 0; a_nb[i] = 0; }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int j = n0 + r0 + RPP * i;
+        b_ok[i] = j < p.Nn ? ~0u : 0u;
+        b_row[i] = j * (MODE == FPROP ? p.K : p.Kc);
+    }
+    int a_off[NA];                                               // element offset of the A row for the current tap
+    unsigned a_ok[NA];
+    auto set_tap = [&](int tap) {
+        int kh, kw;
+        if (MODE == DGRAD && p.parity) { const int ty = tap / ntw; kh = cy + 2 * ty; kw = cx + 2 * (tap - ty * ntw); }
+        else { kh = tap / p.KW; kw = tap - kh * p.KW; }
+        const int dh = kh * p.dil, dw = kw * p.dil;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if constexpr (MODE == FPROP) {
+                const int ih = a_y[i] + dh, iw = a_x[i] + dw;
+                a_ok[i] = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? ~0u : 0u;
+                a_off[i] = (a_nb[i] + ih * p.W + iw) * (int)p.lda;
+            } else {
+                int th = a_y[i] - dh, tw = a_x[i] - dw;
+                bool ok = th >= 0 && tw >= 0;
+                if (p.stride > 1) {
+                    ok = ok && (th % p.stride == 0) && (tw % p.stride == 0);
+                    th /= p.stride; tw /= p.stride;
+                }
+                a_ok[i] = (ok && th < p.Ho && tw < p.Wo) ? ~0u : 0u;
+                a_off[i] = (a_nb[i] + th * p.Wo + tw) * (int)p.lda;
+            }
+        }
+    };
+    // tap of the half-tile whose loads are issued next (scalar when tap_uniform); switching taps is a (block-uniform) branch
+    // that is taken at the START of a phase so that the rest of the phase stays one basic block
+    auto prepare_tap = [&](int q) {
+        if constexpr (TAP == 1) {
+            const int tap = (16 * q) / p.Kc;
+            if (tap != cur_tap) { set_tap(tap); cur_tap = tap; }
+        }
+    };
+    if constexpr (TAP == 0) { set_tap(0); cur_tap = 0; }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    struct Regs { f32x4 a[NA]; f32x4 b[NB]; int cc; unsigned okm; };
+    auto load_half = [&](int q, Regs& R) {
+        const int kbase = 16 * q, k = kbase + 4 * kc;
+        int tap, cc;
+        if constexpr (single_tap) { tap = 0; cc = k; }
+        else if constexpr (tap_uniform) { tap = cur_tap; cc = k - tap * p.Kc; }
+        else { tap = k / p.Kc; cc = k - tap * p.Kc; set_tap(tap); }
+        const unsigned kok = (unsigned)((k - klim) >> 31);          // all ones while k < klim
+        int wtap = tap;
+        if (MODE == DGRAD && p.parity) { const int ty = tap / ntw; wtap = (cy + 2 * ty) * p.KW + cx + 2 * (tap - ty * ntw); }
+        R.cc = cc; R.okm = 0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const unsigned ok = kok & a_ok[i];
+            const unsigned voff = (((unsigned)(a_off[i] + cc) * 4u) & ok) | (OOB & ~ok);
+            R.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff, 0, 0));
+            if (AFF) R.okm |= ok & (1u << i);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            int off;
+            if constexpr (MODE == FPROP) off = b_row[i] + k;
+            else off = wtap * p.Cin * p.Kc + b_row[i] + cc;
+            const unsigned okb = kok & b_ok[i];
+            const unsigned voff = (((unsigned)off * 4u) & okb) | (OOB & ~okb);
+            R.b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, voff, 0, 0));
+        }
+    };
+    const int swz_w = swz_row(r0);                               // RPP is a multiple of 64: every row of this thread has r0's low bits
+    auto store_half = [&](Regs& R, int hb) {
+        const int off0 = r0 * ROWB + ((((2 * hb) | (kc >> 1)) ^ swz_w) << 4) + ((kc & 1) << 3);
+        f32x4 sc = zero4, sh = zero4;
+        if constexpr (AFF) { sc = *reinterpret_cast<const f32x4*>(coef + R.cc); sh = *reinterpret_cast<const f32x4*>(coef + p.Kc + R.cc); }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            f32x4 v = R.a[i];
+            if constexpr (AFF) {
+                // bn_act_kernel's own operation order (y * scale + shift, then max with 0): the loader sees exactly the values the
+                // separate BatchNorm + ReLU pass would have written; padded taps / rows beyond M stay exact zeros
+                const bool ok = (R.okm >> i) & 1u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float w = fmaxf(v[e] * sc[e] + sh[e], 0.f); v[e] = ok ? w : 0.f; }
+            }
+            u32x2 q1, q2, q3;
+            split4(v, q1, q2, q3);
+            const int off = off0 + RPP * i * ROWB;
+            *reinterpret_cast<u32x2*>(As + off) = q1;
+            *reinterpret_cast<u32x2*>(As + A_PLANE + off) = q2;
+            *reinterpret_cast<u32x2*>(As + 2 * A_PLANE + off) = q3;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            u32x2 q1, q2, q3;
+            split4(R.b[i], q1, q2, q3);
+            const int off = off0 + RPP * i * ROWB;
+            *reinterpret_cast<u32x2*>(Bs + off) = q1;
+            *reinterpret_cast<u32x2*>(Bs + B_PLANE + off) = q2;
+            *reinterpret_cast<u32x2*>(Bs + 2 * B_PLANE + off) = q3;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int arow = wm * 32 * TM + l31, brow = wn * 32 * TN + l31;
+    const int swz_r = swz_row(l31);
+    auto compute_half = [&](int hb) {
+        const int rd = (((2 * hb) | h) ^ swz_r) << 4;
+        bf16x8 bfr[TN][3];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                bfr[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + pl * B_PLANE + (brow + 32 * j) * ROWB + rd));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            bf16x8 af[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                af[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + pl * A_PLANE + (arow + 32 * i) * ROWB + rd));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = mma6(af, bfr[j], acc[i][j]);
+        }
+    };
+
+    // Issue order of one phase (a compile-time directive to the scheduler, guide T19): the B fragments and the first A fragment
+    // first, then every MFMA carries a few VALU instructions of the split in its issue shadow; the LDS stores, the global loads
+    // and the remaining A-fragment reads are spread over the MFMA stream.
+    auto phase_schedule = [&]() {
+        constexpr int NMFMA = TM * TN * 6, NVALU = 30 * (NA + NB) + 8 * AFF * NA, NDSW = 3 * (NA + NB), NVM = NA + NB;
+        constexpr int VPM = (NVALU + NMFMA - 1) / NMFMA;
+        __builtin_amdgcn_sched_group_barrier(0x100, 3 * TN + 3, 0);             // DS read: B fragments + A fragment 0
+#pragma unroll
+        for (int g = 0; g < NMFMA; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);                // VALU of the split
+            if (g * NDSW / NMFMA != (g + 1) * NDSW / NMFMA) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // DS write
+            if (g * NVM / NMFMA != (g + 1) * NVM / NMFMA) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // VMEM read
+            if (g % (6 * TN) == 2 && g / (6 * TN) + 1 < TM) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);      // next A fragment
+        }
+    };
+    // ------------------------------------------------------------------ prologue
+    if constexpr (AFF) {
+        for (int c = t; c < p.Kc; c += NT) { coef[c] = p.aff_scale[c]; coef[p.Kc + c] = p.aff_shift[c]; }
+        __syncthreads();
+    }
+    Regs R0, R1;
+    prepare_tap(q_begin);     load_half(q_begin, R0);
+    prepare_tap(q_begin + 1); load_half(q_begin + 1, R1);
+    store_half(R0, 0);
+    prepare_tap(q_begin + 2); load_half(q_begin + 2, R0);
+    __syncthreads();
+    // ------------------------------------------------------------------ main loop: two phases (= one K=32 tile) per iteration
+    for (int j = 0; j < nq; j += 2) {
+        prepare_tap(q_begin + j + 3);
+        store_half(R1, 1);                       // half-tile j+1 (zeros beyond the K range)
+        load_half(q_begin + j + 3, R1);
+        compute_half(0);                         // half-tile j
+        phase_schedule();
+        __syncthreads();
+        prepare_tap(q_begin + j + 4);
+        store_half(R0, 0);                       // half-tile j+2
+        load_half(q_begin + j + 4, R0);
+        compute_half(1);                         // half-tile j+1
+        phase_schedule();
+        __syncthreads();
+    }
+
+    if constexpr (SK) {          // split-K: raw partial sums; bias / addend / BN statistics are applied by the reduce kernel
+        float* slab = p.slab + (long long)blockIdx.y * p.M * p.ldslab;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * 32 * TN + 32 * j + l31;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 32 * TM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (m < p.M && n < p.Nn) slab[(long long)m * p.ldslab + n] = acc[i][j][r];
+                }
+        }
+        return;
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    static_assert(EPI == 0 || TM % 2 == 0, "statistics epilogues need whole 64-row groups per wave");
+    int ncol[TN];
+    bool nok[TN];
+    float bias[TN];
+    [[maybe_unused]] float b_mu[TN], b_is[TN], b_sc[TN], b_sh[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        ncol[j] = n0 + wn * 32 * TN + 32 * j + l31;
+        nok[j] = ncol[j] < p.Nn;
+        bias[j] = (MODE == FPROP && p.extra != nullptr && nok[j]) ? p.extra[ncol[j]] : 0.f;
+        if constexpr (EPI == 2) {
+            b_mu[j] = b_is[j] = b_sc[j] = b_sh[j] = 0.f;
+            if (nok[j]) { b_mu[j] = p.bnb_mean[ncol[j]]; b_is[j] = p.bnb_invstd[ncol[j]]; b_sc[j] = p.bnb_scale[ncol[j]]; b_sh[j] = p.bnb_shift[ncol[j]]; }
+        }
+    }
+    [[maybe_unused]] float pend_s[TN], pend_q[TN];          // EPI == 2: sums of the even tile of a 64-row group
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        [[maybe_unused]] float gs[TN], gq[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 * TM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const bool mok = m < Mc;
+            long long orow = m;                               // row of the output (and of addend / bnb_y) this element belongs to
+            if constexpr (MODE == DGRAD) {
+                if (p.parity) {
+                    const int iwc = m % Wc, q2 = m / Wc, ihc = q2 % Hc, nb2 = q2 / Hc;
+                    orow = ((long long)nb2 * p.H + 2 * ihc + oy0) * p.W + 2 * iwc + ox0;
+                } else if (p.scatter) {
+                    const int ow = m % p.W, q = m / p.W, oh = q % p.H, nb = q / p.H;
+                    orow = (long long)(nb * p.sH + oh * p.sstride) * p.sW + ow * p.sstride;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (mok && nok[j]) {
+                    float v = acc[i][j][r];
+                    float* dst = p.c + orow * p.ldc + ncol[j];
+                    if constexpr (MODE == FPROP) {
+                        *dst = v + bias[j];
+                    } else {
+                        if (p.scatter) { *dst += v; }
+                        else {
+                            if (p.extra != nullptr) v += p.extra[orow * p.ldadd + ncol[j]];
+                            if constexpr (EPI == 2) {
+                                const float yv = p.bnb_y[orow * p.bnb_ldy + ncol[j]];
+                                if (p.bnb_relu && !(yv * b_sc[j] + b_sh[j] > 0.f)) v = 0.f;      // the forward's own arithmetic (bn_act_kernel)
+                                gs[j] += v; gq[j] += v * ((yv - b_mu[j]) * b_is[j]);
+                            }
+                            *dst = v;
+                        }
+                    }
+                }
+            }
+        }
+        if constexpr (EPI == 2) {      // (sum g, sum g*xhat) of this wave's 64-row groups, tiles summed in tile order
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float s1 = gs[j] + __shfl_xor(gs[j], 32, 64), q1 = gq[j] + __shfl_xor(gq[j], 32, 64);
+                if ((i & 1) == 0) { pend_s[j] = s1; pend_q[j] = q1; }
+                else {
+                    const int pidx = tile_m * (BM / 64) + wm * (TM / 2) + (i >> 1);
+                    if (h == 0 && pidx < p.n_partials && nok[j]) {
+                        p.partials[((long long)pidx * 2 + 0) * p.Nn + ncol[j]] = pend_s[j] + s1;
+                        p.partials[((long long)pidx * 2 + 1) * p.Nn + ncol[j]] = pend_q[j] + q1;
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (MODE == FPROP && EPI == 1) {
+        if (p.partials != nullptr) {
+            const int wrow0 = m0 + wm * 32 * TM;
+#pragma unroll
+            for (int pr = 0; pr < TM / 2; ++pr) {
+                const int prow0 = wrow0 + 64 * pr;
+                const int npr = max(0, min(64, p.M - prow0));
+                const int pidx = tile_m * (BM / 64) + wm * (TM / 2) + pr;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float ss = 0.f;
+#pragma unroll
+                    for (int i = 2 * pr; i < 2 * pr + 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ss += acc[i][j][r];      // rows >= M are exact zeros
+                    ss += __shfl_xor(ss, 32, 64);
+                    const float mean = npr > 0 ? ss / (float)npr : 0.f;
+                    float qq = 0.f;
+#pragma unroll
+                    for (int i = 2 * pr; i < 2 * pr + 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = wrow0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            const float dv = acc[i][j][r] - mean;
+                            qq += (npr == 64 || row < p.M) ? dv * dv : 0.f;
+                        }
+                    qq += __shfl_xor(qq, 32, 64);
+                    const int n = n0 + wn * 32 * TN + 32 * j + l31;
+                    if (h == 0 && pidx < p.n_partials && n < p.Nn) {
+                        p.partials[((long long)pidx * 2 + 0) * p.Nn + n] = ss;
+                        p.partials[((long long)pidx * 2 + 1) * p.Nn + n] = qq;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------- host side
+template <int MODE, int TM, int TN, int WGM, int WGN, int WPS, int AFF, int EPI, int SK, int TAP>
+static int launch_x6p(ConvQ& p, hipStream_t st) {
+    constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
+    const size_t lds = 3 * (size_t)(BM + BN) * ROWB + (AFF ? 8 * (size_t)p.Kc : 0);
+    if (lds > 160 * 1024) return SH_X6P_NO;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6p_kernel<MODE, TM, TN, WGM, WGN, WPS, AFF, EPI, SK, TAP>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        attr_lds = 160 * 1024;
+    }
+    p.tiles_m = (int)sh_cdiv(p.M, BM);
+    p.tiles_n = (int)sh_cdiv(p.Nn, BN);
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), p.parity ? 4u : (SK ? (unsigned)p.ksplit : 1u));
+    conv_x6p_kernel<MODE, TM, TN, WGM, WGN, WPS, AFF, EPI, SK, TAP><<<grid, 64 * WGM * WGN, lds, st>>>(p);
+    return sh_launch_status();
+}
+
+// Tile choice for one (mode, hooks, tap mode) combination.  Measured on the step's shapes (tools/bench_conv.py, round 2): 128 x 128
+// tiles on 4 waves (164 VGPRs, 48 KB LDS => 3 blocks per CU, which also overlaps one block's epilogue stores with its neighbours'
+// MFMAs) match or beat 256 x 256 on 8 waves and 256 x 128 everywhere (sep1.pw 740 vs 743 vs 770 us; l2.conv3 65 vs 77 vs 80 us),
+// so only two shapes are instantiated: 128 x 128, and 128 x 64 for N <= 64.
+template <int MODE, int AFF, int EPI, int TAP>
+static int pick_tile_x6p(ConvQ& p, hipStream_t st, int force) {
+    (void)force;
+    if (p.Nn > 64) return launch_x6p<MODE, 2, 2, 2, 2, 2, AFF, EPI, 0, TAP>(p, st);      // 128 x 128, 4 waves of 64 x 64
+    return launch_x6p<MODE, 2, 1, 2, 2, 2, AFF, EPI, 0, TAP>(p, st);                     // 128 x 64
+}
+
+template <int MODE, int AFF, int EPI>
+static int pick_x6p(ConvQ& p, hipStream_t st, int force) {
+    if (p.ksplit > 1) {          // K slices (mid-network shapes with an under-filled grid): 128 x 128 tiles into slabs, then the reduce
+        int rc;
+        if (p.KH * p.KW == 1) rc = launch_x6p<MODE, 2, 2, 2, 2, 2, AFF, 0, 1, 0>(p, st);
+        else if ((p.Kc & 15) == 0) rc = launch_x6p<MODE, 2, 2, 2, 2, 2, AFF, 0, 1, 1>(p, st);
+        else return SH_X6P_NO;
+        return rc == SH_OK ? sh_x6_splitk_reduce(p, MODE, st) : rc;
+    }
+    if (p.KH * p.KW == 1) return pick_tile_x6p<MODE, AFF, EPI, 0>(p, st, force);
+    if ((p.Kc & 15) == 0) return pick_tile_x6p<MODE, AFF, EPI, 1>(p, st, force);
+    if (AFF || EPI == 2) return SH_X6P_NO;
+    return pick_tile_x6p<MODE, 0, EPI, 2>(p, st, force);
+}
+
+static int x6p_mode() { static int v = -2; if (v == -2) { const char* e = getenv("SEGHIERO_X6P"); v = e ? atoi(e) : 1; } return v; }
+static int x6p_tile() { static int v = -2; if (v == -2) { const char* e = getenv("SEGHIERO_X6P_TILE"); v = e ? atoi(e) : 0; } return v; }
+
+// Entry used by sh_conv_fprop_x6 / sh_conv_dgrad_x6: SH_X6P_NO = shape not handled here (the caller falls back to conv_x6_kernel)
+int sh_x6p_launch(int mode, ConvQ& p, hipStream_t st) {
+    const bool aff = p.aff_scale != nullptr, bnb = p.bnb_y != nullptr;
+    if (!x6p_mode() && !aff && !bnb) return SH_X6P_NO;
+    if ((p.parity || p.scatter) && bnb) return SH_X6P_NO;
+    const int force = x6p_tile();
+    if (mode == FPROP) {
+        if (bnb) return SH_EINVAL;
+        if (aff) return pick_x6p<FPROP, 1, 1>(p, st, force);
+        return pick_x6p<FPROP, 0, 1>(p, st, force);
+    }
+    if (aff) return SH_EINVAL;
+    if (bnb) return pick_x6p<DGRAD, 0, 2>(p, st, force);
+    return pick_x6p<DGRAD, 0, 0>(p, st, force);
+}
+
+// ============================================================================================ WGRAD, pipelined
+// dW[co][n'] = sum_pix dY[pix][co] * im2col(X)[pix][n'] with the same two-half-tile pipeline as above: a K=32 tile of pixels is
+// two K=16 halves = k-rows 0..15 / 16..31 of the [k][row] LDS planes of conv_wgrad_x6_kernel (transposing ds_read_b64_tr_b16
+// fragments, (2*rows+64)-byte k-rows); per phase: split + store half-tile j+1, issue the loads of half-tile j+3, MFMAs of
+// half-tile j, one barrier.  AFF: the X operand is relu(x * scale[c] + shift[c]) of the stored tensor (the producer's train-mode
+// BatchNorm + ReLU, applied in the loader; see AFF above) -- each thread owns one 4-channel chunk, so its coefficients sit in
+// registers for the whole kernel.
+template <int WGM, int WGN, int AFF>
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_x6p_kernel(const ConvQ p) {
+    constexpr int NT = 64 * WGM * WGN, BM = 64 * WGM, BN = 64 * WGN;
+    constexpr int AROWB = 2 * BM + 64, BROWB = 2 * BN + 64;
+    constexpr int APLANE = 32 * AROWB, BPLANE = 32 * BROWB;
+    constexpr int ACPR = BM / 4, BCPR = BN / 4;              // float4 chunks per k-row
+    constexpr int AKPP = NT / ACPR, BKPP = NT / BCPR;        // k-rows per loader pass
+    constexpr int NA = 16 / AKPP, NB = 16 / BKPP;            // passes per half-tile
+    static_assert(NA >= 1 && NB >= 1, "a loader pass must not straddle the two halves");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const As = smem;
+    unsigned char* const Bs = smem + 3 * APLANE;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WGN, wn = wave % WGN, l31 = lane & 31, h = lane >> 5;
+    const unsigned nblk = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+    unsigned slice, bid;                                     // block -> (K slice, tile): see conv_wgrad_x6_kernel
+    if (p.scatter) { const unsigned kq = blockIdx.x >> 3; slice = (kq / nblk) * 8u + (blockIdx.x & 7u); bid = kq % nblk; }
+    else { slice = blockIdx.x / nblk; bid = xcd_remap(blockIdx.x % nblk, nblk); }
+    if (slice >= (unsigned)p.ksplit) return;
+    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = slice * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
+    const int nq = (((kend - kbeg + 15) >> 4) + 1) & ~1;    // half-tiles, rounded up to whole K=32 tiles
+
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, p.b_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int arc = t % ACPR, ak0 = t / ACPR;
+    const int brc = t % BCPR, bk0 = t / BCPR;
+    const int co = m0 + 4 * arc;
+    const int nn = n0 + 4 * brc;
+    const unsigned a_col_ok = co < p.M ? ~0u : 0u, b_col_ok = nn < p.Nn ? ~0u : 0u;
+    const int tap = nn / p.Cin, wg_ci = nn - tap * p.Cin;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int wg_dh = kh * p.dil - p.pad, wg_dw = kw * p.dil - p.pad;
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
+    if constexpr (AFF) { if (b_col_ok) { sc = ld4(p.aff_scale + wg_ci); sh = ld4(p.aff_shift + wg_ci); } }
+    // pixel coordinates of this thread's B k-rows for the NEXT half-tile to load, advanced by 16 pixels per load (Wo >= 16 on
+    // this path, so a step wraps at most one image row and one image: compare + select, no loops, no divisions)
+    int px_ow[NB], px_oh[NB], px_n[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int pix = kbeg + bk0 + BKPP * i;
+        px_ow[i] = pix % p.Wo; const int q2 = pix / p.Wo; px_oh[i] = q2 % p.Ho; px_n[i] = q2 / p.Ho;
+    }
+    struct Regs { f32x4 a[NA]; f32x4 b[NB]; unsigned okm; };
+    auto load_half = [&](int q, Regs& R) {
+        const int kbase = kbeg + 16 * q;
+        R.okm = 0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int pix = kbase + ak0 + AKPP * i;
+            const unsigned ok = (unsigned)((pix - kend) >> 31) & a_col_ok;
+            const unsigned voff = (((unsigned)(pix * (int)p.lda + co) * 4u) & ok) | (OOB & ~ok);
+            R.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int pix = kbase + bk0 + BKPP * i;
+            const int ih = px_oh[i] * p.stride + wg_dh, iw = px_ow[i] * p.stride + wg_dw;
+            const unsigned inimg = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? ~0u : 0u;
+            const unsigned ok = (unsigned)((pix - kend) >> 31) & b_col_ok & inimg;
+            const unsigned voff = (((unsigned)(((px_n[i] * p.H + ih) * p.W + iw) * (int)p.ldb + wg_ci) * 4u) & ok) | (OOB & ~ok);
+            R.b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, voff, 0, 0));
+            if (AFF) R.okm |= ok & (1u << i);
+            int ow = px_ow[i] + 16, oh = px_oh[i], n = px_n[i];
+            const bool c1 = ow >= p.Wo; ow -= c1 ? p.Wo : 0; oh += c1 ? 1 : 0;
+            const bool c2 = oh >= p.Ho; oh -= c2 ? p.Ho : 0; n += c2 ? 1 : 0;
+            px_ow[i] = ow; px_oh[i] = oh; px_n[i] = n;
+        }
+    };
+    auto store_half = [&](Regs& R, int hb) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int off = (16 * hb + ak0 + AKPP * i) * AROWB + arc * 8;
+            u32x2 q1, q2, q3;
+            split4(R.a[i], q1, q2, q3);
+            *reinterpret_cast<u32x2*>(As + off) = q1;
+            *reinterpret_cast<u32x2*>(As + APLANE + off) = q2;
+            *reinterpret_cast<u32x2*>(As + 2 * APLANE + off) = q3;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            f32x4 v = R.b[i];
+            if constexpr (AFF) {
+                const bool ok = (R.okm >> i) & 1u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float w = fmaxf(v[e] * sc[e] + sh[e], 0.f); v[e] = ok ? w : 0.f; }
+            }
+            const int off = (16 * hb + bk0 + BKPP * i) * BROWB + brc * 8;
+            u32x2 q1, q2, q3;
+            split4(v, q1, q2, q3);
+            *reinterpret_cast<u32x2*>(Bs + off) = q1;
+            *reinterpret_cast<u32x2*>(Bs + BPLANE + off) = q2;
+            *reinterpret_cast<u32x2*>(Bs + 2 * BPLANE + off) = q3;
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // transpose-read addressing: 16-lane group g -> (row half g&1, k half g>>1); lane 4q+pp supplies row q, columns 4pp..4pp+3
+    const int g = lane >> 4, li = lane & 15, qq = li >> 2, pp = li & 3;
+    const int krow = (g >> 1) * 8 + qq, coff = (16 * (g & 1) + 4 * pp) * 2;
+    auto frag = [&](const unsigned char* plane, int rowb, int hb, int rowbase) -> bf16x8 {
+        const unsigned char* a0 = plane + (krow + hb * 16) * rowb + coff + rowbase * 2;
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0 + 4 * rowb));
+        s16x8 r;
+        r[0] = v0[0]; r[1] = v0[1]; r[2] = v0[2]; r[3] = v0[3]; r[4] = v1[0]; r[5] = v1[1]; r[6] = v1[2]; r[7] = v1[3];
+        return __builtin_bit_cast(bf16x8, r);
+    };
+    auto compute_half = [&](int hb) {
+        bf16x8 af[2][3], bfr[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                af[i][pl] = frag(As + pl * APLANE, AROWB, hb, wm * 64 + 32 * i);
+                bfr[i][pl] = frag(Bs + pl * BPLANE, BROWB, hb, wn * 64 + 32 * i);
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = mma6(af[i], bfr[j], acc[i][j]);
+    };
+    auto phase_schedule = [&]() {
+        constexpr int NVALU = (30 + 8 * AFF) * NB + 30 * NA + 8 * NB, NDSW = 3 * (NA + NB), NVM = NA + NB;
+        constexpr int VPM = (NVALU + 23) / 24;
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);                     // DS read: first A / B fragment pairs
+#pragma unroll
+        for (int gq = 0; gq < 24; ++gq) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);                // VALU of the split / addressing
+            if (gq * NDSW / 24 != (gq + 1) * NDSW / 24) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // DS write
+            if (gq * NVM / 24 != (gq + 1) * NVM / 24) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // VMEM read
+            if (gq == 2) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);    // remaining fragment reads
+        }
+    };
+    Regs R0, R1;
+    load_half(0, R0);
+    load_half(1, R1);
+    store_half(R0, 0);
+    load_half(2, R0);
+    __syncthreads();
+    for (int j = 0; j < nq; j += 2) {
+        store_half(R1, 1);
+        load_half(j + 3, R1);
+        compute_half(0);
+        phase_schedule();
+        __syncthreads();
+        store_half(R0, 0);
+        load_half(j + 4, R0);
+        compute_half(1);
+        phase_schedule();
+        __syncthreads();
+    }
+    float* slab = p.c + (long long)slice * p.M * p.Nn;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + 32 * j + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < p.M && n < p.Nn) slab[(long long)m * p.Nn + n] = acc[i][j][r];
+            }
+        }
+}
+template <int WGM, int WGN, int AFF>
+static int launch_wgrad_x6p(ConvQ& p, int splits, hipStream_t st) {
+    constexpr size_t lds = 3 * 32 * (size_t)((2 * 64 * WGM + 64) + (2 * 64 * WGN + 64));
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x6p_kernel<WGM, WGN, AFF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    p.tiles_m = (int)sh_cdiv(p.M, 64 * WGM); p.tiles_n = (int)sh_cdiv(p.Nn, 64 * WGN);
+    p.ksplit = splits;
+    const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n) * (unsigned)(p.scatter ? sh_cdiv(splits, 8) * 8 : splits);
+    conv_wgrad_x6p_kernel<WGM, WGN, AFF><<<grid, 64 * WGM * WGN, lds, st>>>(p);
+    return sh_launch_status();
+}
+template <int AFF>
+static int pick_wgrad_x6p(ConvQ& p, int wgm, int wgn, int splits, hipStream_t st) {
+    if (wgm == 4 && wgn == 1) return launch_wgrad_x6p<4, 1, AFF>(p, splits, st);
+    if (wgm == 2 && wgn == 1) return launch_wgrad_x6p<2, 1, AFF>(p, splits, st);
+    if (wgm == 2 && wgn == 4) return launch_wgrad_x6p<2, 4, AFF>(p, splits, st);
+    if (wgm == 1 && wgn == 4) return launch_wgrad_x6p<1, 4, AFF>(p, splits, st);
+    if (wgm == 1 && wgn == 2) return launch_wgrad_x6p<1, 2, AFF>(p, splits, st);
+    return launch_wgrad_x6p<2, 2, AFF>(p, splits, st);
+}
+// Entry used by sh_conv_wgrad_x6 (same tile / K-slice plan as conv_wgrad_x6_kernel; the slab reduce stays with the caller)
+int sh_x6p_wgrad_launch(ConvQ& p, int wgm, int wgn, int splits, hipStream_t st) {
+    const bool aff = p.aff_scale != nullptr;
+    if (!x6p_mode() && !aff) return SH_X6P_NO;
+    if (p.Wo < 16 || (p.Cin & 3)) return SH_X6P_NO;
+    return aff ? pick_wgrad_x6p<1>(p, wgm, wgn, splits, st) : pick_wgrad_x6p<0>(p, wgm, wgn, splits, st);
+}

@@ -87,7 +87,7 @@ class _HeadFn(torch.autograd.Function):
         # ---- projection head -> l2-normalised embedding (:12-30)
         proj = mod.proj_head.proj
         if isinstance(proj, nn.Sequential):
-            p1, R["p1"] = L.cba_fwd(c4, proj[0].weight, G1, proj[1], True, training)
+            p1, R["p1"] = L.cba_fwd(c4, proj[0].weight, G1, proj[1], True, training, lazy=True)
             e_raw = L.conv_fwd(p1, proj[3].weight, None, G1)
             R["p1_out"] = p1
         else:
@@ -108,7 +108,7 @@ class _HeadFn(torch.autograd.Function):
         _, R["b0"] = L.cba_fwd(c4, aspp.branches[0][0].weight, G1, aspp.branches[0][1], True, training, out=cat[:, A:2 * A])
         for i, d in enumerate(aspp.dilations[1:], start=1):
             ds = aspp.branches[i][0]
-            t, R[f"dw{i}"] = L.dw_fwd(c4, ds.depthwise.weight, d, ds.bn_dw, training)
+            t, R[f"dw{i}"] = L.dw_fwd(c4, ds.depthwise.weight, d, ds.bn_dw, training, lazy=True)
             _, R[f"pw{i}"] = L.cba_fwd(t, ds.pointwise.weight, G1, ds.bn_pw, True, training, out=cat[:, (i + 1) * A:(i + 2) * A])
         b, R["bt"] = L.cba_fwd(cat, mod.bottleneck[0].weight, G1, mod.bottleneck[1], True, training)
         # ---- decoder: x8 bilinear + C1 skip into one buffer (:231-242)
@@ -123,8 +123,8 @@ class _HeadFn(torch.autograd.Function):
         else:
             xin = b
         for j, ds in enumerate(mod.sep_bottleneck):
-            t, R[f"sdw{j}"] = L.dw_fwd(xin, ds.depthwise.weight, 1, ds.bn_dw, training)
-            xin, R[f"spw{j}"] = L.cba_fwd(t, ds.pointwise.weight, G1, ds.bn_pw, True, training)
+            t, R[f"sdw{j}"] = L.dw_fwd(xin, ds.depthwise.weight, 1, ds.bn_dw, training, lazy=True)
+            xin, R[f"spw{j}"] = L.cba_fwd(t, ds.pointwise.weight, G1, ds.bn_pw, True, training, lazy=True)
         logits = L.conv_fwd(xin, mod.cls_seg.weight, mod.cls_seg.bias, G1)
         R["cls_in"] = xin
         if training:

@@ -44,6 +44,49 @@ def bump_bn_counters(bns):
         torch._foreach_add_(ctrs, 1)
 
 
+# ----------------------------------------------------------------------------- deferred BatchNorm + ReLU
+FUSE_BN = __import__("os").environ.get("SEGHIERO_FUSE_BN", "1") != "0"      # 0: every BatchNorm + ReLU is its own pass (round-1 path)
+
+
+class Lazy:
+    """relu(y * scale + shift) of a raw conv output, NOT materialised: the consumer convolution applies it in its loader
+    (ops.conv_fprop_aff / conv_wgrad(aff=...)), so conv -> BN -> ReLU -> conv chains never write or re-read the activated
+    tensor.  `materialize()` is the fallback for consumers without a fused loader."""
+    __slots__ = ("y", "coefs", "_out")
+
+    def __init__(self, y, coefs):
+        self.y, self.coefs, self._out = y, coefs, None
+
+    @property
+    def shape(self):
+        return self.y.shape
+
+    @property
+    def device(self):
+        return self.y.device
+
+    def materialize(self):
+        if self._out is None:
+            n, c, h, w = self.y.shape
+            ld = ops.pad4(c)
+            self._out = ops.new_act(n, c, h, w, self.y.device, ld=ld, zero=ld != c)
+            ops.bn_act(self.y, self.coefs, self._out, True)
+        return self._out
+
+
+class GradPack:
+    """Gradient w.r.t. a deferred activation as the dgrad epilogue leaves it (ops.conv_dgrad_bnb): g = relumask * dx and the
+    (sum g, sum g*xhat) partials per 64 rows -- the producer's BatchNorm backward starts from its finalize step."""
+    __slots__ = ("g", "partials")
+
+    def __init__(self, g, partials):
+        self.g, self.partials = g, partials
+
+
+def dense(x):
+    return x.materialize() if isinstance(x, Lazy) else x
+
+
 # ----------------------------------------------------------------------------- conv + BN (+res) (+ReLU)
 class CBARec:
     __slots__ = ("x", "y", "out", "coefs", "relu", "geom", "weight", "has_res")
@@ -56,8 +99,45 @@ def _bn_coefs(bn, partials, count, training, c, device):
     return ops.bn_eval_coefs(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
 
 
-def cba_fwd(x, weight, geom, bn, relu, training, residual=None, out=None):
-    """out = [relu](BN(conv(x, weight)) [+ residual]); `out` may be a channel slice of a concat buffer."""
+def _fprop(x, weight, bias, y, partials, s, p, d):
+    """conv forward of a tensor or a deferred activation (fused loader where the geometry has one)."""
+    if isinstance(x, Lazy):
+        if ops.conv_fprop_aff(x.y, x.coefs, weight, bias, y, partials, s, p, d):
+            return
+        x = x.materialize()
+    ops.conv_fprop(x, weight, bias, y, partials, s, p, d)
+
+
+def _wgrad(x, dy, dw, s, p, d):
+    if isinstance(x, Lazy):
+        if x._out is None and ops.wgrad_aff_ok(x.y, dw, s, p, d):
+            ops.conv_wgrad(x.y, dy, dw, s, p, d, side=True, aff=x.coefs)
+            return
+        x = x.materialize()
+    ops.conv_wgrad(x, dy, dw, s, p, d, side=True)
+
+
+def _dgrad(rec_x, dy, weight, s, p, d, addend=None):
+    """Gradient w.r.t. a conv input.  For a deferred activation the dgrad epilogue also runs the front half of the producer's
+    BatchNorm backward (-> GradPack); otherwise a plain tensor."""
+    n, c, h, w = rec_x.shape
+    dev = dy.device
+    if isinstance(rec_x, Lazy) and FUSE_BN:
+        g = ops.new_act(n, c, h, w, dev)
+        partials = torch.empty((-(-n * h * w // 64), 2, c), device=dev, dtype=torch.float32)
+        if ops.conv_dgrad_bnb(dy, weight, g, rec_x.y, rec_x.coefs, True, partials, s, p, d, addend=addend):
+            return GradPack(g, partials)
+        dx = g
+    else:
+        dx = ops.new_act(n, c, h, w, dev)
+    ops.conv_dgrad(dy, weight, dx, s, p, d, addend=addend)
+    return dx
+
+
+def cba_fwd(x, weight, geom, bn, relu, training, residual=None, out=None, lazy=False):
+    """out = [relu](BN(conv(x, weight)) [+ residual]); `out` may be a channel slice of a concat buffer.
+    x may be a deferred activation (Lazy).  lazy=True (training, ReLU, no residual, no `out`): the BatchNorm + ReLU of THIS
+    layer is deferred too -- a Lazy is returned and no elementwise pass runs."""
     s, p, d = geom
     n, _, h, w = x.shape
     o, _, kh, kw = weight.shape
@@ -69,18 +149,22 @@ def cba_fwd(x, weight, geom, bn, relu, training, residual=None, out=None):
         coefs = _bn_coefs(bn, None, m, False, o, x.device)
         if out is None:
             out = ops.new_act(n, o, ho, wo, x.device, ld=ld, zero=ld != o)
-        ops.conv_fprop_act(x, weight, coefs, out, relu, residual, s, p, d)
+        ops.conv_fprop_act(dense(x), weight, coefs, out, relu, residual, s, p, d)
         y = None
     else:
         y = ops.new_act(n, o, ho, wo, x.device, ld=ld, zero=ld != o)
         partials = ops.conv_partials(m, o, x.device) if training else None
-        ops.conv_fprop(x, weight, None, y, partials, s, p, d)
+        _fprop(x, weight, None, y, partials, s, p, d)
         coefs = _bn_coefs(bn, partials, m, training, o, x.device)
-        if out is None:
-            out = ops.new_act(n, o, ho, wo, x.device, ld=ld, zero=ld != o)
-        ops.bn_act(y, coefs, out, relu, residual)
+        if lazy and FUSE_BN and training and relu and residual is None and out is None and ops.CONV_IMPL == "x6":
+            out = Lazy(y, coefs)
+        else:
+            if out is None:
+                out = ops.new_act(n, o, ho, wo, x.device, ld=ld, zero=ld != o)
+            ops.bn_act(y, coefs, out, relu, residual)
     rec = CBARec()
-    rec.x, rec.y, rec.out, rec.coefs, rec.relu, rec.geom, rec.weight = x, y, out, coefs, relu, geom, weight
+    rec.x, rec.y, rec.coefs, rec.relu, rec.geom, rec.weight = x, y, coefs, relu, geom, weight
+    rec.out = None if isinstance(out, Lazy) else out
     rec.has_res = residual is not None
     return out, rec
 
@@ -97,25 +181,24 @@ def cba_bwd(rec, bn, dout, need_dx=True, addend=None, want_dres=False, scatter_i
     """-> (dx, dweight, dgamma, dbeta, dres).  `addend` is summed into dx by the dgrad epilogue;
     `scatter_into` (1x1 strided convs) accumulates the result into an existing dx instead."""
     s, p, d = rec.geom
-    # ReLU mask: from `out` only where a residual was added; otherwise recomputed from y (one activation read less)
+    # ReLU mask: from `out` only where a residual was added; otherwise recomputed from y (one activation read less).
+    # dout may be a GradPack (mask applied, statistics partials done by the consumer's dgrad epilogue).
     mode = 0 if not rec.relu else (1 if rec.has_res else 2)
     dy, dgamma, dbeta, dres = ops.bn_backward(dout, rec.out if mode == 1 else None, rec.y, rec.coefs, bn.weight,
                                               mode, want_dres)
     dw = new_grad(rec.weight)
     if not ops.WGRAD_AFTER_DGRAD:
-        ops.conv_wgrad(rec.x, dy, dw, s, p, d, side=True)
+        _wgrad(rec.x, dy, dw, s, p, d)
     dx = None
     if scatter_into is not None:
         ops.conv_dgrad(dy, rec.weight, scatter_into, s, p, d, mode=1)
         dx = scatter_into
     elif need_dx:
-        n, c, h, w = rec.x.shape
-        dx = ops.new_act(n, c, h, w, rec.x.device)
-        ops.conv_dgrad(dy, rec.weight, dx, s, p, d, addend=addend)
+        dx = _dgrad(rec.x, dy, rec.weight, s, p, d, addend=addend)
     if ops.WGRAD_AFTER_DGRAD:
         # enqueued after the dgrad: the side stream then starts this (MFMA-bound) wgrad when the dgrad has finished, i.e.
         # next to the HBM-bound BatchNorm backward of the previous layer instead of next to another MFMA-bound kernel
-        ops.conv_wgrad(rec.x, dy, dw, s, p, d, side=True)
+        _wgrad(rec.x, dy, dw, s, p, d)
     return dx, dw, dgamma, dbeta, dres
 
 
@@ -124,16 +207,22 @@ class DWRec:
     __slots__ = ("x", "y", "out", "coefs", "dil", "weight")
 
 
-def dw_fwd(x, weight, dil, bn, training):
+def dw_fwd(x, weight, dil, bn, training, lazy=False):
+    """depthwise 3x3 -> BN -> ReLU; lazy=True defers the BatchNorm + ReLU to the pointwise conv's loader (-> Lazy)."""
+    x = dense(x)
     n, c, h, w = x.shape
     y = ops.new_act(n, c, h, w, x.device)
     partials = torch.empty((ops.dw_partials_rows(n, h, w), 2, c), device=x.device) if training else None
     ops.dwconv_fprop(x, weight, y, partials, dil)
     coefs = _bn_coefs(bn, partials, n * h * w, training, c, x.device)
-    out = ops.new_act(n, c, h, w, x.device)
-    ops.bn_act(y, coefs, out, True)
+    if lazy and FUSE_BN and training and ops.CONV_IMPL == "x6":
+        out = Lazy(y, coefs)
+    else:
+        out = ops.new_act(n, c, h, w, x.device)
+        ops.bn_act(y, coefs, out, True)
     rec = DWRec()
-    rec.x, rec.y, rec.out, rec.coefs, rec.dil, rec.weight = x, y, out, coefs, dil, weight
+    rec.x, rec.y, rec.coefs, rec.dil, rec.weight = x, y, coefs, dil, weight
+    rec.out = None if isinstance(out, Lazy) else out
     return out, rec
 
 
@@ -160,20 +249,18 @@ def conv_fwd(x, weight, bias, geom):
     ho, wo = ops.conv_out_hw(h, w, kh, kw, s, p, d)
     ld = ops.pad4(o)
     y = ops.new_act(n, o, ho, wo, x.device, ld=ld, zero=ld != o)
-    ops.conv_fprop(x, weight, bias, y, None, s, p, d)
+    _fprop(x, weight, bias, y, None, s, p, d)
     return y
 
 
 def conv_bwd(x, weight, geom, dy, need_dx=True, addend=None):
-    """dy must be NHWC with its padding lanes zeroed.  -> (dx, dweight)."""
+    """dy must be NHWC with its padding lanes zeroed.  -> (dx (tensor, or GradPack for a deferred input), dweight)."""
     s, p, d = geom
     dw = new_grad(weight)
-    ops.conv_wgrad(x, dy, dw, s, p, d, side=True)
+    _wgrad(x, dy, dw, s, p, d)
     dx = None
     if need_dx:
-        n, c, h, w = x.shape
-        dx = ops.new_act(n, c, h, w, x.device)
-        ops.conv_dgrad(dy, weight, dx, s, p, d, addend=addend)
+        dx = _dgrad(x, dy, weight, s, p, d, addend=addend)
     return dx, dw
 
 

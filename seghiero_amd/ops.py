@@ -148,6 +148,45 @@ def w_ohwi(weight):
     return weight
 
 
+UNSUPPORTED = -3          # SH_EUNSUPPORTED: a fused entry point has no instantiation for the geometry (nothing launched)
+
+
+def _call_fused(name, *args, cost=None):
+    """Fused entry points: True = launched, False = SH_EUNSUPPORTED (the caller runs the unfused sequence); raises otherwise."""
+    if _PROF is None:
+        rc = LIB.raw(name)(*args)
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = LIB.raw(name)(*args)
+        e1.record()
+        if rc == 0:
+            _PROF.append((name, cost, e0, e1))
+    if rc == 0:
+        return True
+    if rc == UNSUPPORTED:
+        return False
+    raise SegHieroHipError(f"{name} failed with status {rc} ({'invalid argument' if rc == -1 else 'HIP launch error'})")
+
+
+def conv_fprop_aff(x, in_coefs, weight, bias, y, partials, stride, pad, dil):
+    """y = conv(relu(x * scale + shift), weight): the producer's train-mode BatchNorm + ReLU applied in the conv's loader
+    (in_coefs = the (4, C) coefficient tensor of bn_finalize).  -> False when the geometry has no fused kernel."""
+    if CONV_IMPL != "x6":
+        return False
+    n, cin, h, w = x.shape
+    o, _, kh, kw = weight.shape
+    xp, ldx = pm(x)
+    yp, ldy = pm(y)
+    ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
+    m = n * ho * wo
+    cost = (2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin + m * o + o * cin * kh * kw))
+    ws, nb = _splitk_ws(0, n, h, w, cin, o, kh, kw, stride, pad, dil, 0, x.device)
+    return _call_fused("sh_conv_fprop_x6_aff", xp, ldx, in_coefs[2].data_ptr(), in_coefs[3].data_ptr(), w_ohwi(weight).data_ptr(),
+                       None if bias is None else bias.data_ptr(), yp, ldy, None if partials is None else partials.data_ptr(),
+                       n, h, w, cin, o, kh, kw, stride, pad, dil, ws, nb, _st(), cost=cost)
+
+
 def conv_fprop(x, weight, bias, y, partials, stride, pad, dil):
     n, cin, h, w = x.shape
     o, _, kh, kw = weight.shape
@@ -263,6 +302,28 @@ def conv_dgrad(dy, weight, dx, stride, pad, dil, addend=None, mode=0):
         _call("sh_conv_dgrad", *args, _st(), cost=cost)
 
 
+def conv_dgrad_bnb(dy, weight, g, y_prev, coefs, relu, partials, stride, pad, dil, addend=None):
+    """Input gradient + front half of the producer layer's BatchNorm backward in the dgrad epilogue: g <- relumask * (dx [+ addend]),
+    partials[ceil(M/64), 2, Cin] <- (sum g, sum g*xhat) per 64 rows.  -> False when the geometry has no fused kernel."""
+    if CONV_IMPL != "x6":
+        return False
+    n, cin, h, w = g.shape
+    o, _, kh, kw = weight.shape
+    dyp, lddy = pm(dy)
+    gp, ldg = pm(g)
+    ypp, ldyp = pm(y_prev)
+    if lddy < pad4(o):
+        return False
+    ap, lda = (None, 0) if addend is None else pm(addend)
+    ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
+    m = n * ho * wo
+    cost = (2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin * (3 if addend is not None else 2) + m * o + o * cin * kh * kw))
+    ws, nb = _splitk_ws(1, n, h, w, cin, o, kh, kw, stride, pad, dil, 0, g.device)
+    return _call_fused("sh_conv_dgrad_x6_bnb", dyp, lddy, weight_transpose(weight).data_ptr(), ap, lda, gp, ldg, ypp, ldyp,
+                       coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(), coefs[3].data_ptr(), int(bool(relu)),
+                       partials.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, ws, nb, _st(), cost=cost)
+
+
 _WS = {}
 
 
@@ -318,13 +379,23 @@ def join_wgrad():
                 ent.pending[k] = False
 
 
-def conv_wgrad(x, dy, dweight, stride, pad, dil, side=False):
+def wgrad_aff_ok(x, dweight, stride, pad, dil):
+    """Can conv_wgrad(..., aff=...) read this x through the producer's BatchNorm + ReLU?  (x6 kernel, output width >= 16)"""
+    n, cin, h, w = x.shape
+    o, _, kh, kw = dweight.shape
+    return CONV_IMPL == "x6" and cin % 4 == 0 and conv_out_hw(h, w, kh, kw, stride, pad, dil)[1] >= 16
+
+
+def conv_wgrad(x, dy, dweight, stride, pad, dil, side=False, aff=None):
     """dweight <- grad_weight.  side=True (the backward nodes): launched on the weight-gradient stream; the caller must
-    run join_wgrad() before anything consumes dweight."""
+    run join_wgrad() before anything consumes dweight.  aff = (4, C) BatchNorm coefficients: x holds the producer conv's raw
+    output and the loader applies relu(x * scale + shift) (check wgrad_aff_ok first)."""
     n, cin, h, w = x.shape
     o, _, kh, kw = dweight.shape
     # tiny output-channel counts (cls_seg, aux head) stay on the f32-MFMA kernel
     x6 = CONV_IMPL == "x6" and o >= 32 and (cin * kh * kw >= 128 or (cin * kh * kw == 64 and o >= 128))
+    if aff is not None:
+        x6 = True
     need = LIB.raw("sh_conv_wgrad_x6_workspace" if x6 else "sh_conv_wgrad_workspace")(n, h, w, cin, o, kh, kw, stride, pad, dil)
     if need < 0:
         raise SegHieroHipError("sh_conv_wgrad_workspace rejected the geometry")
@@ -337,6 +408,11 @@ def conv_wgrad(x, dy, dweight, stride, pad, dil, side=False):
 
     def launch(tag="wgrad"):
         ws = workspace(need, x.device, tag)              # one workspace per stream: its kernels stay in that stream's order
+        if aff is not None:
+            if not _call_fused("sh_conv_wgrad_x6_aff", xp, ldx, aff[2].data_ptr(), aff[3].data_ptr(), dyp, lddy, dweight.data_ptr(),
+                               ws.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, _st(), cost=cost):
+                raise SegHieroHipError("sh_conv_wgrad_x6_aff: unsupported geometry (check wgrad_aff_ok before deferring the activation)")
+            return
         _call(name, xp, ldx, dyp, lddy, dweight.data_ptr(), ws.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, _st(), cost=cost)
 
     if not (side and WGRAD_ASYNC and x.is_cuda):
@@ -464,20 +540,27 @@ def bn_act(y, coefs, out, relu, residual=None):
 
 def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None):
     """-> (dy, dgamma, dbeta, dres).  relu: 0 none, 1 mask from `out` (residual blocks), 2 mask recomputed from y and
-    the forward coefficients (out may be None)."""
+    the forward coefficients (out may be None).  dout may be a layers.GradPack: the ReLU mask is already applied and the
+    (sum g, sum g*xhat) partials were produced by the consumer's dgrad epilogue, so the statistics pass is skipped."""
     relu = int(relu)
     if relu == 2:
         out = None
     n, c, h, w = y.shape
     m = n * h * w
     dev = y.device
-    dop, lddo = pm(dout)
     yp, ldy = pm(y)
     op, ldo = (None, 0) if out is None else pm(out)
-    p = LIB.raw("sh_stats_partials_count")(m)
-    partials = torch.empty((p, 2, c), device=dev, dtype=torch.float32)
-    _call("sh_bn_bwd_reduce", dop, lddo, op, ldo, yp, ldy, coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(),
-          coefs[3].data_ptr(), partials.data_ptr(), m, c, relu, _st())
+    packed = hasattr(dout, "partials")
+    if packed:
+        partials, dout, relu, op, ldo = dout.partials, dout.g, 0, None, 0
+        p = partials.shape[0]
+        dop, lddo = pm(dout)
+    else:
+        dop, lddo = pm(dout)
+        p = LIB.raw("sh_stats_partials_count")(m)
+        partials = torch.empty((p, 2, c), device=dev, dtype=torch.float32)
+        _call("sh_bn_bwd_reduce", dop, lddo, op, ldo, yp, ldy, coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(),
+              coefs[3].data_ptr(), partials.data_ptr(), m, c, relu, _st())
     red = torch.empty((4, c), device=dev, dtype=torch.float32)           # dgamma, dbeta, c1, c2
     if _sync_on():
         local = torch.empty((2 * c + 1,), device=dev, dtype=torch.float64)

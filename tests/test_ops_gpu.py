@@ -104,6 +104,73 @@ def test_conv_fprop_dgrad_wgrad(ops, case):
     close(dw, wr.grad, 2e-4, 2e-4 * float(wr.grad.abs().max()), "wgrad")
 
 
+FUSED_CASES = [
+    # n, h, w, cin, cout, k, pad, dil
+    (2, 16, 16, 64, 64, 1, 0, 1),
+    (2, 20, 18, 64, 256, 1, 0, 1),
+    (2, 17, 19, 32, 48, 3, 1, 1),         # zero padding must stay zero AFTER the activation; N <= 64 tile
+    (2, 16, 16, 128, 128, 3, 1, 1),
+    (2, 16, 16, 560, 512, 1, 0, 1),       # K = 560: last half-tile masked
+    (2, 12, 16, 256, 64, 3, 1, 1),        # split-K fprop with the fused loader / split-K dgrad with the fused epilogue
+    (1, 160, 160, 64, 128, 1, 0, 1),      # many tiles
+    (2, 16, 16, 32, 32, 3, 6, 6),         # dilated
+]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_conv_fused_batchnorm_hooks(ops, case):
+    """The three fused forms of conv -> BN -> ReLU -> conv chains (resnet.py:65-73, sep_aspp_contrast_head.py:56-61) against torch:
+    fprop / wgrad reading their input through relu(x*scale+shift) in the loader, and dgrad emitting g = relumask * dx plus the
+    (sum g, sum g*xhat) partials of the producer's BatchNorm backward from its epilogue."""
+    n, h, w, cin, cout, k, p, d = case
+    g = torch.Generator().manual_seed(sum(case))
+    raw = torch.randn(n, cin, h, w, generator=g)                       # raw output of the producer conv
+    scale = torch.randn(cin, generator=g)                               # both signs
+    shift = 0.3 * torch.randn(cin, generator=g)
+    mean = 0.2 * torch.randn(cin, generator=g)
+    invstd = 0.5 + torch.rand(cin, generator=g)
+    coefs = torch.stack([mean, invstd, scale, shift]).to(DEV).contiguous()
+    act = torch.relu(raw * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    ar = act.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    ref = F.conv2d(ar, wr, None, 1, p, d)
+    ho, wo = ref.shape[2:]
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    rawg, wg = nhwc(raw), wl(wt)
+    ldy = ops.pad4(cout)
+    # ---- fprop through the loader + BN statistics of ITS output
+    y = ops.new_act(n, cout, ho, wo, DEV, ld=ldy, zero=True)
+    part = ops.conv_partials(n * ho * wo, cout, DEV)
+    assert ops.conv_fprop_aff(rawg, coefs, wg, None, y, part, 1, p, d)
+    close(y, ref, 2e-5, 2e-5, "fprop through BN+ReLU")
+    st = ops.bn_finalize(part, n * ho * wo, None, None, 1e-5, 0.1, None, None, cout, DEV, rows=64)
+    close(st[0], ref.detach().mean((0, 2, 3)), 1e-4, 1e-5, "stat mean")
+    # ---- wgrad through the loader
+    dyg = ops.new_act(n, cout, ho, wo, DEV, ld=ldy, zero=True)
+    dyg.copy_(dy.to(DEV))
+    if ops.wgrad_aff_ok(rawg, wg, 1, p, d):
+        dw = torch.empty_like(wg)
+        ops.conv_wgrad(rawg, dyg, dw, 1, p, d, aff=coefs)
+        close(dw, wr.grad, 2e-4, 2e-4 * float(wr.grad.abs().max()), "wgrad through BN+ReLU")
+    # ---- dgrad with the BatchNorm-backward front half in the epilogue (with and without an addend)
+    for add in (None, torch.randn(raw.shape, generator=g)):
+        gbuf = ops.new_act(n, cin, h, w, DEV)
+        bpart = torch.empty((-(-n * h * w // 64), 2, cin), device=DEV)
+        assert ops.conv_dgrad_bnb(dyg, wg, gbuf, rawg, coefs, True, bpart, 1, p, d, addend=None if add is None else nhwc(add))
+        dx = ar.grad if add is None else ar.grad + add
+        g_ref = dx * (raw * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) > 0)
+        close(gbuf, g_ref, 1e-4, 1e-4, "g = relumask * dx")
+        xhat = (raw - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+        sums = bpart.sum(0).cpu()
+        close(sums[0], g_ref.sum((0, 2, 3)), 1e-4, 1e-3, "sum g")
+        close(sums[1], (g_ref * xhat).sum((0, 2, 3)), 1e-4, 2e-3, "sum g*xhat")
+    gb2 = ops.new_act(n, cin, h, w, DEV)
+    assert ops.conv_dgrad_bnb(dyg, wg, gb2, rawg, coefs, False, bpart, 1, p, d)
+    close(gb2, ar.grad, 1e-4, 1e-4, "no ReLU: g = dx")
+
+
 def test_conv_reads_and_writes_channel_slices(ops):
     g = torch.Generator().manual_seed(5)
     big_in = nhwc(torch.randn(2, 96, 10, 10, generator=g))
