@@ -28,6 +28,16 @@ HBM_PEAK_GBS = 8000.0
 CFG = dict(depth=50, n_fine=9, coarse_to_fine_map=[[0, 3], [4, 6], [7], [8]], size=512, batch=16)
 
 
+def csrc_sha():
+    """hash of the kernel sources (profiles/*_hbm_traffic.json records the one it was measured with)"""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "seghiero_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "seghiero_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
 def cpu_baseline(seconds_budget=30.0):
     """Reference CPU train loop (the oracle) at the headline shape, bounded: batch 2 at 512x512, ResNet-50."""
     from oracle.step import OracleTrainer
@@ -55,8 +65,8 @@ def cpu_baseline(seconds_budget=30.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=150)        # ~5 s timed region: a sustained-clock number
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=CFG["batch"])
     ap.add_argument("--syncbn", action="store_true",
@@ -120,42 +130,56 @@ def main():
     with ops.profile() as prof:
         tr.train_step(img, lab8, 0)
     barrier()
-    rows = prof.rows
+    rows, shapes = prof.rows, prof.shapes
+    total_ms = sum(v["ms"] for v in rows.values())
+
+    def price(name, r):
+        """achieved rate of one kernel (family or single shape) against the roofline that bounds it"""
+        x6 = "_x6" in name
+        if r["flops"] > 0:
+            peak = BF16_MFMA_PEAK_TF / 6.0 if x6 else FP32_MFMA_PEAK_TF
+            ach = r["flops"] / (r["ms"] * 1e-3) / 1e12
+            return {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4)}
+        return {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None}
+
     dom = max(rows, key=lambda k: rows[k]["ms"])
     r = rows[dom]
-    total_ms = sum(v["ms"] for v in rows.values())
-    x6 = dom.endswith("_x6")
-    peak = BF16_MFMA_PEAK_TF / 6.0 if x6 else FP32_MFMA_PEAK_TF
-    roof = {"bound": "mfma", "kernel": dom, "achieved": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2),
-            "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(r["flops"] / (r["ms"] * 1e-3) / 1e12 / peak, 4),
+    roof = {"kernel": dom, **price(dom, r),
             "peak_note": ("fp32-equivalent peak of the 6x bf16-split MFMA path = 2500 TF dense bf16 / 6 products; "
-                          "the plain f32 MFMA peak is 157.3 TF") if x6 else "dense f32 MFMA peak",
+                          "the plain f32 MFMA peak is 157.3 TF") if "_x6" in dom else "dense f32 MFMA peak",
             "traffic": None, "launches": r["calls"], "avg_launch_us": round(1e3 * r["ms"] / r["calls"], 1),
             "alg_bytes_per_step": r["bytes"], "alg_flops_per_step": r["flops"],
-            "share_of_step": round(r["ms"] / total_ms, 3)}
-    # HBM traffic of the same kernel family from the committed PMC passes (tools/profile_bench.sh ->
-    # tools/summarize_profile.py): rocprofv3 cannot wrap this process from the inside, so the number is read from
-    # profiles/ and labelled with its source.
+            "share_of_step": round(r["ms"] / total_ms, 3), "scope": "kernel family: all launches of this C-ABI entry point in one step"}
+    # the dominant SINGLE kernel: one entry point on one layer shape (several launches only where layers repeat the shape)
+    if shapes:
+        (sname, skey), sr = max(shapes.items(), key=lambda kv: kv[1]["ms"])
+        roof["single"] = {"kernel": sname, "shape": skey, **price(sname, sr), "launches": sr["calls"],
+                          "avg_launch_us": round(1e3 * sr["ms"] / sr["calls"], 1), "share_of_step": round(sr["ms"] / total_ms, 3)}
+    # HBM traffic of the same kernel family from the committed PMC passes (tools/profile_bench.sh -> tools/summarize_profile.py):
+    # rocprofv3 cannot wrap this process from the inside, so the number is read from profiles/ and labelled with its source; the
+    # profile records the hash of csrc/ it was taken with, and a number from other kernel sources is flagged stale.
     fam = {"sh_conv_fprop_x6": "conv_fprop_x6", "sh_conv_dgrad_x6": "conv_dgrad_x6", "sh_conv_wgrad_x6": "conv_wgrad_x6",
+           "sh_conv_fprop_x6_aff": "conv_fprop_x6", "sh_conv_dgrad_x6_bnb": "conv_dgrad_x6", "sh_conv_wgrad_x6_aff": "conv_wgrad_x6",
            "sh_conv_fprop": "conv_fprop_f32", "sh_conv_dgrad": "conv_dgrad_f32", "sh_conv_wgrad": "conv_wgrad_f32"}.get(dom)
     try:
         import glob
         tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))[-1]
-        tj = json.load(open(tf))["per_kernel_family"].get(fam)
+        tjs = json.load(open(tf))
+        tj = tjs["per_kernel_family"].get(fam)
         if tj:
             roof["traffic"] = round(tj["hbm_bytes_per_launch"])
-            roof["traffic_source"] = os.path.relpath(tf, ROOT) + " (PMC FETCH_SIZE x2 + WRITE_SIZE, per launch)"
+            roof["traffic_source"] = os.path.relpath(tf, ROOT) + " (PMC FETCH_SIZE x2 + WRITE_SIZE, per launch of the family)"
             roof["alg_bytes_per_launch"] = round(r["bytes"] / r["calls"])
+            roof["traffic_stale"] = tjs.get("csrc_sha") != csrc_sha()
     except Exception:
         pass
-    if r["flops"] == 0:
-        roof.update(bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None)
     breakdown = {k: round(v["ms"], 2) for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])[:12]}
     out = {
         "metric": "images/sec at 512x512 (ResNet-50 2-level), full train step", "value": round(args.batch * world * args.steps / dt, 2),
         "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32 (convolutions: exact 3-way bf16 split of every fp32 operand, 6 bf16 MFMA products, f32 accumulate; rest plain f32)",
+        "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: ResNet-50 + DepthwiseSeparableASPPContrastHead + 2-level HieraTripletLoss "
                                "+ aux head, 9 fine / 4 coarse, 512x512 synthetic, fwd+loss+bwd+SGD",
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world,

@@ -133,13 +133,21 @@ int sh_conv_wgrad_x6_aff(const float* x, int ldx, const float* in_scale, const f
  * w is [C][3][3].  stat_partials: [sh_dw_partials(N,H,W)][2][C]. */
 int sh_dw_partials(int N, int H, int W);
 int sh_dw_tile_rows(void);                      /* rows per stat-partial of sh_dwconv_fprop (=64) */
-int sh_dwconv_fprop(const float* x, int ldx, const float* w, float* y, int ldy, float* stat_partials,
-                    int N, int H, int W, int C, int dil, void* stream);
+/* in_scale / in_shift (optional, both or neither, [C], 16-byte aligned): x is the RAW output of the producer convolution and is
+ * read as relu(x * in_scale[c] + in_shift[c]) -- the producer's train-mode BatchNorm + ReLU in the loader (zero padding stays
+ * zero), see sh_conv_fprop_x6_aff. */
+int sh_dwconv_fprop(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* w, float* y, int ldy,
+                    float* stat_partials, int N, int H, int W, int C, int dil, void* stream);
 int sh_dwconv_dgrad(const float* dy, int lddy, const float* w, float* dx, int lddx,
                     int N, int H, int W, int C, int dil, int accumulate, void* stream);
+/* ... with the front half of the producer layer's BatchNorm backward in the epilogue (see sh_conv_dgrad_x6_bnb):
+ * g <- relumask(y_prev*scale + shift) * dx, stat_partials[sh_dw_partials(N,H,W)][2][C] <- (sum g, sum g*xhat) per 64 pixels. */
+int sh_dwconv_dgrad_bnb(const float* dy, int lddy, const float* w, float* g, int ldg, const float* y_prev, int ldyp,
+                        const float* mean, const float* invstd, const float* scale, const float* shift,
+                        float* stat_partials, int N, int H, int W, int C, int dil, void* stream);
 /* dw_partials: [sh_dw_partials(N,H,W)][9][C] floats; dw: [C][9] */
-int sh_dwconv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw_partials, float* dw,
-                    int N, int H, int W, int C, int dil, void* stream);
+int sh_dwconv_wgrad(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* dy, int lddy,
+                    float* dw_partials, float* dw, int N, int H, int W, int C, int dil, void* stream);
 
 /* batch norm ------------------------------------------------------------------------------ */
 /* Train-mode nn.BatchNorm2d (every BN of the path; math: SURVEY A.2).  Combines the centred stat partials
@@ -188,8 +196,11 @@ int sh_bn_bwd_apply(const float* dout, int lddo, const float* out, int ldo, cons
 /* pooling / resampling -------------------------------------------------------------------- */
 /* nn.MaxPool2d(3, 2, 1) (models/backbone/resnet.py:68) and its backward (first-max tie rule).  argmax: one byte per
  * output element [N,Ho,Wo,C] = window position kh*3+kw of the first maximum (NULL in fwd = not recorded); the backward
- * gathers from it and dy alone (x is not re-read, so the stem activation need not be kept). */
-int sh_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int N, int H, int W, int C, void* stream);
+ * gathers from it and dy alone (x is not re-read, so the stem activation need not be kept).  in_scale / in_shift (optional):
+ * x is the stem conv's RAW output, read as relu(x * in_scale[c] + in_shift[c]) -- stem_bn + stem_relu (resnet.py:65-67) in the
+ * pooling kernel's loader, so the 64-channel half-resolution activation is never materialised. */
+int sh_maxpool_fwd(const float* x, const float* in_scale, const float* in_shift, float* y, uint8_t* argmax, int N, int H,
+                   int W, int C, void* stream);
 int sh_maxpool_bwd(const uint8_t* argmax, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
 /* nn.AdaptiveAvgPool2d(1) (sep_aspp_contrast_head.py:93,104): x [N,HW,C] -> y [N,C]; backward broadcasts. */
 int sh_avgpool_fwd(const float* x, int ldx, float* y, int N, int HW, int C, void* stream);

@@ -128,8 +128,11 @@ class _BackboneFn(torch.autograd.Function):
             raise SegHieroHipError("stem_conv.weight must be contiguous")
         wpad = ops.new_act(w.shape[0], 4, 7, 7, w.device, zero=True)
         ops._call("sh_nchw_to_nhwc", w.data_ptr(), wpad.data_ptr(), w.shape[0], 3, 7, 7, 4, ops._st())
-        s_out, s_rec = L.cba_fwd(x4, wpad, L.conv_geom(mod.stem_conv), mod.stem_bn, True, training)
-        pooled, pool_idx = ops.maxpool_fwd(s_out, want_argmax=training)
+        s_out, s_rec = L.cba_fwd(x4, wpad, L.conv_geom(mod.stem_conv), mod.stem_bn, True, training, lazy=True)
+        if isinstance(s_out, L.Lazy):          # stem_bn + stem_relu run in the pooling kernel's loader
+            pooled, pool_idx = ops.maxpool_fwd(s_out.y, want_argmax=training, aff=s_out.coefs)
+        else:
+            pooled, pool_idx = ops.maxpool_fwd(s_out, want_argmax=training)
         h = pooled
         saved, outs = [], []
         for layer in (mod.layer1, mod.layer2, mod.layer3, mod.layer4):

@@ -38,6 +38,7 @@ struct ConvQ {
     const float* bnb_scale;
     const float* bnb_shift;
     int bnb_relu;
+    int vec_epi;            // output / addend / bnb_y rows are 16-byte addressable: row-major float4 epilogue through LDS
     unsigned a_bytes, b_bytes;  // extents of the A / B operands for the buffer descriptors (bytes, < 2^31)
 };
 

@@ -304,44 +304,134 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
             if (nok[j]) { b_mu[j] = p.bnb_mean[ncol[j]]; b_is[j] = p.bnb_invstd[ncol[j]]; b_sc[j] = p.bnb_scale[ncol[j]]; b_sh[j] = p.bnb_shift[ncol[j]]; }
         }
     }
+    // ---- row-major epilogue through LDS (the planes are free after the loop's last barrier).  An accumulator register holds ONE
+    // column per lane, so a direct epilogue moves 4 bytes per lane and instruction (64 loads + 64 stores per lane for a 64 x 64
+    // wave tile, more with an addend or the BatchNorm-backward y tile).  Each wave instead parks 32 rows of its tile in its own LDS
+    // strip, reads them back as one float4 of a row per lane, and every global access (output, addend, y) is a 16-byte load /
+    // store, 256 contiguous bytes per 16 lanes: a quarter of the memory instructions, all loads of a strip issued before its stores.
+    if (EPI == 2 || p.vec_epi) {       // (the BatchNorm-backward epilogue exists in this form only)
+        constexpr int WC = 32 * TN, RS = WC + 4, LPR = WC / 4, RPI = 64 / LPR, NRD = 32 / RPI;
+        float* const stage = reinterpret_cast<float*>(smem) + wave * (32 * RS);
+        const int rr = lane / LPR, c4 = (lane % LPR) * 4;
+        const int ncv = n0 + wn * WC + c4;
+        const bool nokv = ncv < p.Nn;
+        f32x4 vb = zero4, v_mu = zero4, v_is = zero4, v_sc = zero4, v_sh = zero4;
+        if (MODE == FPROP && p.extra != nullptr && nokv) vb = ld4(p.extra + ncv);
+        if constexpr (EPI == 2) { if (nokv) { v_mu = ld4(p.bnb_mean + ncv); v_is = ld4(p.bnb_invstd + ncv); v_sc = ld4(p.bnb_scale + ncv); v_sh = ld4(p.bnb_shift + ncv); } }
+        [[maybe_unused]] f32x4 pend_gs = zero4, pend_gq = zero4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * RS + 32 * j + l31] = acc[i][j][r];
+            __syncthreads();
+            f32x4 v[NRD];
+            [[maybe_unused]] f32x4 ad[NRD], yv[NRD];
+            long long mrow[NRD];
+#pragma unroll
+            for (int k = 0; k < NRD; ++k) {
+                const int row = k * RPI + rr;
+                mrow[k] = m0 + wm * 32 * TM + 32 * i + row;
+                v[k] = *reinterpret_cast<const f32x4*>(stage + row * RS + c4);
+                if constexpr (MODE == DGRAD) {
+                    ad[k] = zero4;
+                    if (mrow[k] < Mc && nokv) {
+                        if (p.extra != nullptr) ad[k] = ld4(p.extra + mrow[k] * p.ldadd + ncv);
+                        if constexpr (EPI == 2) yv[k] = ld4(p.bnb_y + mrow[k] * p.bnb_ldy + ncv);
+                    }
+                }
+            }
+            [[maybe_unused]] f32x4 gs = zero4, gq = zero4;
+#pragma unroll
+            for (int k = 0; k < NRD; ++k) {
+                if (mrow[k] < Mc && nokv) {
+                    f32x4 o = v[k];
+                    if constexpr (MODE == FPROP) o += vb;
+                    else {
+                        o += ad[k];
+                        if constexpr (EPI == 2) {
+                            if (p.bnb_relu) {
+                                const f32x4 a = yv[k] * v_sc + v_sh;                  // the forward's own arithmetic (bn_act_kernel)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) if (!(a[e] > 0.f)) o[e] = 0.f;
+                            }
+                            gs += o; gq += o * ((yv[k] - v_mu) * v_is);
+                        }
+                    }
+                    st4(p.c + mrow[k] * p.ldc + ncv, o);
+                }
+            }
+            if constexpr (EPI == 2) {      // column sums over the strip's 32 rows: across the RPI row groups of the wave
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int o2 = LPR; o2 < 64; o2 <<= 1) { gs[e] += __shfl_xor(gs[e], o2, 64); gq[e] += __shfl_xor(gq[e], o2, 64); }
+                }
+                if ((i & 1) == 0) { pend_gs = gs; pend_gq = gq; }
+                else {
+                    const int pidx = tile_m * (BM / 64) + wm * (TM / 2) + (i >> 1);
+                    if (lane < LPR && pidx < p.n_partials && nokv) {
+                        st4(p.partials + ((long long)pidx * 2 + 0) * p.Nn + ncv, pend_gs + gs);
+                        st4(p.partials + ((long long)pidx * 2 + 1) * p.Nn + ncv, pend_gq + gq);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    } else if constexpr (EPI != 2) {
     [[maybe_unused]] float pend_s[TN], pend_q[TN];          // EPI == 2: sums of the even tile of a 64-row group
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         [[maybe_unused]] float gs[TN], gq[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
+        // Two passes per 32-row tile: FIRST every load of the tile (addend, BatchNorm-backward y), THEN arithmetic and stores.  In one
+        // fused loop each load would have to wait for the previous element's store (the output may alias the inputs as far as the
+        // compiler can tell), i.e. 64 dependent round trips per lane -- measured: +28 % on the 512->512 @128^2 dgrad.
+        long long orow[16];
+        bool mok[16];
+        [[maybe_unused]] float ad[16][TN], yv[16][TN];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 32 * TM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const bool mok = m < Mc;
-            long long orow = m;                               // row of the output (and of addend / bnb_y) this element belongs to
+            mok[r] = m < Mc;
+            orow[r] = m;                                      // row of the output (and of addend / bnb_y) this element belongs to
             if constexpr (MODE == DGRAD) {
                 if (p.parity) {
                     const int iwc = m % Wc, q2 = m / Wc, ihc = q2 % Hc, nb2 = q2 / Hc;
-                    orow = ((long long)nb2 * p.H + 2 * ihc + oy0) * p.W + 2 * iwc + ox0;
+                    orow[r] = ((long long)nb2 * p.H + 2 * ihc + oy0) * p.W + 2 * iwc + ox0;
                 } else if (p.scatter) {
                     const int ow = m % p.W, q = m / p.W, oh = q % p.H, nb = q / p.H;
-                    orow = (long long)(nb * p.sH + oh * p.sstride) * p.sW + ow * p.sstride;
+                    orow[r] = (long long)(nb * p.sH + oh * p.sstride) * p.sW + ow * p.sstride;
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    ad[r][j] = 0.f;
+                    if (mok[r] && nok[j]) {
+                        if (p.scatter) ad[r][j] = p.c[orow[r] * p.ldc + ncol[j]];                 // accumulate into the existing gradient
+                        else if (p.extra != nullptr) ad[r][j] = p.extra[orow[r] * p.ldadd + ncol[j]];
+                        if constexpr (EPI == 2) yv[r][j] = p.bnb_y[orow[r] * p.bnb_ldy + ncol[j]];
+                    }
                 }
             }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                if (mok && nok[j]) {
+                if (mok[r] && nok[j]) {
                     float v = acc[i][j][r];
-                    float* dst = p.c + orow * p.ldc + ncol[j];
+                    float* dst = p.c + orow[r] * p.ldc + ncol[j];
                     if constexpr (MODE == FPROP) {
                         *dst = v + bias[j];
                     } else {
-                        if (p.scatter) { *dst += v; }
-                        else {
-                            if (p.extra != nullptr) v += p.extra[orow * p.ldadd + ncol[j]];
-                            if constexpr (EPI == 2) {
-                                const float yv = p.bnb_y[orow * p.bnb_ldy + ncol[j]];
-                                if (p.bnb_relu && !(yv * b_sc[j] + b_sh[j] > 0.f)) v = 0.f;      // the forward's own arithmetic (bn_act_kernel)
-                                gs[j] += v; gq[j] += v * ((yv - b_mu[j]) * b_is[j]);
-                            }
-                            *dst = v;
+                        v += ad[r][j];
+                        if constexpr (EPI == 2) {
+                            if (p.bnb_relu && !(yv[r][j] * b_sc[j] + b_sh[j] > 0.f)) v = 0.f;      // the forward's own arithmetic (bn_act_kernel)
+                            gs[j] += v; gq[j] += v * ((yv[r][j] - b_mu[j]) * b_is[j]);
                         }
+                        *dst = v;
                     }
                 }
             }
@@ -361,6 +451,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
             }
         }
     }
+    }      // scalar epilogue
     if constexpr (MODE == FPROP && EPI == 1) {
         if (p.partials != nullptr) {
             const int wrow0 = m0 + wm * 32 * TM;
@@ -425,16 +516,16 @@ static int launch_x6p(ConvQ& p, hipStream_t st) {
 template <int MODE, int AFF, int EPI, int TAP>
 static int pick_tile_x6p(ConvQ& p, hipStream_t st, int force) {
     (void)force;
-    if (p.Nn > 64) return launch_x6p<MODE, 2, 2, 2, 2, 2, AFF, EPI, 0, TAP>(p, st);      // 128 x 128, 4 waves of 64 x 64
-    return launch_x6p<MODE, 2, 1, 2, 2, 2, AFF, EPI, 0, TAP>(p, st);                     // 128 x 64
+    if (p.Nn > 64) return launch_x6p<MODE, 2, 2, 2, 2, 3, AFF, EPI, 0, TAP>(p, st);      // 128 x 128, 4 waves of 64 x 64, 3 blocks per CU
+    return launch_x6p<MODE, 2, 1, 2, 2, 4, AFF, EPI, 0, TAP>(p, st);                     // 128 x 64, 4 blocks per CU
 }
 
 template <int MODE, int AFF, int EPI>
 static int pick_x6p(ConvQ& p, hipStream_t st, int force) {
     if (p.ksplit > 1) {          // K slices (mid-network shapes with an under-filled grid): 128 x 128 tiles into slabs, then the reduce
         int rc;
-        if (p.KH * p.KW == 1) rc = launch_x6p<MODE, 2, 2, 2, 2, 2, AFF, 0, 1, 0>(p, st);
-        else if ((p.Kc & 15) == 0) rc = launch_x6p<MODE, 2, 2, 2, 2, 2, AFF, 0, 1, 1>(p, st);
+        if (p.KH * p.KW == 1) rc = launch_x6p<MODE, 2, 2, 2, 2, 3, AFF, 0, 1, 0>(p, st);
+        else if ((p.Kc & 15) == 0) rc = launch_x6p<MODE, 2, 2, 2, 2, 3, AFF, 0, 1, 1>(p, st);
         else return SH_X6P_NO;
         return rc == SH_OK ? sh_x6_splitk_reduce(p, MODE, st) : rc;
     }
@@ -451,8 +542,14 @@ static int x6p_tile() { static int v = -2; if (v == -2) { const char* e = getenv
 int sh_x6p_launch(int mode, ConvQ& p, hipStream_t st) {
     const bool aff = p.aff_scale != nullptr, bnb = p.bnb_y != nullptr;
     if (!x6p_mode() && !aff && !bnb) return SH_X6P_NO;
-    if ((p.parity || p.scatter) && bnb) return SH_X6P_NO;
     const int force = x6p_tile();
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    p.vec_epi = !p.parity && !p.scatter && (p.Nn & 3) == 0 && (p.ldc & 3) == 0 && al16(p.c) &&
+                (p.extra == nullptr || (al16(p.extra) && (mode == FPROP || (p.ldadd & 3) == 0))) &&
+                (!bnb || ((p.bnb_ldy & 3) == 0 && al16(p.bnb_y) && al16(p.bnb_mean) && al16(p.bnb_invstd) && al16(p.bnb_scale) &&
+                          al16(p.bnb_shift) && al16(p.partials)));
+    if (bnb && !p.vec_epi) return SH_X6P_NO;
+    { static int v = -2; if (v == -2) { const char* e = getenv("SEGHIERO_X6P_VEC"); v = e ? atoi(e) : 1; } if (!v && !bnb) p.vec_epi = 0; }
     if (mode == FPROP) {
         if (bnb) return SH_EINVAL;
         if (aff) return pick_x6p<FPROP, 1, 1>(p, st, force);

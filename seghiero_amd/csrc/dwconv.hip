@@ -11,6 +11,46 @@
 #define DW_PIX 64          // pixels per block
 #define DW_CH 64           // channels per block (16 float4 lanes)
 
+// input read through the producer's train-mode BatchNorm + ReLU (in_scale != nullptr): relu(x * scale + shift) in sh_bn_act's own
+// operation order, applied to in-image taps only (zero padding stays zero) -- see sh_conv_fprop_x6_aff
+__device__ __forceinline__ f32x4 dw_in(const float* p, const float* isc, const float* ish, int c) {
+    f32x4 v = ld4(p);
+    if (isc != nullptr) {
+        v = v * ld4(isc + c) + ld4(ish + c);
+        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+    }
+    return v;
+}
+
+// dgrad epilogue = front half of the BatchNorm backward of the layer that produced the conv's input (see sh_conv_dgrad_x6_bnb):
+// g = relumask(y * scale + shift) * dx is stored and (sum g, sum g * xhat) per 64-pixel block go to `partials`
+struct DwBnb { const float* y; long long ldy; const float* mean; const float* invstd; const float* scale; const float* shift; float* partials; };
+__device__ __forceinline__ f32x4 dw_bnb_apply(const DwBnb& b, long long m, int c, f32x4 dx, f32x4& sg, f32x4& sq) {
+    const f32x4 yv = ld4(b.y + m * b.ldy + c);
+    const f32x4 a = yv * ld4(b.scale + c) + ld4(b.shift + c);                // the forward's own arithmetic (bn_act_kernel)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (!(a[j] > 0.f)) dx[j] = 0.f;
+    sg += dx;
+    sq += dx * ((yv - ld4(b.mean + c)) * ld4(b.invstd + c));
+    return dx;
+}
+// block-level sum over the 16 pixel lanes of the two statistics -> partials[pidx][2][C]   (red: [16][DW_CH] LDS scratch)
+__device__ __forceinline__ void dw_bnb_store(const DwBnb& b, float (*red)[64], f32x4 sg, f32x4 sq, long long pidx, int C, int c0, int t, int cq, int pl) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[pl][cq * 4 + j] = pass == 0 ? sg[j] : sq[j];
+        __syncthreads();
+        if (t < 64 && c0 + t < C) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a += red[k][t];
+            b.partials[(pidx * 2 + pass) * C + c0 + t] = a;
+        }
+    }
+}
+
 extern "C" int sh_dw_partials(int N, int H, int W) { return (int)sh_cdiv((long long)N * H * W, DW_PIX); }
 extern "C" int sh_dw_tile_rows(void) { return DW_PIX; }
 
@@ -18,7 +58,8 @@ extern "C" int sh_dw_tile_rows(void) { return DW_PIX; }
 template <int MODE>   // 0 fprop (+stats), 1 dgrad (flipped taps)
 __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ w,
                                                      float* __restrict__ y, long long ldy, float* __restrict__ partials,
-                                                     int H, int W, int C, int dil, long long M, int accumulate) {
+                                                     int H, int W, int C, int dil, long long M, int accumulate,
+                                                     const float* __restrict__ isc, const float* __restrict__ ish, const DwBnb bnb) {
     __shared__ float ws[9][DW_CH];
     __shared__ float red[16][DW_CH];
     __shared__ float colmean[DW_CH];
@@ -33,6 +74,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
     const int c = c0 + cq * 4;
     const bool cok = c < C;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bsg = s, bsq = s;
     f32x4 kept[DW_PIX / 16];
     bool kept_ok[DW_PIX / 16];
     const bool tap_row_ok = dil < H, tap_col_ok = dil < W;   // off-centre taps can touch the image at all?
@@ -57,16 +99,18 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
                     if (kw != 1 && !tap_col_ok) continue;
                     const int iw = ow + (kw - 1) * dil;
                     if ((unsigned)iw >= (unsigned)W) continue;
-                    const f32x4 v = ld4(x + ((n * H + ih) * W + iw) * ldx + c);
+                    const f32x4 v = dw_in(x + ((n * H + ih) * W + iw) * ldx + c, isc, ish, c);
                     const f32x4 wv = ld4(&ws[kh * 3 + kw][cq * 4]);
                     acc += v * wv;
                 }
             }
             if (MODE == 1 && accumulate) acc += ld4(y + m * ldy + c);
+            if (MODE == 1 && bnb.y != nullptr) acc = dw_bnb_apply(bnb, m, c, acc, bsg, bsq);
             st4(y + m * ldy + c, acc);
             s += acc; kept[it] = acc; kept_ok[it] = true;
         }
     }
+    if (MODE == 1 && bnb.y != nullptr) dw_bnb_store(bnb, red, bsg, bsq, blockIdx.x, C, c0, t, cq, pl);
     if (MODE == 0 && partials != nullptr) {
         // per-block partial = (sum, M2 about the block's own mean) -- centred, see conv_gemm.hip
         const long long left = M - (long long)blockIdx.x * DW_PIX;
@@ -106,7 +150,8 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
 template <int MODE>   // 0 fprop (+stats), 1 dgrad (flipped taps, optional accumulate)
 __global__ __launch_bounds__(256) void dwconv_tile_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ w,
                                                           float* __restrict__ y, long long ldy, float* __restrict__ partials,
-                                                          int H, int W, int C, int accumulate) {
+                                                          int H, int W, int C, int accumulate,
+                                                          const float* __restrict__ isc, const float* __restrict__ ish, const DwBnb bnb) {
     __shared__ __attribute__((aligned(16))) float xs[(DT + 2) * (DT + 2)][DW_CH];
     __shared__ float ws[9][DW_CH];
     __shared__ float red[16][DW_CH];
@@ -129,11 +174,12 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const float* __restric
         const int hy = i / (DT + 2), hx = i - hy * (DT + 2);
         const int iy = ty * DT + hy - 1, ix = tx * DT + hx - 1;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (cok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = ld4(x + ((n * H + iy) * W + ix) * ldx + c);
+        if (cok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = dw_in(x + ((n * H + iy) * W + ix) * ldx + c, isc, ish, c);
         st4(&xs[i][cq * 4], v);
     }
     __syncthreads();
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bsg = s, bsq = s;
     f32x4 kept[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -146,12 +192,15 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const float* __restric
                 acc += ld4(&xs[(py + kh) * (DT + 2) + px + kw][cq * 4]) * ld4(&ws[kh * 3 + kw][cq * 4]);
         kept[it] = acc;
         if (cok) {
-            float* dst = y + ((n * H + ty * DT + py) * W + tx * DT + px) * ldy + c;
+            const long long m = (n * H + ty * DT + py) * W + tx * DT + px;
+            float* dst = y + m * ldy + c;
             if (MODE == 1 && accumulate) acc += ld4(dst);
+            if (MODE == 1 && bnb.y != nullptr) acc = dw_bnb_apply(bnb, m, c, acc, bsg, bsq);
             st4(dst, acc);
         }
         s += kept[it];
     }
+    if (MODE == 1 && bnb.y != nullptr) dw_bnb_store(bnb, red, bsg, bsq, tile, C, c0, t, cq, pl);
     if (MODE == 0 && partials != nullptr) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) red[pl][cq * 4 + j] = s[j];
@@ -182,7 +231,7 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const float* __restric
 // wgrad, tiled: each block walks tiles (grid-stride), x halo staged in LDS, nine accumulators per thread
 __global__ __launch_bounds__(256) void dwconv_wgrad_tile_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ dy,
                                                                long long lddy, float* __restrict__ partials, int H, int W, int C,
-                                                               long long ntiles) {
+                                                               long long ntiles, const float* __restrict__ isc, const float* __restrict__ ish) {
     __shared__ __attribute__((aligned(16))) float xs[(DT + 2) * (DT + 2)][DW_CH];
     __shared__ float red[16][DW_CH];
     const int t = threadIdx.x, cq = t & 15, pl = t >> 4;
@@ -202,7 +251,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tile_kernel(const float* __r
             const int hy = i / (DT + 2), hx = i - hy * (DT + 2);
             const int iy = ty * DT + hy - 1, ix = tx * DT + hx - 1;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (cok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = ld4(x + ((n * H + iy) * W + ix) * ldx + c);
+            if (cok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = dw_in(x + ((n * H + iy) * W + ix) * ldx + c, isc, ish, c);
             st4(&xs[i][cq * 4], v);
         }
         __syncthreads();
@@ -236,7 +285,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tile_kernel(const float* __r
 // wgrad: dw[c][tap] = sum_pix dy[pix][c] * x[pix + tap][c]; per-block partials [P][9][C], then a column reduce.
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ dy,
                                                            long long lddy, float* __restrict__ partials, int H, int W, int C,
-                                                           int dil, long long M) {
+                                                           int dil, long long M, const float* __restrict__ isc, const float* __restrict__ ish) {
     __shared__ float red[16][DW_CH];
     const int t = threadIdx.x, cq = t & 15, pl = t >> 4;
     const int c0 = blockIdx.y * DW_CH, c = c0 + cq * 4;
@@ -263,7 +312,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restri
                     for (int kw = 0; kw < 3; ++kw) {
                         const int iw = ow + (kw - 1) * dil;
                         if ((unsigned)iw >= (unsigned)W) continue;
-                        acc[kh * 3 + kw] += g * ld4(x + ((n * H + ih) * W + iw) * ldx + c);
+                        acc[kh * 3 + kw] += g * dw_in(x + ((n * H + ih) * W + iw) * ldx + c, isc, ish, c);
                     }
                 }
             }
@@ -302,40 +351,55 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_reduce_kernel(const float* _
 static bool dw_args_ok(const void* a, const void* b, const void* c, int N, int H, int W, int C, int dil, int ld1, int ld2) {
     return a && b && c && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && dil > 0 && ld1 >= C && ld2 >= C && !(ld1 & 3) && !(ld2 & 3);
 }
-extern "C" int sh_dwconv_fprop(const float* x, int ldx, const float* w, float* y, int ldy, float* stat_partials,
-                               int N, int H, int W, int C, int dil, void* stream) {
+extern "C" int sh_dwconv_fprop(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* w, float* y, int ldy,
+                               float* stat_partials, int N, int H, int W, int C, int dil, void* stream) {
     if (!dw_args_ok(x, w, y, N, H, W, C, dil, ldx, ldy)) return SH_EINVAL;
+    if ((in_scale == nullptr) != (in_shift == nullptr) || (((uintptr_t)in_scale | (uintptr_t)in_shift) & 15)) return SH_EINVAL;
     const long long M = (long long)N * H * W;
     dim3 grid((unsigned)sh_cdiv(M, DW_PIX), (unsigned)sh_cdiv(C, DW_CH));
     if (dil == 1 && H % DT == 0 && W % DT == 0)       // same partial count: (H/8)*(W/8) tiles of 64 pixels per image
-        dwconv_tile_kernel<0><<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(x, ldx, w, y, ldy, stat_partials, H, W, C, 0);
+        dwconv_tile_kernel<0><<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(x, ldx, w, y, ldy, stat_partials, H, W, C, 0, in_scale, in_shift, DwBnb{});
     else
-        dwconv_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, w, y, ldy, stat_partials, H, W, C, dil, M, 0);
+        dwconv_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, w, y, ldy, stat_partials, H, W, C, dil, M, 0, in_scale, in_shift, DwBnb{});
+    return sh_launch_status();
+}
+static int dw_dgrad_any(const float* dy, int lddy, const float* w, float* dx, int lddx, int N, int H, int W, int C, int dil, int accumulate,
+                        const DwBnb& bnb, void* stream) {
+    const long long M = (long long)N * H * W;
+    dim3 grid((unsigned)sh_cdiv(M, DW_PIX), (unsigned)sh_cdiv(C, DW_CH));
+    if (dil == 1 && H % DT == 0 && W % DT == 0)
+        dwconv_tile_kernel<1><<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(dy, lddy, w, dx, lddx, nullptr, H, W, C, accumulate, nullptr, nullptr, bnb);
+    else
+        dwconv_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(dy, lddy, w, dx, lddx, nullptr, H, W, C, dil, M, accumulate, nullptr, nullptr, bnb);
     return sh_launch_status();
 }
 extern "C" int sh_dwconv_dgrad(const float* dy, int lddy, const float* w, float* dx, int lddx, int N, int H, int W, int C,
                                int dil, int accumulate, void* stream) {
     if (!dw_args_ok(dy, w, dx, N, H, W, C, dil, lddy, lddx)) return SH_EINVAL;
-    const long long M = (long long)N * H * W;
-    dim3 grid((unsigned)sh_cdiv(M, DW_PIX), (unsigned)sh_cdiv(C, DW_CH));
-    if (dil == 1 && H % DT == 0 && W % DT == 0)
-        dwconv_tile_kernel<1><<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(dy, lddy, w, dx, lddx, nullptr, H, W, C, accumulate);
-    else
-        dwconv_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(dy, lddy, w, dx, lddx, nullptr, H, W, C, dil, M, accumulate);
-    return sh_launch_status();
+    return dw_dgrad_any(dy, lddy, w, dx, lddx, N, H, W, C, dil, accumulate, DwBnb{}, stream);
 }
-extern "C" int sh_dwconv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw_partials, float* dw,
-                               int N, int H, int W, int C, int dil, void* stream) {
+// ... with the front half of the producer layer's BatchNorm backward in the epilogue (see sh_conv_dgrad_x6_bnb): g <- relumask * dx,
+// stat_partials[sh_dw_partials(N,H,W)][2][C] <- (sum g, sum g * xhat) per 64-pixel block.  y_prev: raw output of the producer conv.
+extern "C" int sh_dwconv_dgrad_bnb(const float* dy, int lddy, const float* w, float* g, int ldg, const float* y_prev, int ldyp,
+                                   const float* mean, const float* invstd, const float* scale, const float* shift, float* stat_partials,
+                                   int N, int H, int W, int C, int dil, void* stream) {
+    if (!dw_args_ok(dy, w, g, N, H, W, C, dil, lddy, ldg) || !y_prev || !mean || !invstd || !scale || !shift || !stat_partials) return SH_EINVAL;
+    if (ldyp < C || (ldyp & 3) || (((uintptr_t)y_prev | (uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)scale | (uintptr_t)shift) & 15)) return SH_EINVAL;
+    return dw_dgrad_any(dy, lddy, w, g, ldg, N, H, W, C, dil, 0, DwBnb{y_prev, ldyp, mean, invstd, scale, shift, stat_partials}, stream);
+}
+extern "C" int sh_dwconv_wgrad(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* dy, int lddy,
+                               float* dw_partials, float* dw, int N, int H, int W, int C, int dil, void* stream) {
     if (!dw_args_ok(x, dy, dw, N, H, W, C, dil, ldx, lddy) || !dw_partials) return SH_EINVAL;
+    if ((in_scale == nullptr) != (in_shift == nullptr) || (((uintptr_t)in_scale | (uintptr_t)in_shift) & 15)) return SH_EINVAL;
     const long long M = (long long)N * H * W;
     int P = (int)sh_cdiv(M, DW_PIX);
     const int cap = (int)sh_cdiv(1024, sh_cdiv(C, DW_CH));          // ~4 blocks per CU over all channel chunks
     if (P > cap) P = cap < 1 ? 1 : cap;
     dim3 grid((unsigned)P, (unsigned)sh_cdiv(C, DW_CH));
     if (dil == 1 && H % DT == 0 && W % DT == 0)
-        dwconv_wgrad_tile_kernel<<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(x, ldx, dy, lddy, dw_partials, H, W, C, M / (DT * DT));
+        dwconv_wgrad_tile_kernel<<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(x, ldx, dy, lddy, dw_partials, H, W, C, M / (DT * DT), in_scale, in_shift);
     else
-        dwconv_wgrad_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, dy, lddy, dw_partials, H, W, C, dil, M);
+        dwconv_wgrad_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, dy, lddy, dw_partials, H, W, C, dil, M, in_scale, in_shift);
     int rc = sh_launch_status();
     if (rc != SH_OK) return rc;
     dwconv_wgrad_reduce_kernel<<<(unsigned)sh_cdiv(9 * C, 64), 256, 0, (hipStream_t)stream>>>(dw_partials, dw, P, C);

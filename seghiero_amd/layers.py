@@ -209,11 +209,14 @@ class DWRec:
 
 def dw_fwd(x, weight, dil, bn, training, lazy=False):
     """depthwise 3x3 -> BN -> ReLU; lazy=True defers the BatchNorm + ReLU to the pointwise conv's loader (-> Lazy)."""
-    x = dense(x)
     n, c, h, w = x.shape
     y = ops.new_act(n, c, h, w, x.device)
     partials = torch.empty((ops.dw_partials_rows(n, h, w), 2, c), device=x.device) if training else None
-    ops.dwconv_fprop(x, weight, y, partials, dil)
+    if isinstance(x, Lazy) and x._out is None:
+        ops.dwconv_fprop(x.y, weight, y, partials, dil, aff=x.coefs)      # the producer's BN + ReLU in the depthwise loader
+    else:
+        x = dense(x)
+        ops.dwconv_fprop(x, weight, y, partials, dil)
     coefs = _bn_coefs(bn, partials, n * h * w, training, c, x.device)
     if lazy and FUSE_BN and training and ops.CONV_IMPL == "x6":
         out = Lazy(y, coefs)
@@ -230,14 +233,23 @@ def dw_bwd(rec, bn, dout, dx_accumulate_into=None):
     """-> (dx, dweight, dgamma, dbeta); with dx_accumulate_into the input gradient is added into that tensor."""
     dy, dgamma, dbeta, _ = ops.bn_backward(dout, None, rec.y, rec.coefs, bn.weight, 2)
     dw = new_grad(rec.weight)
-    ops.dwconv_wgrad(rec.x, dy, dw, rec.dil, side=True)
+    if isinstance(rec.x, Lazy) and rec.x._out is None:
+        ops.dwconv_wgrad(rec.x.y, dy, dw, rec.dil, side=True, aff=rec.x.coefs)
+    else:
+        ops.dwconv_wgrad(dense(rec.x), dy, dw, rec.dil, side=True)
     if dx_accumulate_into is not None:
         ops.dwconv_dgrad(dy, rec.weight, dx_accumulate_into, rec.dil, accumulate=True)
         dx = dx_accumulate_into
     else:
         n, c, h, w = rec.x.shape
         dx = ops.new_act(n, c, h, w, rec.x.device)
-        ops.dwconv_dgrad(dy, rec.weight, dx, rec.dil)
+        if isinstance(rec.x, Lazy) and FUSE_BN:
+            # the input is a deferred activation: its BatchNorm backward starts in this dgrad's epilogue (-> GradPack)
+            partials = torch.empty((ops.dw_partials_rows(n, h, w), 2, c), device=dx.device, dtype=torch.float32)
+            ops.dwconv_dgrad_bnb(dy, rec.weight, dx, rec.x.y, rec.x.coefs, partials, rec.dil)
+            dx = GradPack(dx, partials)
+        else:
+            ops.dwconv_dgrad(dy, rec.weight, dx, rec.dil)
     return dx, dw, dgamma, dbeta
 
 

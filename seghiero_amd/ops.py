@@ -18,15 +18,16 @@ CONV_IMPL = os.environ.get("SEGHIERO_CONV", "x6")
 _PROF = None          # when set (see `profile()`), every C-ABI call is bracketed by HIP events on its launch stream
 
 
-def _call(name, *args, cost=None):
-    """Launch one C-ABI entry point on the current stream.  `cost` = (algorithmic flops, algorithmic bytes)."""
+def _call(name, *args, cost=None, key=None):
+    """Launch one C-ABI entry point on the current stream.  `cost` = (algorithmic flops, algorithmic bytes); `key` = shape label
+    (profiling only: per-shape rows next to the per-family ones)."""
     if _PROF is None:
         return LIB.call(name, *args)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     rc = LIB.call(name, *args)
     e1.record()
-    _PROF.append((name, cost, e0, e1))
+    _PROF.append((name, cost, e0, e1, key))
     return rc
 
 
@@ -48,14 +49,18 @@ class profile:
         WGRAD_ASYNC = self._async
         rec, _PROF = _PROF, None
         torch.cuda.synchronize()
-        self.rows = {}
-        for name, cost, e0, e1 in rec:
-            r = self.rows.setdefault(name, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
-            r["calls"] += 1
-            r["ms"] += e0.elapsed_time(e1)
-            if cost:
-                r["flops"] += cost[0]
-                r["bytes"] += cost[1]
+        self.rows, self.shapes = {}, {}
+        for name, cost, e0, e1, key in rec:
+            ms = e0.elapsed_time(e1)
+            for table, k in ((self.rows, name), (self.shapes, (name, key))):
+                if k[1] is None and table is self.shapes:
+                    continue
+                r = table.setdefault(k, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+                r["calls"] += 1
+                r["ms"] += ms
+                if cost:
+                    r["flops"] += cost[0]
+                    r["bytes"] += cost[1]
         return False
 
 
@@ -132,6 +137,10 @@ def to_nhwc(t, cpad=None):
 
 
 # ----------------------------------------------------------------------------- conv
+def _ckey(n, h, w, cin, o, kh, stride, dil):
+    return f"{n}x{h}x{w} {cin}->{o} k{kh}" + (f" s{stride}" if stride != 1 else "") + (f" d{dil}" if dil != 1 else "")
+
+
 def conv_out_hw(h, w, kh, kw, stride, pad, dil):
     return (h + 2 * pad - dil * (kh - 1) - 1) // stride + 1, (w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
 
@@ -151,7 +160,7 @@ def w_ohwi(weight):
 UNSUPPORTED = -3          # SH_EUNSUPPORTED: a fused entry point has no instantiation for the geometry (nothing launched)
 
 
-def _call_fused(name, *args, cost=None):
+def _call_fused(name, *args, cost=None, key=None):
     """Fused entry points: True = launched, False = SH_EUNSUPPORTED (the caller runs the unfused sequence); raises otherwise."""
     if _PROF is None:
         rc = LIB.raw(name)(*args)
@@ -161,7 +170,7 @@ def _call_fused(name, *args, cost=None):
         rc = LIB.raw(name)(*args)
         e1.record()
         if rc == 0:
-            _PROF.append((name, cost, e0, e1))
+            _PROF.append((name, cost, e0, e1, key))
     if rc == 0:
         return True
     if rc == UNSUPPORTED:
@@ -184,7 +193,7 @@ def conv_fprop_aff(x, in_coefs, weight, bias, y, partials, stride, pad, dil):
     ws, nb = _splitk_ws(0, n, h, w, cin, o, kh, kw, stride, pad, dil, 0, x.device)
     return _call_fused("sh_conv_fprop_x6_aff", xp, ldx, in_coefs[2].data_ptr(), in_coefs[3].data_ptr(), w_ohwi(weight).data_ptr(),
                        None if bias is None else bias.data_ptr(), yp, ldy, None if partials is None else partials.data_ptr(),
-                       n, h, w, cin, o, kh, kw, stride, pad, dil, ws, nb, _st(), cost=cost)
+                       n, h, w, cin, o, kh, kw, stride, pad, dil, ws, nb, _st(), cost=cost, key=_ckey(n, h, w, cin, o, kh, stride, dil))
 
 
 def conv_fprop(x, weight, bias, y, partials, stride, pad, dil):
@@ -201,9 +210,9 @@ def conv_fprop(x, weight, bias, y, partials, stride, pad, dil):
             None if partials is None else partials.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil)
     if x6:
         ws, nb = _splitk_ws(0, n, h, w, cin, o, kh, kw, stride, pad, dil, 0, x.device)
-        _call("sh_conv_fprop_x6", *args, ws, nb, _st(), cost=cost)
+        _call("sh_conv_fprop_x6", *args, ws, nb, _st(), cost=cost, key=_ckey(n, h, w, cin, o, kh, stride, dil))
     else:
-        _call("sh_conv_fprop", *args, _st(), cost=cost)
+        _call("sh_conv_fprop", *args, _st(), cost=cost, key=_ckey(n, h, w, cin, o, kh, stride, dil))
 
 
 SPLIT_K = os.environ.get("SEGHIERO_SPLITK", "1") != "0"      # debugging knob: 0 = never hand the conv kernels a split-K workspace
@@ -297,9 +306,9 @@ def conv_dgrad(dy, weight, dx, stride, pad, dil, addend=None, mode=0):
     args = (dyp, lddy, wptr, ap, lda, dxp, lddx, n, h, w, cin, o, kh, kw, stride, pad, dil, mode)
     if x6:
         ws, nb = _splitk_ws(1, n, h, w, cin, o, kh, kw, stride, pad, dil, mode, dx.device)
-        _call("sh_conv_dgrad_x6", *args, ws, nb, _st(), cost=cost)
+        _call("sh_conv_dgrad_x6", *args, ws, nb, _st(), cost=cost, key=_ckey(n, h, w, cin, o, kh, stride, dil))
     else:
-        _call("sh_conv_dgrad", *args, _st(), cost=cost)
+        _call("sh_conv_dgrad", *args, _st(), cost=cost, key=_ckey(n, h, w, cin, o, kh, stride, dil))
 
 
 def conv_dgrad_bnb(dy, weight, g, y_prev, coefs, relu, partials, stride, pad, dil, addend=None):
@@ -321,7 +330,8 @@ def conv_dgrad_bnb(dy, weight, g, y_prev, coefs, relu, partials, stride, pad, di
     ws, nb = _splitk_ws(1, n, h, w, cin, o, kh, kw, stride, pad, dil, 0, g.device)
     return _call_fused("sh_conv_dgrad_x6_bnb", dyp, lddy, weight_transpose(weight).data_ptr(), ap, lda, gp, ldg, ypp, ldyp,
                        coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(), coefs[3].data_ptr(), int(bool(relu)),
-                       partials.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, ws, nb, _st(), cost=cost)
+                       partials.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, ws, nb, _st(), cost=cost,
+                       key=_ckey(n, h, w, cin, o, kh, stride, dil))
 
 
 _WS = {}
@@ -410,10 +420,12 @@ def conv_wgrad(x, dy, dweight, stride, pad, dil, side=False, aff=None):
         ws = workspace(need, x.device, tag)              # one workspace per stream: its kernels stay in that stream's order
         if aff is not None:
             if not _call_fused("sh_conv_wgrad_x6_aff", xp, ldx, aff[2].data_ptr(), aff[3].data_ptr(), dyp, lddy, dweight.data_ptr(),
-                               ws.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, _st(), cost=cost):
+                               ws.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, _st(), cost=cost,
+                               key=_ckey(n, h, w, cin, o, kh, stride, dil)):
                 raise SegHieroHipError("sh_conv_wgrad_x6_aff: unsupported geometry (check wgrad_aff_ok before deferring the activation)")
             return
-        _call(name, xp, ldx, dyp, lddy, dweight.data_ptr(), ws.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, _st(), cost=cost)
+        _call(name, xp, ldx, dyp, lddy, dweight.data_ptr(), ws.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, _st(), cost=cost,
+              key=_ckey(n, h, w, cin, o, kh, stride, dil))
 
     if not (side and WGRAD_ASYNC and x.is_cuda):
         launch()
@@ -435,12 +447,13 @@ def dw_partials_rows(n, h, w):
     return LIB.raw("sh_dw_partials")(n, h, w)
 
 
-def dwconv_fprop(x, weight, y, partials, dil):
+def dwconv_fprop(x, weight, y, partials, dil, aff=None):
+    """aff = (4, C) BatchNorm coefficients: x is the producer conv's raw output, read as relu(x * scale + shift)."""
     n, c, h, w = x.shape
     xp, ldx = pm(x)
     yp, ldy = pm(y)
-    _call("sh_dwconv_fprop", xp, ldx, weight.data_ptr(), yp, ldy, None if partials is None else partials.data_ptr(),
-          n, h, w, c, dil, _st())
+    _call("sh_dwconv_fprop", xp, ldx, None if aff is None else aff[2].data_ptr(), None if aff is None else aff[3].data_ptr(),
+          weight.data_ptr(), yp, ldy, None if partials is None else partials.data_ptr(), n, h, w, c, dil, _st())
 
 
 def dwconv_dgrad(dy, weight, dx, dil, accumulate=False):
@@ -450,8 +463,19 @@ def dwconv_dgrad(dy, weight, dx, dil, accumulate=False):
     _call("sh_dwconv_dgrad", dyp, lddy, weight.data_ptr(), dxp, lddx, n, h, w, c, dil, int(accumulate), _st())
 
 
-def dwconv_wgrad(x, dy, dweight, dil, side=False):
-    """side=True: on the weight-gradient stream (see conv_wgrad); join_wgrad() before dweight is consumed."""
+def dwconv_dgrad_bnb(dy, weight, g, y_prev, coefs, partials, dil):
+    """depthwise input gradient + front half of the producer's BatchNorm backward: g <- relumask * dx, partials <- (sum g, sum g*xhat)."""
+    n, c, h, w = g.shape
+    dyp, lddy = pm(dy)
+    gp, ldg = pm(g)
+    ypp, ldyp = pm(y_prev)
+    _call("sh_dwconv_dgrad_bnb", dyp, lddy, weight.data_ptr(), gp, ldg, ypp, ldyp, coefs[0].data_ptr(), coefs[1].data_ptr(),
+          coefs[2].data_ptr(), coefs[3].data_ptr(), partials.data_ptr(), n, h, w, c, dil, _st())
+
+
+def dwconv_wgrad(x, dy, dweight, dil, side=False, aff=None):
+    """side=True: on the weight-gradient stream (see conv_wgrad); join_wgrad() before dweight is consumed.
+    aff: as dwconv_fprop."""
     n, c, h, w = x.shape
     p = dw_partials_rows(n, h, w)
     xp, ldx = pm(x)
@@ -459,7 +483,8 @@ def dwconv_wgrad(x, dy, dweight, dil, side=False):
 
     def launch(tag="dwwgrad"):
         ws = workspace(p * 9 * c * 4, x.device, tag)
-        _call("sh_dwconv_wgrad", xp, ldx, dyp, lddy, ws.data_ptr(), dweight.data_ptr(), n, h, w, c, dil, _st())
+        _call("sh_dwconv_wgrad", xp, ldx, None if aff is None else aff[2].data_ptr(), None if aff is None else aff[3].data_ptr(),
+              dyp, lddy, ws.data_ptr(), dweight.data_ptr(), n, h, w, c, dil, _st())
 
     if not (side and WGRAD_ASYNC and x.is_cuda):
         launch()
@@ -583,8 +608,9 @@ def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None):
 
 
 # ----------------------------------------------------------------------------- pooling / resampling
-def maxpool_fwd(x, want_argmax=True):
-    """-> (y, argmax): argmax uint8 [N,Ho,Wo,C] (window position of the first maximum) or None."""
+def maxpool_fwd(x, want_argmax=True, aff=None):
+    """-> (y, argmax): argmax uint8 [N,Ho,Wo,C] (window position of the first maximum) or None.
+    aff = (4, C) BatchNorm coefficients: x is the stem conv's raw output, read as relu(x * scale + shift)."""
     n, c, h, w = x.shape
     xp, ldx = pm(x)
     if ldx != c:
@@ -592,7 +618,8 @@ def maxpool_fwd(x, want_argmax=True):
     ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
     y = new_act(n, c, ho, wo, x.device)
     am = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.uint8) if want_argmax else None
-    _call("sh_maxpool_fwd", xp, y.data_ptr(), None if am is None else am.data_ptr(), n, h, w, c, _st())
+    _call("sh_maxpool_fwd", xp, None if aff is None else aff[2].data_ptr(), None if aff is None else aff[3].data_ptr(), y.data_ptr(),
+          None if am is None else am.data_ptr(), n, h, w, c, _st())
     return y, am
 
 

@@ -111,7 +111,8 @@ FUSED_CASES = [
     (2, 17, 19, 32, 48, 3, 1, 1),         # zero padding must stay zero AFTER the activation; N <= 64 tile
     (2, 16, 16, 128, 128, 3, 1, 1),
     (2, 16, 16, 560, 512, 1, 0, 1),       # K = 560: last half-tile masked
-    (2, 12, 16, 256, 64, 3, 1, 1),        # split-K fprop with the fused loader / split-K dgrad with the fused epilogue
+    (2, 12, 16, 256, 64, 3, 1, 1),        # split-K fprop with the fused loader
+    (2, 16, 16, 128, 256, 3, 1, 1),       # split-K dgrad (K = 2304, 8 tiles): BatchNorm-backward front half in the slab reduce
     (1, 160, 160, 64, 128, 1, 0, 1),      # many tiles
     (2, 16, 16, 32, 32, 3, 6, 6),         # dilated
 ]
@@ -162,10 +163,12 @@ def test_conv_fused_batchnorm_hooks(ops, case):
         dx = ar.grad if add is None else ar.grad + add
         g_ref = dx * (raw * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) > 0)
         close(gbuf, g_ref, 1e-4, 1e-4, "g = relumask * dx")
-        xhat = (raw - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
-        sums = bpart.sum(0).cpu()
-        close(sums[0], g_ref.sum((0, 2, 3)), 1e-4, 1e-3, "sum g")
-        close(sums[1], (g_ref * xhat).sum((0, 2, 3)), 1e-4, 2e-3, "sum g*xhat")
+        xhat = ((raw - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)).double()
+        sums = bpart.double().sum(0).cpu()
+        gk = gbuf.cpu().double()                              # against the kernel's own g: the summation itself must be fp32-exact
+        np.testing.assert_allclose(sums[0].numpy(), gk.sum((0, 2, 3)).numpy(), rtol=1e-5, atol=1e-5 * float(gk.abs().sum((0, 2, 3)).max()))
+        np.testing.assert_allclose(sums[1].numpy(), (gk * xhat).sum((0, 2, 3)).numpy(), rtol=1e-5,
+                                   atol=1e-5 * float((gk * xhat).abs().sum((0, 2, 3)).max()))
     gb2 = ops.new_act(n, cin, h, w, DEV)
     assert ops.conv_dgrad_bnb(dyg, wg, gb2, rawg, coefs, False, bpart, 1, p, d)
     close(gb2, ar.grad, 1e-4, 1e-4, "no ReLU: g = dx")
@@ -208,6 +211,44 @@ def test_dwconv(ops, shape, dil):
     dw = torch.empty_like(wg)
     ops.dwconv_wgrad(xg, nhwc(dy), dw, dil)
     close(dw, wt.grad, 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize("shape,dil", [((2, 64, 16, 16), 1), ((2, 64, 16, 16), 12), ((1, 72, 9, 11), 1), ((2, 128, 24, 16), 1)])
+def test_dwconv_fused_batchnorm_hooks(ops, shape, dil):
+    """Depthwise conv reading its input through the producer's BatchNorm + ReLU (fprop, wgrad) and emitting the producer's
+    BatchNorm-backward statistics + mask from its dgrad epilogue (sep_aspp_contrast_head.py:56-61, 200-203) against torch."""
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(c + dil + h)
+    raw = torch.randn(shape, generator=g)
+    scale, shift = torch.randn(c, generator=g), 0.3 * torch.randn(c, generator=g)
+    mean, invstd = 0.2 * torch.randn(c, generator=g), 0.5 + torch.rand(c, generator=g)
+    coefs = torch.stack([mean, invstd, scale, shift]).to(DEV).contiguous()
+    v = lambda t: t.view(1, -1, 1, 1)
+    act = torch.relu(raw * v(scale) + v(shift)).requires_grad_(True)
+    wt = (torch.randn(c, 1, 3, 3, generator=g) / 3).requires_grad_(True)
+    ref = F.conv2d(act, wt, None, 1, dil, dil, groups=c)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    rawg, wg, dyg = nhwc(raw), wt.detach().to(DEV).contiguous(), nhwc(dy)
+    y = ops.new_act(n, c, h, w, DEV)
+    part = torch.empty((ops.dw_partials_rows(n, h, w), 2, c), device=DEV)
+    ops.dwconv_fprop(rawg, wg, y, part, dil, aff=coefs)
+    close(y, ref, 1e-5, 1e-5, "fprop through BN+ReLU")
+    dw = torch.empty_like(wg)
+    ops.dwconv_wgrad(rawg, dyg, dw, dil, aff=coefs)
+    close(dw, wt.grad, 1e-4, 1e-4 * float(wt.grad.abs().max()), "wgrad through BN+ReLU")
+    gbuf = ops.new_act(n, c, h, w, DEV)
+    bpart = torch.empty((ops.dw_partials_rows(n, h, w), 2, c), device=DEV)
+    ops.dwconv_dgrad_bnb(dyg, wg, gbuf, rawg, coefs, bpart, dil)
+    g_ref = act.grad * (raw * v(scale) + v(shift) > 0)
+    close(gbuf, g_ref, 1e-5, 1e-5, "g = relumask * dx")
+    xhat = (raw - v(mean)) * v(invstd)
+    sums = bpart.double().sum(0).cpu()
+    gk = gbuf.cpu().double()                                  # against the kernel's own g: the summation itself must be fp32-exact
+    np.testing.assert_allclose(sums[0].numpy(), gk.sum((0, 2, 3)).numpy(), rtol=1e-5, atol=1e-5 * float(gk.abs().sum((0, 2, 3)).max()))
+    np.testing.assert_allclose(sums[1].numpy(), (gk * xhat.double()).sum((0, 2, 3)).numpy(), rtol=1e-5,
+                               atol=1e-5 * float((gk * xhat.double()).abs().sum((0, 2, 3)).max()))
+
 
 
 @pytest.mark.parametrize("shape", [(4, 64, 12, 12), (2, 9, 7, 5), (16, 32, 1, 1)])

@@ -86,10 +86,19 @@ def main():
             phase_profile(x, wt, y, part, n, h, w, cin, cout, k, s, p)
         td = timeit(lambda: ops.conv_dgrad(dy, wt, dx, s, p, 1))
         tw = timeit(lambda: ops.conv_wgrad(x, dy, dw, s, p, 1))
+        extra = ""
+        if os.environ.get("SEGHIERO_BENCH_FUSED") == "1" and cin % 4 == 0:
+            # the fused BatchNorm hooks on the same shape: input read through BN+ReLU (fprop / wgrad), BN-backward front half in dgrad
+            coefs = torch.rand(4, cin, device=DEV) + 0.5
+            bp = torch.empty((-(-n * h * w // 64), 2, cin), device=DEV)
+            tfa = timeit(lambda: ops.conv_fprop_aff(x, coefs, wt, None, y, part, s, p, 1)) if ops.conv_fprop_aff(x, coefs, wt, None, y, part, s, p, 1) else float("nan")
+            twa = timeit(lambda: ops.conv_wgrad(x, dy, dw, s, p, 1, aff=coefs)) if ops.wgrad_aff_ok(x, dw, s, p, 1) else float("nan")
+            tdb = timeit(lambda: ops.conv_dgrad_bnb(dy, wt, dx, x, coefs, True, bp, s, p, 1)) if ops.conv_dgrad_bnb(dy, wt, dx, x, coefs, True, bp, s, p, 1) else float("nan")
+            extra = f" || fused: fprop_aff {tfa*1e3:7.1f}us dgrad_bnb {tdb*1e3:7.1f}us wgrad_aff {twa*1e3:7.1f}us"
         for key, t in (("fprop", tf), ("dgrad", td), ("wgrad", tw)):
             tot[key][0] += fl; tot[key][1] += t
         print(f"{name:20s} GF={fl/1e9:7.1f}  fprop {tf*1e3:7.1f}us {fl/tf/1e9:6.1f}TF | dgrad {td*1e3:7.1f}us {fl/td/1e9:6.1f}TF | "
-              f"wgrad {tw*1e3:7.1f}us {fl/tw/1e9:6.1f}TF", flush=True)
+              f"wgrad {tw*1e3:7.1f}us {fl/tw/1e9:6.1f}TF" + extra, flush=True)
     for key, (fl, t) in tot.items():
         if t:
             print(f"TOTAL {key}: {fl/t/1e9:.1f} TF")

@@ -19,6 +19,7 @@ shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
 
 def family(name):
     for key, fam in (("conv_x6_kernel<0", "conv_fprop_x6"), ("conv_x6_kernel<1", "conv_dgrad_x6"), ("conv_wgrad_x6", "conv_wgrad_x6"),
+                     ("conv_x6p_kernel<0", "conv_fprop_x6"), ("conv_x6p_kernel<1", "conv_dgrad_x6"),
                      ("conv_gemm_kernel<0", "conv_fprop_f32"), ("conv_gemm_kernel<1", "conv_dgrad_f32"),
                      ("conv_gemm_kernel<2", "conv_wgrad_f32")):
         if key in name:
@@ -42,7 +43,12 @@ for fam, d in out.items():
     res[fam] = dict(launches_per_step=round(d["launches"], 1), hbm_read_bytes_per_step=rd, hbm_write_bytes_per_step=wr,
                     hbm_bytes_per_launch=(rd + wr) / max(d["launches"], 1e-9))
 top = dict(sorted(res.items(), key=lambda kv: -(kv[1]["hbm_read_bytes_per_step"] + kv[1]["hbm_write_bytes_per_step"]))[:25])
-json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over `python bench.py --steps 1 --warmup 1` ({tag}); FETCH_SIZE doubled "
+import hashlib
+import os
+_h = hashlib.sha1()
+for _f in sorted(glob.glob("seghiero_amd/csrc/*.hip") + glob.glob("seghiero_amd/csrc/*.h")):
+    _h.update(open(_f, "rb").read())
+json.dump({"csrc_sha": _h.hexdigest()[:12], "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over `python bench.py --steps 1 --warmup 1` ({tag}); FETCH_SIZE doubled "
                      "(gfx950 wide-read correction), KiB -> bytes", "per_kernel_family": top}, open(f"profiles/{tag}_hbm_traffic.json", "w"), indent=1)
 for fam, d in list(top.items())[:14]:
     print(f"{fam:28s} launches/step {d['launches_per_step']:6.1f}  read {d['hbm_read_bytes_per_step']/1e9:7.2f} GB  write {d['hbm_write_bytes_per_step']/1e9:7.2f} GB")
