@@ -44,6 +44,15 @@ int sh_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, int Cp
  * from interleaved RGB u8 [N,H,W,3] straight into the stem's NHWC4 fp32 layout (4th channel 0). */
 int sh_ingest_image_u8(const uint8_t* rgb, float* out, const uint8_t* flip, int N, int H, int W,
                        const float* mean3_host, const float* std3_host, void* stream);
+/* PIL's antialiasing `img.resize(size, Image.BILINEAR)` of dataset/dataloader.py:50 on interleaved RGB u8, bit-identical to Pillow
+ * (src/libImaging/Resample.c: separable triangle filter stretched by the downscale factor, horizontal pass first, 22-bit fixed-point
+ * coefficients, each pass rounded to u8).  sh_resize_bilinear_coeffs is HOST arithmetic (double, Pillow's operation order): returns
+ * ksize and fills bounds[out][2] = (first tap, tap count) and kk[out][ksize]; NULL tables = size query.  The caller uploads the
+ * tables (int32) and passes tmp = N*H*Wo*3 bytes when both axes change. */
+int sh_resize_bilinear_coeffs(int in_size, int out_size, int* bounds, int* kk, int kk_capacity);
+int sh_resize_bilinear_u8(const uint8_t* src, uint8_t* tmp, uint8_t* dst, int N, int H, int W, int Ho, int Wo,
+                          const int* bounds_x, const int* kk_x, int ksize_x, const int* bounds_y, const int* kk_y,
+                          int ksize_y, void* stream);
 /* Label maps: F.interpolate(mode="nearest") from [N,Hs,Ws] to [N,H,W] (ATen index rule), then the same flip, to u8.
  * mask: int64 (is_i64 = 1, as the reference holds them) or uint8. */
 int sh_ingest_mask(const void* mask, int is_i64, uint8_t* out, const uint8_t* flip, int N, int Hs, int Ws, int H,

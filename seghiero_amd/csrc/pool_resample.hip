@@ -327,3 +327,97 @@ extern "C" int sh_ingest_mask(const void* mask, int is_i64, uint8_t* out, const 
     else ingest_mask_kernel<unsigned char><<<(unsigned)g, 256, 0, (hipStream_t)stream>>>((const unsigned char*)mask, out, flip, N, Hs, Ws, H, W);
     return sh_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------ PIL bilinear image resize (u8)
+// `img.resize(size, Image.BILINEAR)` of dataset/dataloader.py:50.  Pillow's resampler (src/libImaging/Resample.c) is a separable
+// triangle filter whose support grows with the downscale factor (antialiasing); each pass rounds to uint8.  The coefficient
+// tables are host arithmetic in double, exactly Pillow's operation order (precompute_coeffs + normalize_coeffs_8bpc); the passes
+// are integer: acc = 2^21 + sum pixel * k (22 fractional bits), >> 22, clip to 0..255 -- bit-identical to Pillow.
+#define SH_RZ_BITS 22
+extern "C" int sh_resize_bilinear_coeffs(int in_size, int out_size, int* bounds, int* kk, int kk_capacity) {
+    if (in_size <= 0 || out_size <= 0) return SH_EINVAL;
+    double scale, filterscale;
+    filterscale = scale = (double)in_size / (double)out_size;
+    if (filterscale < 1.0) filterscale = 1.0;
+    const double support = 1.0 * filterscale;
+    const int ksize = (int)ceil(support) * 2 + 1;
+    if (!bounds || !kk) return ksize;                         // size query
+    if ((long long)ksize * out_size > kk_capacity) return SH_EINVAL;
+    const double ss = 1.0 / filterscale;
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = (xx + 0.5) * scale;
+        double ww = 0.0;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        int* k = kk + (long long)xx * ksize;
+        double w[64];
+        if (xmax > 64) return SH_EINVAL;                      // downscale factors beyond 31x are not supported
+        for (int x = 0; x < xmax; ++x) {
+            double t = (x + xmin - center + 0.5) * ss;
+            if (t < 0.0) t = -t;
+            w[x] = t < 1.0 ? 1.0 - t : 0.0;
+            ww += w[x];
+        }
+        for (int x = 0; x < ksize; ++x) {
+            if (x < xmax) {
+                const double v = ww != 0.0 ? w[x] / ww : w[x];
+                k[x] = v < 0 ? (int)(-0.5 + v * (1 << SH_RZ_BITS)) : (int)(0.5 + v * (1 << SH_RZ_BITS));
+            } else k[x] = 0;
+        }
+        bounds[2 * xx] = xmin; bounds[2 * xx + 1] = xmax;
+    }
+    return ksize;
+}
+// one pass over interleaved RGB u8: AXIS 0 = along x ([N,H,W,3] -> [N,H,Wo,3]), 1 = along y ([N,H,W,3] -> [N,Ho,W,3]); thread = output pixel
+template <int AXIS>
+__global__ __launch_bounds__(256) void resize_u8_pass_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
+                                                             const int* __restrict__ bounds, const int* __restrict__ kk, int ksize,
+                                                             int H, int W, int Ho, int Wo, long long total) {
+    GRID_STRIDE(i, total) {
+        const int ox = (int)(i % Wo);
+        const long long q = i / Wo;
+        const int oy = (int)(q % Ho);
+        const long long n = q / Ho;
+        const int o = AXIS == 0 ? ox : oy;
+        const int lo = bounds[2 * o], cnt = bounds[2 * o + 1];
+        const int* k = kk + (long long)o * ksize;
+        int a0 = 1 << (SH_RZ_BITS - 1), a1 = a0, a2 = a0;
+        for (int t = 0; t < cnt; ++t) {
+            const long long pix = AXIS == 0 ? (n * H + oy) * W + lo + t : (n * H + lo + t) * W + ox;
+            const unsigned char* sp = src + pix * 3;
+            const int kv = k[t];
+            a0 += sp[0] * kv; a1 += sp[1] * kv; a2 += sp[2] * kv;
+        }
+        unsigned char* dp = dst + i * 3;
+        dp[0] = (unsigned char)min(255, max(0, a0 >> SH_RZ_BITS));
+        dp[1] = (unsigned char)min(255, max(0, a1 >> SH_RZ_BITS));
+        dp[2] = (unsigned char)min(255, max(0, a2 >> SH_RZ_BITS));
+    }
+}
+// src [N,H,W,3] -> dst [N,Ho,Wo,3]; tmp: N*H*Wo*3 bytes (horizontal pass first, as Pillow); tables from sh_resize_bilinear_coeffs
+// uploaded by the caller (device int32): bounds_x [Wo][2], kk_x [Wo][ksize_x], bounds_y [Ho][2], kk_y [Ho][ksize_y].
+extern "C" int sh_resize_bilinear_u8(const uint8_t* src, uint8_t* tmp, uint8_t* dst, int N, int H, int W, int Ho, int Wo,
+                                     const int* bounds_x, const int* kk_x, int ksize_x, const int* bounds_y, const int* kk_y, int ksize_y,
+                                     void* stream) {
+    if (!src || !dst || N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return SH_EINVAL;
+    if ((Wo != W && (!bounds_x || !kk_x || ksize_x <= 0)) || (Ho != H && (!bounds_y || !kk_y || ksize_y <= 0))) return SH_EINVAL;
+    if (Wo != W && Ho != H && !tmp) return SH_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const uint8_t* cur = src;
+    if (Wo != W) {
+        uint8_t* out = Ho != H ? tmp : dst;
+        const long long total = (long long)N * H * Wo;
+        resize_u8_pass_kernel<0><<<grid_for(total), 256, 0, st>>>(cur, out, bounds_x, kk_x, ksize_x, H, W, H, Wo, total);
+        cur = out;
+    }
+    if (Ho != H) {
+        const long long total = (long long)N * Ho * Wo;
+        resize_u8_pass_kernel<1><<<grid_for(total), 256, 0, st>>>(cur, dst, bounds_y, kk_y, ksize_y, H, Wo, Ho, Wo, total);
+    } else if (Wo == W) {
+        (void)hipMemcpyAsync(dst, src, (size_t)N * H * W * 3, hipMemcpyDeviceToDevice, st);
+    }
+    return sh_launch_status();
+}

@@ -410,6 +410,27 @@ def test_ingest_matches_reference_transform_arithmetic(ops, resize):
     assert lab.dtype == torch.uint8 and torch.equal(lab.cpu().long(), m)
 
 
+@pytest.mark.parametrize("tag", ["down", "up", "mixed", "big", "same_w"])
+def test_pil_bilinear_resize_bit_exact(ops, tag):
+    """SURVEY 8f row 3 / dataset/dataloader.py:50: `img.resize(size, Image.BILINEAR)` on the device, bit-identical to the arrays
+    Pillow itself produced (tests/golden/g9_pil_bilinear.npz, tools/make_goldens.py g9); batch of two (second image flipped)."""
+    from conftest import load_golden
+    from seghiero_amd.ingest import JointTransformDevice, resize_bilinear_u8
+    g = load_golden("g9_pil_bilinear")
+    a, ref = torch.from_numpy(g[f"{tag}_in"]), torch.from_numpy(g[f"{tag}_out"])
+    ho, wo = ref.shape[:2]
+    got = resize_bilinear_u8(a[None].to(DEV).contiguous(), (wo, ho))
+    assert got.dtype == torch.uint8 and tuple(got.shape) == (1, ho, wo, 3)
+    assert torch.equal(got[0].cpu(), ref)
+    # the whole transform from an un-resized image: resize -> ToTensor -> Normalize, no flip
+    tf = JointTransformDevice(resize=(wo, ho), hflip_prob=0.0)
+    mask = torch.zeros(1, a.shape[0], a.shape[1], dtype=torch.long)
+    img, lab = tf(a[None].to(DEV).contiguous(), mask.to(DEV))
+    mean, std = torch.tensor(tf.normalize_mean).view(1, 3, 1, 1), torch.tensor(tf.normalize_std).view(1, 3, 1, 1)
+    want = (ref.permute(2, 0, 1)[None].float().div(255) - mean) / std
+    assert torch.equal(img[:, :3].cpu(), want) and tuple(lab.shape) == (1, ho, wo)
+
+
 def test_backbone_accepts_ingested_input(ops):
     from seghiero_amd.backbone import ResNetBackbone
     torch.manual_seed(0)

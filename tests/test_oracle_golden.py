@@ -236,3 +236,26 @@ def test_g8_pixel_accuracy(golden):
     assert c / max(v, 1) == float(g["acc"])
     c0, v0 = losses.pixel_accuracy_counts(logits, torch.full_like(label, 255))
     assert (c0, v0) == (0, 0) and float(g["acc_void"]) == 0.0
+
+
+# ---------------------------------------------------------------- G9: PIL's antialiasing bilinear image resize
+@pytest.mark.parametrize("tag", ["down", "up", "mixed", "big", "same_w"])
+def test_g9_pil_bilinear_resize_oracle_and_host_tables(golden, tag):
+    """The numpy restatement of Pillow's resampler is bit-exact against Pillow's own output, and the product's HOST coefficient
+    tables (sh_resize_bilinear_coeffs: double arithmetic in the C library, no GPU involved) equal the restatement's."""
+    import ctypes
+    from oracle import resize
+    from seghiero_amd._lib import LIB
+    g = golden("g9_pil_bilinear")
+    a, ref = g[f"{tag}_in"], g[f"{tag}_out"]
+    ho, wo = ref.shape[:2]
+    assert np.array_equal(resize.pil_bilinear_resize_u8(a, (wo, ho)), ref)
+    fn = LIB.raw("sh_resize_bilinear_coeffs")
+    for n_in, n_out in ((a.shape[1], wo), (a.shape[0], ho)):
+        bounds, kk = resize.coeffs(n_in, n_out)
+        ks = fn(n_in, n_out, None, None, 0)
+        assert ks == kk.shape[1]
+        cb, ck = (ctypes.c_int * (2 * n_out))(), (ctypes.c_int * (ks * n_out))()
+        assert fn(n_in, n_out, cb, ck, ks * n_out) == ks
+        assert np.array_equal(np.array(list(cb), np.int32).reshape(n_out, 2), bounds)
+        assert np.array_equal(np.array(list(ck), np.int32).reshape(n_out, ks), kk)

@@ -278,6 +278,25 @@ def g8():
          acc=np.float64(acc), acc_void=np.float64(acc0))
 
 
+# ------------------------------------------------------------------ G9 PIL's antialiasing bilinear image resize
+def g9():
+    """``img.resize(size, Image.BILINEAR)`` of ``dataset/dataloader.py:50`` as Pillow itself computes it (third-party arithmetic of
+    the reference; Pillow is importable in the authoring container): random RGB images, down-, up- and mixed scaling."""
+    from PIL import Image
+    import PIL
+    rng = np.random.default_rng(9)
+    out = {"pillow_version": np.array([int(v) for v in PIL.__version__.split(".")[:3]], dtype=np.int64)}
+    for tag, (h, w), (wo, ho) in (("down", (97, 131), (50, 40)), ("up", (24, 20), (75, 60)), ("mixed", (40, 90), (64, 64)),
+                                  ("big", (200, 300), (150, 150)), ("same_w", (33, 48), (48, 20))):
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        a[: h // 4, : w // 3] = 255            # saturated and flat regions too
+        a[-h // 5:, :, 1] = 0
+        ref = np.asarray(Image.fromarray(a, "RGB").resize((wo, ho), Image.BILINEAR))
+        out[f"{tag}_in"] = a
+        out[f"{tag}_out"] = ref.copy()
+    save("g9_pil_bilinear", **out)
+
+
 if __name__ == "__main__":
-    for fn in (g1, g2, g3, g4, g5, g6, g8):
+    for fn in (g1, g2, g3, g4, g5, g6, g8, g9):
         fn()
