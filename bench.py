@@ -173,6 +173,12 @@ def main():
             roof["traffic_stale"] = tjs.get("csrc_sha") != csrc_sha()
     except Exception:
         pass
+    # the north-star unit (BASELINE.json): ASPP depthwise-separable branch forward, timed on its own
+    try:
+        from seghiero_amd import units
+        roof_units = {"aspp_ds_branch": units.measure(device=dev, batch=args.batch)}
+    except Exception as e:                      # never lose the headline line to the side measurement
+        roof_units = {"aspp_ds_branch": {"error": repr(e)}}
     breakdown = {k: round(v["ms"], 2) for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])[:12]}
     out = {
         "metric": "images/sec at 512x512 (ResNet-50 2-level), full train step", "value": round(args.batch * world * args.steps / dt, 2),
@@ -184,7 +190,7 @@ def main():
                                "+ aux head, 9 fine / 4 coarse, 512x512 synthetic, fwd+loss+bwd+SGD",
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                    "parallelism": f"dp{world}" + ("" if world == 1 else (" + SyncBN" if args.syncbn else " (per-rank BatchNorm statistics)"))},
-        "loss": round(loss_val, 5), "roofline": roof, "kernel_ms_per_step": breakdown,
+        "loss": round(loss_val, 5), "roofline": roof, "roofline_units": roof_units, "kernel_ms_per_step": breakdown,
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

@@ -107,6 +107,15 @@ int sh_conv_fprop_x6_act(const float* x, int ldx, const float* w, const float* s
 int sh_conv_fprop_x6_aff(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* w,
                          const float* bias, float* y, int ldy, float* stat_partials, int N, int H, int W, int Cin, int Cout,
                          int KH, int KW, int stride, int pad, int dil, float* workspace, int64_t workspace_bytes, void* stream);
+/* ngroups (<= 6) pointwise convolutions of ONE geometry in one launch -- the ASPP branches of
+ * models/head/sep_aspp_contrast_head.py:100-131 (the 1x1 branch + the pointwise convs of the three depthwise-separable branches):
+ * group g: y[:, g*Cout:(g+1)*Cout] = conv1x1(in_g, w[g]), in_g = relu(x[g]*in_scale[g] + in_shift[g]) (the producer's BatchNorm +
+ * ReLU in the loader) or plain x[g] when in_scale[g] is NULL.  x / ldx / in_scale / in_shift / w: HOST arrays of ngroups device
+ * pointers / strides.  y = first group's column, ldy >= ngroups*Cout; stat_partials [ceil(N*H*W/64)][2][ngroups*Cout].
+ * Cout % 128 == 0 and Cin % 16 == 0, else SH_EUNSUPPORTED. */
+int sh_conv1x1_grouped_fprop_x6(int ngroups, const float* const* x, const int* ldx, const float* const* in_scale,
+                                const float* const* in_shift, const float* const* w, float* y, int ldy,
+                                float* stat_partials, int N, int H, int W, int Cin, int Cout, void* stream);
 int sh_weight_transpose(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream);
 /* ... for n <= SH_WT_MAX weights in one launch (taps = KH*KW); the training step prepares all dgrad operands at once. */
 #define SH_WT_MAX 40
@@ -165,7 +174,30 @@ int sh_dwconv_wgrad(const float* x, int ldx, const float* in_scale, const float*
 int sh_bn_finalize(const float* partials, int n_partials, int C, double count, const float* gamma,
                    const float* beta, float eps, float momentum, float* running_mean,
                    float* running_var, float* mean, float* invstd, float* scale, float* shift,
-                   int rows_per_partial, void* stream);
+                   int rows_per_partial, int partials_ld, void* stream);
+/* (partials_ld: row length of the partials when this layer's C columns are a slice of a wider set -- the grouped ASPP launch;
+ * 0 = C.)
+ * BatchNorm of y = chan_mul[c*chan_stride] * x from the statistics partials of x: depthwise conv + BN of an ASPP branch whose
+ * dilation exceeds the feature map (sep_aspp_contrast_head.py:125-131 at stride 32: only the centre tap touches the image) without
+ * forming y.  Coefficients come out in the x domain -- mean = mean_x, invstd = w*invstd_y, scale = w*gamma*invstd_y, shift as for y
+ * -- so loaders / BatchNorm-backward kernels work on x itself and gamma*invstd*(...) is already d/dx; isy[C] <- invstd_y. */
+int sh_bn_finalize_scaled(const float* partials, int n_partials, int C, double count, const float* chan_mul,
+                          int chan_stride, const float* gamma, const float* beta, float eps, float momentum,
+                          float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                          float* shift, float* isy, int rows_per_partial, void* stream);
+/* k (<= 8) BatchNorm layers of C channels finalized in one launch (the grouped ASPP unit): layer i reads columns
+ * [partials_col[i], +C) of `partials` (rows of partials_ld floats, 0 = C), optionally through a channel multiplier chan_mul[i]
+ * (see sh_bn_finalize_scaled; chan_mul / isy may be NULL arrays or hold NULL entries).  All pointer arguments are HOST arrays of k
+ * device pointers; eps / momentum are shared. */
+int sh_bn_finalize_multi(int k, const float* partials, int n_partials, int C, double count, int rows_per_partial,
+                         int partials_ld, const int* partials_col, const float* const* gamma, const float* const* beta,
+                         float* const* running_mean, float* const* running_var, float* const* mean, float* const* invstd,
+                         float* const* scale, float* const* shift, const float* const* chan_mul, int chan_stride,
+                         float* const* isy, float eps, float momentum, void* stream);
+/* Weight gradient [C][9] of such a centre-tap depthwise conv in closed form from the BatchNorm-backward sums:
+ * dL/dw_centre = gamma * dgamma * eps * invstd_y^2 / w, off-centre taps exactly 0. */
+int sh_dw_center_wgrad(const float* dgamma, const float* gamma, const float* isy, const float* w, float eps, float* dw,
+                       int C, void* stream);
 /* SyncBN building blocks (cross-GPU BatchNorm is new functionality): reduce the partials to f64 per-channel
  * sums on each rank -- sq is double[2*C + 1] = {sum x [C], sum x^2 [C], local pixel count} (forward, from the centred
  * partials) or {sum g [C], sum g*xhat [C], count} (backward, rows_per_partial = 0) -- all-reduce the vector over RCCL on

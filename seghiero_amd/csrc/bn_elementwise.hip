@@ -90,15 +90,16 @@ extern "C" int sh_axpy(float* y, const float* x, float a, int64_t n, void* strea
 // Writes sums[0][c], sums[1][c] (double) into LDS-resident result then calls the functor on thread < 4.
 // CENTRED != 0: partial = (sum, M2 about its own mean) over n_p = min(R, M - p*R) rows -> returns (sum, sum of squares about 0)
 template <typename F>
-__device__ __forceinline__ void reduce_partials_4ch(const float* __restrict__ partials, int P, int C, int c0, int R, long long M, F&& fin) {
+__device__ __forceinline__ void reduce_partials_4ch(const float* __restrict__ partials, int P, int C, int c0, int R, long long M, F&& fin, long long ldp = 0) {
+    if (ldp == 0) ldp = C;                 // row length of the partials (> C: this tensor is a column slice of a wider set)
     __shared__ double red[8][4];   // [stat*4+ch][wave]
     const int t = threadIdx.x;
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool vec = (C & 3) == 0;
+    const bool vec = (C & 3) == 0 && (ldp & 3) == 0 && ((uintptr_t)partials & 15) == 0;
 #pragma unroll 4                    // the loads of successive partials are independent: keep several in flight (latency-bound kernel)
     for (int p = t; p < P; p += 256) {
-        const float* r0 = partials + ((long long)p * 2 + 0) * C + c0;
-        const float* r1 = partials + ((long long)p * 2 + 1) * C + c0;
+        const float* r0 = partials + ((long long)p * 2 + 0) * ldp + c0;
+        const float* r1 = partials + ((long long)p * 2 + 1) * ldp + c0;
         double inv_n = 0.0;
         if (R > 0) { const long long left = M - (long long)p * R; inv_n = 1.0 / (double)(left < R ? left : R); }
         if (vec) {
@@ -125,38 +126,150 @@ __device__ __forceinline__ void reduce_partials_4ch(const float* __restrict__ pa
     }
 }
 
+// wmul != nullptr (per-channel multiplier wmul[c * wstride]): the statistics are those of x but the BatchNorm normalises y = w * x
+// (a depthwise conv whose off-centre taps never touch the image, SURVEY A.1: dilation >= H, W) -- mean_y = w mean_x, var_y = w^2 var_x.
+// The coefficients are then emitted in the x domain so that every consumer can work on x itself:
+//   mean = mean_x, invstd = w * invstd_y  (=> xhat_y = (x - mean) * invstd, and gamma * invstd * (...) is already d/dx),
+//   scale = w * gamma * invstd_y, shift = beta - mean_y * gamma * invstd_y  (=> y_bn = x * scale + shift);  isy[c] = invstd_y.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int P, int C, double count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, float momentum, float* running_mean,
                                                           float* running_var, float* mean, float* invstd, float* scale,
-                                                          float* shift, int R) {
+                                                          float* shift, int R, long long ldp, const float* __restrict__ wmul, int wstride,
+                                                          float* __restrict__ isy) {
     reduce_partials_4ch(partials, P, C, blockIdx.x * 4, R, (long long)count, [&](int c, double s, double q) {
         const double mu = s / count;
         double var = q / count - mu * mu;
         if (var < 0) var = 0;
-        const float fmu = (float)mu, fvar = (float)var;
-        const float is = 1.0f / sqrtf(fvar + eps);
+        const float w = wmul ? wmul[(long long)c * wstride] : 1.f;
+        const float fmu = (float)mu;
+        const float fmu_y = wmul ? w * fmu : fmu;
+        const double var_y = wmul ? (double)w * (double)w * var : var;
+        const float is = 1.0f / sqrtf((float)var_y + eps);
         mean[c] = fmu;
-        invstd[c] = is;
+        invstd[c] = wmul ? w * is : is;
         const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
         const float sc = g * is;
-        scale[c] = sc;
-        shift[c] = b - fmu * sc;
+        scale[c] = wmul ? w * sc : sc;
+        shift[c] = b - fmu_y * sc;
+        if (isy) isy[c] = is;
         if (running_mean) {
-            const double unbiased = count > 1 ? var * (count / (count - 1.0)) : var;
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * fmu;
+            const double unbiased = count > 1 ? var_y * (count / (count - 1.0)) : var_y;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * fmu_y;
             running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
         }
-    });
+    }, ldp);
 }
 extern "C" int sh_bn_finalize(const float* partials, int n_partials, int C, double count, const float* gamma,
                               const float* beta, float eps, float momentum, float* running_mean, float* running_var,
-                              float* mean, float* invstd, float* scale, float* shift, int rows_per_partial, void* stream) {
+                              float* mean, float* invstd, float* scale, float* shift, int rows_per_partial, int partials_ld, void* stream) {
     if (!partials || n_partials <= 0 || C <= 0 || count <= 0 || !mean || !invstd || !scale || !shift || rows_per_partial <= 0) return SH_EINVAL;
+    if ((long long)n_partials != sh_cdiv((long long)count, rows_per_partial)) return SH_EINVAL;
+    if ((running_mean == nullptr) != (running_var == nullptr) || (partials_ld != 0 && partials_ld < C)) return SH_EINVAL;
+    bn_finalize_kernel<<<(unsigned)sh_cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(
+        partials, n_partials, C, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, rows_per_partial,
+        partials_ld, nullptr, 0, nullptr);
+    return sh_launch_status();
+}
+// Several BatchNorm layers of C channels each finalized in ONE launch (the grouped ASPP unit: its four pointwise BatchNorms share one
+// partials tensor, layer k's columns start at partials_col[k]; its centre-tap depthwise BatchNorms share the statistics of c4 with
+// a per-layer channel multiplier).  blockIdx.y = layer.
+#define SH_BN_MULTI 8
+struct BnMultiTab {
+    const float* gamma[SH_BN_MULTI]; const float* beta[SH_BN_MULTI];
+    float* rm[SH_BN_MULTI]; float* rv[SH_BN_MULTI];
+    float* mean[SH_BN_MULTI]; float* invstd[SH_BN_MULTI]; float* scale[SH_BN_MULTI]; float* shift[SH_BN_MULTI];
+    const float* wmul[SH_BN_MULTI]; float* isy[SH_BN_MULTI];
+    int col[SH_BN_MULTI];
+};
+__global__ __launch_bounds__(256) void bn_finalize_multi_kernel(const float* __restrict__ partials, int P, int C, double count, float eps,
+                                                                float momentum, int R, long long ldp, int wstride, const BnMultiTab T) {
+    const int k = blockIdx.y;
+    const float* gamma = T.gamma[k]; const float* beta = T.beta[k]; const float* wmul = T.wmul[k];
+    float* running_mean = T.rm[k]; float* running_var = T.rv[k];
+    float* mean = T.mean[k]; float* invstd = T.invstd[k]; float* scale = T.scale[k]; float* shift = T.shift[k]; float* isy = T.isy[k];
+    reduce_partials_4ch(partials + T.col[k], P, C, blockIdx.x * 4, R, (long long)count, [&](int c, double s, double q) {
+        const double mu = s / count;
+        double var = q / count - mu * mu;
+        if (var < 0) var = 0;
+        const float w = wmul ? wmul[(long long)c * wstride] : 1.f;
+        const float fmu = (float)mu;
+        const float fmu_y = wmul ? w * fmu : fmu;
+        const double var_y = wmul ? (double)w * (double)w * var : var;
+        const float is = 1.0f / sqrtf((float)var_y + eps);
+        mean[c] = fmu;
+        invstd[c] = wmul ? w * is : is;
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        const float sc = g * is;
+        scale[c] = wmul ? w * sc : sc;
+        shift[c] = b - fmu_y * sc;
+        if (isy) isy[c] = is;
+        if (running_mean) {
+            const double unbiased = count > 1 ? var_y * (count / (count - 1.0)) : var_y;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * fmu_y;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }, ldp);
+}
+extern "C" int sh_bn_finalize_multi(int k, const float* partials, int n_partials, int C, double count, int rows_per_partial, int partials_ld,
+                                    const int* partials_col, const float* const* gamma, const float* const* beta, float* const* running_mean,
+                                    float* const* running_var, float* const* mean, float* const* invstd, float* const* scale,
+                                    float* const* shift, const float* const* chan_mul, int chan_stride, float* const* isy, float eps,
+                                    float momentum, void* stream) {
+    if (k < 1 || k > SH_BN_MULTI || !partials || n_partials <= 0 || C <= 0 || count <= 0 || rows_per_partial <= 0 || !partials_col || !gamma ||
+        !beta || !running_mean || !running_var || !mean || !invstd || !scale || !shift) return SH_EINVAL;
+    if ((long long)n_partials != sh_cdiv((long long)count, rows_per_partial) || (partials_ld != 0 && partials_ld < C)) return SH_EINVAL;
+    BnMultiTab T;
+    for (int i = 0; i < k; ++i) {
+        if (!mean[i] || !invstd[i] || !scale[i] || !shift[i] || partials_col[i] < 0 || (running_mean[i] == nullptr) != (running_var[i] == nullptr))
+            return SH_EINVAL;
+        T.gamma[i] = gamma[i]; T.beta[i] = beta[i]; T.rm[i] = running_mean[i]; T.rv[i] = running_var[i];
+        T.mean[i] = mean[i]; T.invstd[i] = invstd[i]; T.scale[i] = scale[i]; T.shift[i] = shift[i];
+        T.wmul[i] = chan_mul ? chan_mul[i] : nullptr; T.isy[i] = isy ? isy[i] : nullptr; T.col[i] = partials_col[i];
+        if (T.wmul[i] && chan_stride <= 0) return SH_EINVAL;
+    }
+    dim3 grid((unsigned)sh_cdiv(C, 4), (unsigned)k);
+    bn_finalize_multi_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(partials, n_partials, C, count, eps, momentum, rows_per_partial, partials_ld,
+                                                                   chan_stride, T);
+    return sh_launch_status();
+}
+// BatchNorm of y = w[c] * x from the statistics partials of x (see bn_finalize_kernel): the depthwise + BN of an ASPP branch whose
+// dilation exceeds the feature map (sep_aspp_contrast_head.py:125-131 at stride 32) without ever forming y.  chan_mul: the depthwise
+// weight's centre taps = weight + 4 with chan_stride 9.  isy[C] <- 1/sqrt(var_y + eps) (for sh_dw_center_wgrad).
+extern "C" int sh_bn_finalize_scaled(const float* partials, int n_partials, int C, double count, const float* chan_mul, int chan_stride,
+                                     const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                     float* running_var, float* mean, float* invstd, float* scale, float* shift, float* isy,
+                                     int rows_per_partial, void* stream) {
+    if (!partials || n_partials <= 0 || C <= 0 || count <= 0 || !chan_mul || chan_stride <= 0 || !mean || !invstd || !scale || !shift || !isy ||
+        rows_per_partial <= 0) return SH_EINVAL;
     if ((long long)n_partials != sh_cdiv((long long)count, rows_per_partial)) return SH_EINVAL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return SH_EINVAL;
     bn_finalize_kernel<<<(unsigned)sh_cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(
-        partials, n_partials, C, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, rows_per_partial);
+        partials, n_partials, C, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, rows_per_partial,
+        0, chan_mul, chan_stride, isy);
+    return sh_launch_status();
+}
+// Weight gradient of such a centre-tap depthwise conv, in closed form from the BatchNorm-backward sums: with y = w x the loss
+// depends on w only through eps -- dL/dw_centre = gamma * dgamma * eps * invstd_y^2 / w (derivation in DESIGN.md) -- and the eight
+// off-centre taps never touch the image: exact zeros.  dw: [C][9].
+__global__ __launch_bounds__(256) void dw_center_wgrad_kernel(const float* __restrict__ dgamma, const float* __restrict__ gamma,
+                                                              const float* __restrict__ isy, const float* __restrict__ w, float eps,
+                                                              float* __restrict__ dw, int C) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 9 * C) return;
+    const int c = i / 9, tap = i - 9 * c;
+    float v = 0.f;
+    if (tap == 4) {
+        const float wc = w[(long long)c * 9 + 4];
+        const float g = gamma ? gamma[c] : 1.f;
+        v = wc != 0.f ? g * dgamma[c] * eps * isy[c] * isy[c] / wc : 0.f;
+    }
+    dw[i] = v;
+}
+extern "C" int sh_dw_center_wgrad(const float* dgamma, const float* gamma, const float* isy, const float* w, float eps, float* dw, int C,
+                                  void* stream) {
+    if (!dgamma || !isy || !w || !dw || C <= 0) return SH_EINVAL;
+    dw_center_wgrad_kernel<<<(unsigned)sh_cdiv(9 * C, 256), 256, 0, (hipStream_t)stream>>>(dgamma, gamma, isy, w, eps, dw, C);
     return sh_launch_status();
 }
 
@@ -251,12 +364,61 @@ __global__ __launch_bounds__(256) void channel_partials_kernel(const float* __re
             partials[((long long)blockIdx.x * 2 + st) * C + ch] = (red[st][0][cc] + red[st][1][cc]) + (red[st][2][cc] + red[st][3][cc]);
     }
 }
+// float4 form of the plain statistics: block = 256 rows x 64 channels, thread = (channel quad, row lane) holding its 16 rows in
+// registers: one pass over y, block sum -> block mean through LDS, then M2 about that mean (centred partial, as the conv epilogues)
+__global__ __launch_bounds__(256) void channel_stats_v4_kernel(const float* __restrict__ y, long long ldy, float* __restrict__ partials,
+                                                               long long M, int C) {
+    __shared__ float red[16][64];
+    __shared__ float colmean[64];
+    const int t = threadIdx.x, cq = t & 15, rl = t >> 4;
+    const unsigned nch = (unsigned)((C + 63) / 64), rb = blockIdx.x / nch, cb = blockIdx.x % nch;
+    const int c = cb * 64 + cq * 4;
+    const long long rbeg = (long long)rb * STAT_ROWS;
+    const long long left = M - rbeg;
+    const float nvalid = (float)(left < STAT_ROWS ? left : STAT_ROWS);
+    f32x4 v[STAT_ROWS / 16];
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < STAT_ROWS / 16; ++k) {
+        const long long r = rbeg + rl + 16 * k;
+        v[k] = (c < C && r < M) ? ld4(y + r * ldy + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += v[k];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[rl][cq * 4 + j] = s[j];
+    __syncthreads();
+    float colsum = 0.f;
+    if (t < 64) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) colsum += red[k][t];
+        colmean[t] = colsum / nvalid;
+    }
+    __syncthreads();
+    const f32x4 mu = ld4(&colmean[cq * 4]);
+    f32x4 q = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < STAT_ROWS / 16; ++k)
+        if (rbeg + rl + 16 * k < M) { const f32x4 d = v[k] - mu; q += d * d; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[rl][cq * 4 + j] = q[j];
+    __syncthreads();
+    if (t < 64 && cb * 64 + t < C) {
+        float m2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) m2 += red[k][t];
+        partials[((long long)rb * 2 + 0) * C + cb * 64 + t] = colsum;
+        partials[((long long)rb * 2 + 1) * C + cb * 64 + t] = m2;
+    }
+}
 extern "C" int sh_stats_partials_count(int64_t M) { return (int)sh_cdiv(M, STAT_ROWS); }
 extern "C" int sh_stats_tile_rows(void) { return STAT_ROWS; }
 extern "C" int sh_channel_stats(const float* y, int ldy, int64_t M, int C, float* partials, void* stream) {
     if (!y || !partials || M <= 0 || C <= 0 || ldy < C) return SH_EINVAL;
     dim3 grid((unsigned)sh_cdiv(M, STAT_ROWS), (unsigned)sh_cdiv(C, 64));
-    channel_partials_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(y, ldy, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, partials, M, C, 0);
+    if ((C & 3) == 0 && (ldy & 3) == 0 && ((uintptr_t)y & 15) == 0)
+        channel_stats_v4_kernel<<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(y, ldy, partials, M, C);
+    else
+        channel_partials_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(y, ldy, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, partials, M, C, 0);
     return sh_launch_status();
 }
 // float4 variant of the BN-backward partials: block = 256 rows x 64 channels, thread = (channel quad, row lane),

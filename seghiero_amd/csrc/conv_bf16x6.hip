@@ -1066,6 +1066,33 @@ extern "C" int sh_conv_fprop_x6_act(const float* x, int ldx, const float* w, con
     p.M = N * p.Ho * p.Wo; p.Nn = Cout; p.K = KH * KW * Cin; p.Kc = Cin;
     return launch_conv_x6_act(p, (hipStream_t)stream);
 }
+// ngroups (<= 6) pointwise convolutions of ONE geometry in one launch: group g computes y[:, g*Cout : (g+1)*Cout] = conv1x1(in_g, w[g])
+// where in_g = relu(x[g] * in_scale[g] + in_shift[g]) (the producer's train-mode BatchNorm + ReLU in the loader) or plain x[g] when
+// in_scale[g] is NULL.  The ASPP branches of models/head/sep_aspp_contrast_head.py:100-131 (1x1 branch + the three depthwise-
+// separable branches' pointwise convs) are four 4096 x 512 x 2048 GEMMs that each fill half the chip; grouped they are one 512-tile
+// launch that needs no K slices.  y: first group's column (ldy >= ngroups*Cout); stat_partials: [ceil(M/64)][2][ngroups*Cout].
+extern "C" int sh_conv1x1_grouped_fprop_x6(int ngroups, const float* const* x, const int* ldx, const float* const* in_scale,
+                                           const float* const* in_shift, const float* const* w, float* y, int ldy, float* stat_partials,
+                                           int N, int H, int W, int Cin, int Cout, void* stream) {
+    ConvQ p{};
+    if (ngroups < 1 || ngroups > 6 || !x || !ldx || !in_scale || !in_shift || !w || !y || !geom(p, N, H, W, Cin, Cout, 1, 1, 1, 0, 1)) return SH_EINVAL;
+    if ((Cout & 127) || (Cin & 15) || ldy < ngroups * Cout) return SH_EUNSUPPORTED;
+    const long long M = (long long)N * H * W;
+    for (int g = 0; g < ngroups; ++g) {
+        if (!x[g] || !w[g] || ldx[g] < Cin || (ldx[g] & 3) || ((in_scale[g] == nullptr) != (in_shift[g] == nullptr))) return SH_EINVAL;
+        if ((((uintptr_t)in_scale[g] | (uintptr_t)in_shift[g]) & 15)) return SH_EINVAL;
+        const long long ab = ((M - 1) * ldx[g] + Cin) * 4;
+        if (ab >= (1ll << 31)) return SH_EUNSUPPORTED;
+        p.ga[g] = x[g]; p.ga_bytes[g] = (unsigned)ab; p.glda[g] = ldx[g]; p.gb[g] = w[g]; p.gsc[g] = in_scale[g]; p.gsh[g] = in_shift[g];
+    }
+    p.ngroups = ngroups; p.group_n = Cout;
+    p.c = y; p.ldc = ldy; p.partials = stat_partials;
+    p.M = (int)M; p.Nn = ngroups * Cout; p.K = Cin; p.Kc = Cin;
+    p.b_bytes = (unsigned)((long long)Cout * Cin * 4);
+    p.n_partials = (int)sh_cdiv(p.M, 64);
+    const int rc = sh_x6p_grouped_launch(p, (hipStream_t)stream);
+    return rc == SH_X6P_NO ? SH_EUNSUPPORTED : rc;
+}
 // wt = sh_weight_transpose(w): fp32 [KH*KW][Cin][pad4(Cout)]
 extern "C" int sh_conv_dgrad_x6(const float* dy, int lddy, const float* wt, const float* addend, int ldadd, float* dx, int lddx,
                                 int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, int mode,

@@ -38,6 +38,13 @@ struct ConvQ {
     const float* bnb_scale;
     const float* bnb_shift;
     int bnb_relu;
+    // ---- grouped 1x1 fprop (conv_x6p.hip, GRP): ngroups convolutions of the same geometry whose outputs are consecutive column slices of
+    // one buffer; group g = output column / group_n reads its own input (through its own BatchNorm + ReLU, or plain: gfloor = -inf,
+    // scale 1, shift 0) and its own weights
+    int ngroups, group_n;
+    const float* ga[6]; unsigned ga_bytes[6]; long long glda[6];
+    const float* gb[6];
+    const float* gsc[6]; const float* gsh[6];
     int vec_epi;            // output / addend / bnb_y rows are 16-byte addressable: row-major float4 epilogue through LDS
     unsigned a_bytes, b_bytes;  // extents of the A / B operands for the buffer descriptors (bytes, < 2^31)
 };
@@ -90,6 +97,7 @@ __device__ __forceinline__ f32x16 mma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3
 // conv_x6p.hip: software-pipelined fprop / dgrad with the fused BatchNorm hooks; SH_X6P_NO = shape not handled (fall back)
 #define SH_X6P_NO (-100)
 int sh_x6p_launch(int mode, ConvQ& p, hipStream_t st);
+int sh_x6p_grouped_launch(ConvQ& p, hipStream_t st);
 int sh_x6p_wgrad_launch(ConvQ& p, int wgm, int wgn, int splits, hipStream_t st);
 // conv_bf16x6.hip: sum of the split-K slabs + bias / addend / BN statistics / BN-backward front half (p.slab, p.ksplit set)
 int sh_x6_splitk_reduce(const ConvQ& p, int mode, hipStream_t st);

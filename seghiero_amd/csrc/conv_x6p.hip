@@ -33,7 +33,7 @@ __device__ __forceinline__ int swz_row(int row) { return ((row >> 2) & 3) ^ (row
 
 // TAP: 0 = 1x1 (one tap), 1 = KxK with Kc % 16 == 0 (a half-tile never straddles taps: scalar tap math, switched by a block-uniform
 // branch at the start of a phase), 2 = general (per-lane tap; stem 7x7 with 4 channels)
-template <int MODE, int TM, int TN, int WGM, int WGN, int WPS, int AFF, int EPI, int SK, int TAP>
+template <int MODE, int TM, int TN, int WGM, int WGN, int WPS, int AFF, int EPI, int SK, int TAP, int GRP = 0>
 __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const ConvQ p) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
@@ -52,6 +52,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
     const unsigned bid = xcd_remap(blockIdx.x, nblk);
     const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    // GRP: the block's N tile lies inside one group (group_n is a multiple of BN): that group's input, weights and coefficients
+    const int grp = GRP ? n0 / p.group_n : 0;
+    const float* const a_ptr = GRP ? p.ga[grp] : p.a;
+    const float* const b_ptr = GRP ? p.gb[grp] : p.b;
+    const unsigned a_bytes = GRP ? p.ga_bytes[grp] : p.a_bytes;
+    const int lda = (int)(GRP ? p.glda[grp] : p.lda);
+    const float* const sc_ptr = GRP ? p.gsc[grp] : p.aff_scale;
+    const float* const sh_ptr = GRP ? p.gsh[grp] : p.aff_shift;
+    const float aff_floor = (GRP && sc_ptr == nullptr) ? -INFINITY : 0.f;      // plain input: max(x * 1 + 0, -inf) = x exactly
     int cy = 0, cx = 0, Hc = p.H, Wc = p.W, oy0 = 0, ox0 = 0, ntw = p.KW, Mc = p.M, Kt = p.K;
     if constexpr (MODE == DGRAD) {
         if (p.parity) {                                              // stride-2 KxK dgrad by input-parity class (see conv_x6_kernel)
@@ -76,8 +85,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
     // Operands are fetched with raw buffer loads: 32-bit byte offsets against a wave-uniform descriptor, and an offset beyond
     // num_records (padded taps, rows >= M, the K tail) returns zeros in hardware -- no branch and no select around any load, so
     // a whole phase stays one basic block.  (The host side routes tensors of 2 GiB or more to conv_x6_kernel.)
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, p.b_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_ptr), 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b_ptr), 0, p.b_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     const int kc = t & 3, r0 = t >> 2;
     int a_y[NA], a_x[NA], a_nb[NA];
@@ -102,7 +111,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
     for (int i = 0; i < NB; ++i) {
         const int j = n0 + r0 + RPP * i;
         b_ok[i] = j < p.Nn ? ~0u : 0u;
-        b_row[i] = j * (MODE == FPROP ? p.K : p.Kc);
+        b_row[i] = (GRP ? j - grp * p.group_n : j) * (MODE == FPROP ? p.K : p.Kc);
     }
     int a_off[NA];                                               // element offset of the A row for the current tap
     unsigned a_ok[NA];
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
             if constexpr (MODE == FPROP) {
                 const int ih = a_y[i] + dh, iw = a_x[i] + dw;
                 a_ok[i] = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? ~0u : 0u;
-                a_off[i] = (a_nb[i] + ih * p.W + iw) * (int)p.lda;
+                a_off[i] = (a_nb[i] + ih * p.W + iw) * lda;
             } else {
                 int th = a_y[i] - dh, tw = a_x[i] - dw;
                 bool ok = th >= 0 && tw >= 0;
@@ -125,7 +134,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
                     th /= p.stride; tw /= p.stride;
                 }
                 a_ok[i] = (ok && th < p.Ho && tw < p.Wo) ? ~0u : 0u;
-                a_off[i] = (a_nb[i] + th * p.Wo + tw) * (int)p.lda;
+                a_off[i] = (a_nb[i] + th * p.Wo + tw) * lda;
             }
         }
     };
@@ -180,7 +189,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
                 // separate BatchNorm + ReLU pass would have written; padded taps / rows beyond M stay exact zeros
                 const bool ok = (R.okm >> i) & 1u;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float w = fmaxf(v[e] * sc[e] + sh[e], 0.f); v[e] = ok ? w : 0.f; }
+                for (int e = 0; e < 4; ++e) { const float w = fmaxf(v[e] * sc[e] + sh[e], aff_floor); v[e] = ok ? w : 0.f; }
             }
             u32x2 q1, q2, q3;
             split4(v, q1, q2, q3);
@@ -247,7 +256,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
     };
     // ------------------------------------------------------------------ prologue
     if constexpr (AFF) {
-        for (int c = t; c < p.Kc; c += NT) { coef[c] = p.aff_scale[c]; coef[p.Kc + c] = p.aff_shift[c]; }
+        for (int c = t; c < p.Kc; c += NT) { coef[c] = sc_ptr ? sc_ptr[c] : 1.f; coef[p.Kc + c] = sh_ptr ? sh_ptr[c] : 0.f; }
         __syncthreads();
     }
     Regs R0, R1;
@@ -491,21 +500,21 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
 }
 
 // ---------------------------------------------------------------------------------------- host side
-template <int MODE, int TM, int TN, int WGM, int WGN, int WPS, int AFF, int EPI, int SK, int TAP>
+template <int MODE, int TM, int TN, int WGM, int WGN, int WPS, int AFF, int EPI, int SK, int TAP, int GRP = 0>
 static int launch_x6p(ConvQ& p, hipStream_t st) {
     constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
     const size_t lds = 3 * (size_t)(BM + BN) * ROWB + (AFF ? 8 * (size_t)p.Kc : 0);
     if (lds > 160 * 1024) return SH_X6P_NO;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6p_kernel<MODE, TM, TN, WGM, WGN, WPS, AFF, EPI, SK, TAP>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6p_kernel<MODE, TM, TN, WGM, WGN, WPS, AFF, EPI, SK, TAP, GRP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         attr_lds = 160 * 1024;
     }
     p.tiles_m = (int)sh_cdiv(p.M, BM);
     p.tiles_n = (int)sh_cdiv(p.Nn, BN);
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), p.parity ? 4u : (SK ? (unsigned)p.ksplit : 1u));
-    conv_x6p_kernel<MODE, TM, TN, WGM, WGN, WPS, AFF, EPI, SK, TAP><<<grid, 64 * WGM * WGN, lds, st>>>(p);
+    conv_x6p_kernel<MODE, TM, TN, WGM, WGN, WPS, AFF, EPI, SK, TAP, GRP><<<grid, 64 * WGM * WGN, lds, st>>>(p);
     return sh_launch_status();
 }
 
@@ -537,6 +546,16 @@ static int pick_x6p(ConvQ& p, hipStream_t st, int force) {
 
 static int x6p_mode() { static int v = -2; if (v == -2) { const char* e = getenv("SEGHIERO_X6P"); v = e ? atoi(e) : 1; } return v; }
 static int x6p_tile() { static int v = -2; if (v == -2) { const char* e = getenv("SEGHIERO_X6P_TILE"); v = e ? atoi(e) : 0; } return v; }
+
+// ngroups 1x1 convolutions of one geometry in ONE launch (p.ngroups, p.group_n, p.ga / gb / gsc / gsh set by the caller): the ASPP
+// branches of sep_aspp_contrast_head.py:100-131 -- grid = tiles_m x (ngroups * group_n / 128), so four under-filled 128-tile GEMMs
+// become one 512-tile launch without K slices, each reading its own input through its own BatchNorm + ReLU
+int sh_x6p_grouped_launch(ConvQ& p, hipStream_t st) {
+    if (p.ngroups < 1 || p.ngroups > 6 || (p.group_n & 127) || p.KH * p.KW != 1) return SH_X6P_NO;
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    p.vec_epi = (p.ldc & 3) == 0 && al16(p.c);
+    return launch_x6p<FPROP, 2, 2, 2, 2, 3, 1, 1, 0, 0, 1>(p, st);
+}
 
 // Entry used by sh_conv_fprop_x6 / sh_conv_dgrad_x6: SH_X6P_NO = shape not handled here (the caller falls back to conv_x6_kernel)
 int sh_x6p_launch(int mode, ConvQ& p, hipStream_t st) {

@@ -74,6 +74,64 @@ class DepthwiseSeparableASPPModule(nn.Module):
                                                                     dilation=d, padding=d, bias=False))
 
 
+ASPP_GROUPED = __import__("os").environ.get("SEGHIERO_ASPP_GROUPED", "1") != "0"
+
+
+def _aspp_branches_grouped(aspp, c4, cat, A, training, R):
+    """The 1x1 branch and the depthwise-separable branches of the ASPP (``sep_aspp_contrast_head.py:100-131``) as ONE unit:
+
+    * a branch whose dilation is >= the feature map (24 / 36 at 16 x 16) is ``w_centre * c4`` -- no depthwise kernel
+      runs: its BatchNorm coefficients come from the per-channel statistics of c4 (computed once for all such branches) and are
+      folded into the pointwise conv's loader (``ops.bn_finalize_scaled``);
+    * the other depthwise convs run as before, their BatchNorm + ReLU deferred to the loader too;
+    * all pointwise convs (+ the 1x1 branch) are one grouped launch (``ops.conv1x1_grouped_fprop``): a 512-tile GEMM instead of
+      four under-filled ones with K slices and slab reduces; one BatchNorm + ReLU pass writes the four slices of the concat.
+
+    Fills R["b0"], R["pw<i>"] and R["dw<i>"] / R["dwc<i>"]; False = geometry not eligible (the caller runs the branches one by one)."""
+    n, cin, h, w = c4.shape
+    nbr = len(aspp.dilations)
+    if not (ASPP_GROUPED and training and L.FUSE_BN and ops.CONV_IMPL == "x6" and not ops._sync_on() and A % 128 == 0 and cin % 16 == 0
+            and nbr <= 6):
+        return False
+    dev = c4.device
+    m = n * h * w
+    sources, weights, bns = [(c4, None)], [aspp.branches[0][0].weight], [aspp.branches[0][1]]
+    centre = [i for i, d in enumerate(aspp.dilations[1:], start=1) if d >= h and d >= w]      # only the centre tap touches the image
+    if centre:                                           # y = w_centre * c4: statistics of c4 once, all such BatchNorms in one launch
+        x_stats = ops.channel_stats(c4)
+        cfs = [torch.empty((4, cin), device=dev, dtype=torch.float32) for _ in centre]
+        isys = [torch.empty((cin,), device=dev, dtype=torch.float32) for _ in centre]
+        ops.bn_finalize_multi(x_stats, m, ops.LIB.raw("sh_stats_tile_rows")(), [aspp.branches[i][0].bn_dw for i in centre], cfs,
+                              dw_weights=[aspp.branches[i][0].depthwise.weight for i in centre], isy_list=isys)
+        for i, cf, isy in zip(centre, cfs, isys):
+            R[f"dwc{i}"] = (cf, isy)
+    for i, d in enumerate(aspp.dilations[1:], start=1):
+        ds = aspp.branches[i][0]
+        if i in centre:
+            sources.append((c4, R[f"dwc{i}"][0]))
+        else:
+            t, R[f"dw{i}"] = L.dw_fwd(c4, ds.depthwise.weight, d, ds.bn_dw, training, lazy=True)
+            sources.append((t.y, t.coefs))
+        weights.append(ds.pointwise.weight)
+        bns.append(ds.bn_pw)
+    ycat = ops.new_act(n, nbr * A, h, w, dev)
+    partials = ops.conv_partials(m, nbr * A, dev)
+    if not ops.conv1x1_grouped_fprop(sources, weights, ycat, partials):
+        raise SegHieroHipError("grouped ASPP launch rejected an eligible geometry")
+    coefs_cat = torch.empty((4, nbr * A), device=dev, dtype=torch.float32)
+    ops.bn_finalize_multi(partials, m, 64, bns, [coefs_cat[:, g * A:(g + 1) * A] for g in range(nbr)], partials_ld=nbr * A,
+                          cols=[g * A for g in range(nbr)])
+    ops.bn_act(ycat, coefs_cat, cat[:, A:(nbr + 1) * A], True)
+    for g in range(nbr):
+        rec = L.CBARec()
+        src, cf = sources[g]
+        rec.x = src if cf is None else L.Lazy(src, cf)
+        rec.y, rec.out, rec.coefs = ycat[:, g * A:(g + 1) * A], None, coefs_cat[:, g * A:(g + 1) * A]
+        rec.relu, rec.geom, rec.weight, rec.has_res = True, G1, weights[g], False
+        R["b0" if g == 0 else f"pw{g}"] = rec
+    return True
+
+
 class _HeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mod, c1, c4, *params):
@@ -105,11 +163,12 @@ class _HeadFn(torch.autograd.Function):
         pooled = ops.avgpool_fwd(c4)
         ip, R["ip"] = L.cba_fwd(pooled, aspp.image_pool_conv[0].weight, G1, aspp.image_pool_conv[1], True, training)
         ops.broadcast_hw(ip, cat[:, 0:A])
-        _, R["b0"] = L.cba_fwd(c4, aspp.branches[0][0].weight, G1, aspp.branches[0][1], True, training, out=cat[:, A:2 * A])
-        for i, d in enumerate(aspp.dilations[1:], start=1):
-            ds = aspp.branches[i][0]
-            t, R[f"dw{i}"] = L.dw_fwd(c4, ds.depthwise.weight, d, ds.bn_dw, training, lazy=True)
-            _, R[f"pw{i}"] = L.cba_fwd(t, ds.pointwise.weight, G1, ds.bn_pw, True, training, out=cat[:, (i + 1) * A:(i + 2) * A])
+        if not _aspp_branches_grouped(aspp, c4, cat, A, training, R):
+            _, R["b0"] = L.cba_fwd(c4, aspp.branches[0][0].weight, G1, aspp.branches[0][1], True, training, out=cat[:, A:2 * A])
+            for i, d in enumerate(aspp.dilations[1:], start=1):
+                ds = aspp.branches[i][0]
+                t, R[f"dw{i}"] = L.dw_fwd(c4, ds.depthwise.weight, d, ds.bn_dw, training, lazy=True)
+                _, R[f"pw{i}"] = L.cba_fwd(t, ds.pointwise.weight, G1, ds.bn_pw, True, training, out=cat[:, (i + 1) * A:(i + 2) * A])
         b, R["bt"] = L.cba_fwd(cat, mod.bottleneck[0].weight, G1, mod.bottleneck[1], True, training)
         # ---- decoder: x8 bilinear + C1 skip into one buffer (:231-242)
         if mod.c1_bottleneck is not None:
@@ -185,7 +244,16 @@ class _HeadFn(torch.autograd.Function):
                 ds = aspp.branches[i][0]
                 res = L.cba_bwd(R[f"pw{i}"], ds.bn_pw, dcat[:, (i + 1) * A:(i + 2) * A])
                 put_cba(ds.pointwise.weight, ds.bn_pw, res)
-                _, dww, dg, db = L.dw_bwd(R[f"dw{i}"], ds.bn_dw, res[0], dx_accumulate_into=dc4)
+                if f"dwc{i}" in R:
+                    # centre-tap branch (y = w_centre * c4 never existed): the BatchNorm backward on c4 with the x-domain
+                    # coefficients yields d/dc4 directly; the depthwise weight gradient is closed-form (sh_dw_center_wgrad)
+                    coefs_x, isy = R[f"dwc{i}"]
+                    dxc, dg, db, _ = ops.bn_backward(res[0], None, R[f"pw{i}"].x.y, coefs_x, ds.bn_dw.weight, 2)
+                    ops._call("sh_axpy", dc4.data_ptr(), dxc.data_ptr(), 1.0, dc4.numel(), ops._st())
+                    dww = L.new_grad(ds.depthwise.weight)
+                    ops.dw_center_wgrad(dg, ds.bn_dw.weight, isy, ds.depthwise.weight, ds.bn_dw.eps, dww)
+                else:
+                    _, dww, dg, db = L.dw_bwd(R[f"dw{i}"], ds.bn_dw, res[0], dx_accumulate_into=dc4)
                 gm.put(ds.depthwise.weight, dww); gm.put(ds.bn_dw.weight, dg); gm.put(ds.bn_dw.bias, db)
             dip = ops.sum_hw(dcat[:, 0:A])
             res = L.cba_bwd(R["ip"], aspp.image_pool_conv[1], dip)

@@ -515,9 +515,16 @@ def _all_reduce_sq(sq):
     return sq
 
 
-def bn_finalize(partials, count, gamma, beta, eps, momentum, running_mean, running_var, c, device, rows=64):
-    coefs = torch.empty((4, c), device=device, dtype=torch.float32)      # mean, invstd, scale, shift
+def bn_finalize(partials, count, gamma, beta, eps, momentum, running_mean, running_var, c, device, rows=64, coefs=None,
+                partials_ld=0, partials_col=0):
+    """coefs (optional): (4, c) tensor / strided view to fill.  partials_ld / partials_col: this layer's columns are
+    [col, col + c) of a wider partials tensor with rows of partials_ld floats (the grouped ASPP launch)."""
+    if coefs is None:
+        coefs = torch.empty((4, c), device=device, dtype=torch.float32)      # mean, invstd, scale, shift
+    pptr = partials.data_ptr() + 4 * partials_col
     if _sync_on():
+        if partials_ld:
+            raise SegHieroHipError("SyncBN does not take column slices of grouped partials")
         # sq = [sum x (C), sum x^2 (C), local count]: the count travels with the sums, so ranks may hold different numbers of
         # pixels (uneven last batch, different crops) -- torch.nn.SyncBatchNorm all-gathers the counts for the same reason
         sq = torch.empty((2 * c + 1,), device=device, dtype=torch.float64)
@@ -529,12 +536,74 @@ def bn_finalize(partials, count, gamma, beta, eps, momentum, running_mean, runni
               None if running_var is None else running_var.data_ptr(),
               coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(), coefs[3].data_ptr(), _st())
         return coefs
-    _call("sh_bn_finalize", partials.data_ptr(), partials.shape[0], c, float(count),
+    _call("sh_bn_finalize", pptr, partials.shape[0], c, float(count),
           None if gamma is None else gamma.data_ptr(), None if beta is None else beta.data_ptr(), eps, momentum,
           None if running_mean is None else running_mean.data_ptr(),
           None if running_var is None else running_var.data_ptr(),
-          coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(), coefs[3].data_ptr(), rows, _st())
+          coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(), coefs[3].data_ptr(), rows, int(partials_ld), _st())
     return coefs
+
+
+def bn_finalize_scaled(partials, count, dw_weight, gamma, beta, eps, momentum, running_mean, running_var, c, device, rows):
+    """BatchNorm of y = w_centre[c] * x from the statistics partials of x (centre-tap depthwise conv, see sh_bn_finalize_scaled).
+    -> (coefs (4, c) in the x domain, isy (c,))."""
+    coefs = torch.empty((4, c), device=device, dtype=torch.float32)
+    isy = torch.empty((c,), device=device, dtype=torch.float32)
+    _call("sh_bn_finalize_scaled", partials.data_ptr(), partials.shape[0], c, float(count), dw_weight.data_ptr() + 16, 9,
+          gamma.data_ptr(), beta.data_ptr(), eps, momentum, None if running_mean is None else running_mean.data_ptr(),
+          None if running_var is None else running_var.data_ptr(), coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(),
+          coefs[3].data_ptr(), isy.data_ptr(), rows, _st())
+    return coefs, isy
+
+
+def bn_finalize_multi(partials, count, rows, bns, coefs_list, partials_ld=0, cols=None, dw_weights=None, isy_list=None):
+    """k BatchNorm layers (same channel count, eps, momentum) finalized in one launch.  bns: the nn.BatchNorm2d modules; coefs_list:
+    (4, C) tensors / views to fill; cols: first partials column of each layer; dw_weights: per layer a depthwise weight [C,1,3,3]
+    whose centre tap multiplies the statistics (or None); isy_list: (C,) outputs for those."""
+    k = len(bns)
+    c = coefs_list[0].shape[1]
+    eps, mom = bns[0].eps, 0.1 if bns[0].momentum is None else bns[0].momentum
+    if any(b.eps != eps or (0.1 if b.momentum is None else b.momentum) != mom for b in bns) or k > 8:
+        raise SegHieroHipError("bn_finalize_multi needs <= 8 layers with one eps / momentum")
+    vp = ctypes.c_void_p
+    arr = lambda vals: (vp * k)(*vals)
+    ptr = lambda t: None if t is None else t.data_ptr()
+    cols = [0] * k if cols is None else cols
+    dw_weights = [None] * k if dw_weights is None else dw_weights
+    isy_list = [None] * k if isy_list is None else isy_list
+    _call("sh_bn_finalize_multi", k, partials.data_ptr(), partials.shape[0], c, float(count), rows, int(partials_ld),
+          (ctypes.c_int * k)(*cols), arr([b.weight.data_ptr() for b in bns]), arr([b.bias.data_ptr() for b in bns]),
+          arr([ptr(b.running_mean) for b in bns]), arr([ptr(b.running_var) for b in bns]),
+          arr([cf[0].data_ptr() for cf in coefs_list]), arr([cf[1].data_ptr() for cf in coefs_list]),
+          arr([cf[2].data_ptr() for cf in coefs_list]), arr([cf[3].data_ptr() for cf in coefs_list]),
+          arr([None if w is None else w.data_ptr() + 16 for w in dw_weights]), 9, arr([ptr(t) for t in isy_list]),
+          float(eps), float(mom), _st())
+
+
+def dw_center_wgrad(dgamma, gamma, isy, dw_weight, eps, dweight):
+    _call("sh_dw_center_wgrad", dgamma.data_ptr(), gamma.data_ptr(), isy.data_ptr(), dw_weight.data_ptr(), float(eps),
+          dweight.data_ptr(), dw_weight.shape[0], _st())
+
+
+def conv1x1_grouped_fprop(sources, weights, y, partials):
+    """One launch for several pointwise convs of one geometry (the ASPP branches): sources = [(x, coefs or None)], group g writes
+    y[:, g*A:(g+1)*A].  -> False when the geometry has no grouped kernel."""
+    if CONV_IMPL != "x6":
+        return False
+    k = len(sources)
+    n, cin, h, w = sources[0][0].shape
+    a = weights[0].shape[0]
+    xs, lds = zip(*[pm(x) for x, _ in sources])
+    yp, ldy = pm(y)
+    vp = ctypes.c_void_p
+    arr = lambda vals: (vp * k)(*vals)
+    cost = (2.0 * n * h * w * cin * a * k, 4.0 * (n * h * w * (cin + a) * k + a * cin * k))
+    return _call_fused("sh_conv1x1_grouped_fprop_x6", k, arr(xs), (ctypes.c_int * k)(*lds),
+                       arr([None if c is None else c[2].data_ptr() for _, c in sources]),
+                       arr([None if c is None else c[3].data_ptr() for _, c in sources]),
+                       arr([w_ohwi(wt).data_ptr() for wt in weights]), yp, ldy, partials.data_ptr(), n, h, w, cin, a, _st(),
+                       cost=cost, key=f"{k} x ({n}x{h}x{w} {cin}->{a} k1)")
+
 
 
 def bn_eval_coefs(gamma, beta, running_mean, running_var, eps):
