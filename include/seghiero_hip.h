@@ -270,17 +270,22 @@ int sh_hiera2_loss_fwd(const float* logits, int ldl, const uint8_t* labels, cons
                        int n_coarse, double* sums, float* loss_out, float* partials, uint8_t* coarse_out,
                        int N, int h, int w, int H, int W, void* stream);
 /* d(loss_out)/d(logits) * gscale * gscale_dev[0] into dlogits [N,h,w,lddl] (gather form, deterministic; lanes
- * >= C of each row are zeroed).  Uses the counts left in `sums` by the forward. */
+ * >= C of each row are zeroed).  Uses the counts left in `sums` by the forward.  workspace (optional, sh_loss_bwd_workspace
+ * bytes, 16-byte aligned; needs lddl % 4 == 0): two streaming passes -- every full-resolution pixel's gradient once into the
+ * workspace, then the adjoint of the bilinear resize as a gather -- instead of the LDS-tiled single kernel that recomputes
+ * halo pixels (same arithmetic and summation order: bit-identical results, 4-5x faster at the x4 resize of train.py:282-284). */
+int64_t sh_loss_bwd_workspace(int N, int H, int W, int lddl);
 int sh_hiera2_loss_bwd(const float* logits, int ldl, const uint8_t* labels, const int* buckets_host, int n_fine,
                        int n_coarse, const double* sums, const float* gscale_dev, float gscale, float* dlogits,
-                       int lddl, int N, int h, int w, int H, int W, void* stream);
+                       int lddl, int N, int h, int w, int H, int W, float* workspace, int64_t workspace_bytes, void* stream);
 /* Fused bilinear resize + nn.CrossEntropyLoss(ignore_index=255) (valid-pixel mean) of the aux head
  * (train.py:309-313).  sums double[2] = {ce_sum, n_valid}; loss_out = ce_sum / n_valid. */
 int sh_ce_loss_fwd(const float* logits, int ldl, const uint8_t* labels, int C, double* sums, float* loss_out,
                    float* partials, int N, int h, int w, int H, int W, void* stream);
 int sh_ce_loss_bwd(const float* logits, int ldl, const uint8_t* labels, int C, const double* sums,
                    const float* gscale_dev, float gscale, float* dlogits, int lddl, int N, int h, int w, int H,
-                   int W, void* stream);
+                   int W, float* workspace, int64_t workspace_bytes,
+                   void* stream);
 /* int64 label map -> uint8 (the reference hands the loss i64 labels, train.py:262). */
 int sh_labels_to_u8(const int64_t* in, uint8_t* out, int64_t n, void* stream);
 /* Tree-triplet (tree_triplet_loss.py:15-65, rmi_tree_triplet_loss.py:14-70): nearest label resize to the

@@ -311,6 +311,103 @@ __global__ __launch_bounds__(256) void loss_bwd_tile_kernel(const float* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------ two-pass backward through a workspace
+// The fused tile kernel above recomputes a 39 x 39 full-resolution region per 32 x 32 owned pixels (x4 resize: +48 %), holds 79 KB
+// of LDS per block (2 blocks per CU) and took 1.02 ms at the headline shape -- 10x the time its 16.8 MB output and 17.6 MB input
+// justify.  With a workspace the same arithmetic runs as two streaming kernels:
+//   A  every full-resolution pixel's gradient w.r.t. its (interpolated) logits, once, to workspace [N*H*W][lddl]   (coalesced 64 B / pixel)
+//   B  the adjoint of the bilinear resize: each low-resolution (pixel, channel quad) gathers its <= 8 x 8 contributions in the
+//      tile kernel's own (row, column) order with the forward's exact weights => bit-identical to the tile kernel.
+// 268 MB written + re-read (mostly from L2) instead of recomputation: the full-resolution LOGITS still never exist.
+template <int MAXC, int MODE>
+__global__ __launch_bounds__(256) void loss_grad_fullres_kernel(const float* __restrict__ logits, long long ldl, const uint8_t* __restrict__ labels,
+                                                                const H2Tab T, int C, const double* __restrict__ sums,
+                                                                const float* __restrict__ gscale_dev, float gscale, float* __restrict__ gfull,
+                                                                int L, int h, int w, int H, int W, float sy, float sx, long long total) {
+    const bool identity = (h == H && w == W);
+    const float gs = gscale * (gscale_dev ? gscale_dev[0] : 1.f);
+    float af = 0.f, ac = 0.f, b;
+    if (MODE == 0) {
+        const double nvf = sums[4] < 1.0 ? 1.0 : sums[4], nvc = sums[5] < 1.0 ? 1.0 : sums[5];
+        af = gs * (float)(5.0 / (nvf * T.nf));
+        ac = T.nc > 0 ? gs * (float)(5.0 / (nvc * T.nc)) : 0.f;
+        b = gs * (float)(1.0 / sums[6]);
+    } else {
+        b = gs * (float)(1.0 / sums[1]);
+    }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        float g[MAXC];
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j) g[j] = 0.f;
+        const int f = labels[i];
+        if (f != IGN) {
+            const int ox = (int)(i % W);
+            const long long q = i / W;
+            const int oy = (int)(q % H);
+            const long long n = q / H;
+            const Lerp ly = lerp_src(oy, sy, h), lx = lerp_src(ox, sx, w);
+            float z[MAXC];
+            fetch_logits<MAXC>(logits + n * h * w * ldl, ldl, w, ly, lx, identity, C, z);
+            if (MODE == 0) {
+                float o[4];
+                hiera2_pixel<MAXC, true>(z, f, coarse_of(f, T), T, af, ac, b, o, g);
+            } else {
+                softmax_ce<MAXC, true>(z, 0, C, f, b, g);
+            }
+        }
+        float* dst = gfull + i * L;
+#pragma unroll
+        for (int j = 0; j < MAXC; j += 4)
+            if (j < L) st4(dst + j, f32x4{g[j], g[j + 1], g[j + 2], g[j + 3]});
+    }
+}
+// adjoint of the resize: thread = (low-res pixel, channel quad)
+__global__ __launch_bounds__(256) void resize_adjoint_gather_kernel(const float* __restrict__ gfull, float* __restrict__ dlogits, int L, int h, int w,
+                                                                    int H, int W, float sy, float sx, long long total) {
+    const int LQ = L / 4;
+    for (long long item = (long long)blockIdx.x * 256 + threadIdx.x; item < total; item += (long long)gridDim.x * 256) {
+        const int cq = (int)(item % LQ);
+        long long pq = item / LQ;
+        const int ix = (int)(pq % w); pq /= w;
+        const int iy = (int)(pq % h);
+        const long long n = pq / h;
+        int cylo, cyhi, cxlo, cxhi;
+        contrib_range(iy, 1.f / sy, H, cylo, cyhi);
+        contrib_range(ix, 1.f / sx, W, cxlo, cxhi);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int oy = cylo; oy <= cyhi; ++oy) {
+            const Lerp ly = lerp_src(oy, sy, h);
+            const float wy = (ly.i0 == iy ? ly.w0 : 0.f) + (ly.i1 == iy ? ly.w1 : 0.f);
+            if (wy == 0.f) continue;
+            const float* row = gfull + ((n * H + oy) * W) * L + 4 * cq;
+            for (int ox = cxlo; ox <= cxhi; ++ox) {
+                const Lerp lx = lerp_src(ox, sx, w);
+                const float wx = (lx.i0 == ix ? lx.w0 : 0.f) + (lx.i1 == ix ? lx.w1 : 0.f);
+                if (wx != 0.f) acc += (wy * wx) * ld4(row + (long long)ox * L);
+            }
+        }
+        st4(dlogits + ((n * h + iy) * w + ix) * L + 4 * cq, acc);
+    }
+}
+template <int MAXC, int MODE>
+static int launch_loss_bwd_two_pass(const float* logits, int ldl, const uint8_t* labels, const H2Tab& T, int C, const double* sums,
+                                    const float* gscale_dev, float gscale, float* dlogits, int lddl, int N, int h, int w, int H, int W,
+                                    float* workspace, hipStream_t st) {
+    const long long full = (long long)N * H * W, low = (long long)N * h * w * (lddl / 4);
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    long long ga = sh_cdiv(full, 256), gb = sh_cdiv(low, 256);
+    if (ga > 16384) ga = 16384;
+    if (gb > 16384) gb = 16384;
+    loss_grad_fullres_kernel<MAXC, MODE><<<(unsigned)ga, 256, 0, st>>>(logits, ldl, labels, T, C, sums, gscale_dev, gscale, workspace, lddl, h, w,
+                                                                        H, W, sy, sx, full);
+    resize_adjoint_gather_kernel<<<(unsigned)gb, 256, 0, st>>>(workspace, dlogits, lddl, h, w, H, W, sy, sx, low);
+    return sh_launch_status();
+}
+extern "C" int64_t sh_loss_bwd_workspace(int N, int H, int W, int lddl) {
+    if (N <= 0 || H <= 0 || W <= 0 || lddl <= 0) return SH_EINVAL;
+    return (int64_t)N * H * W * lddl * 4;
+}
+
 // host: pick TL (low-res tile side) so the LDS gradient tile stays <= budget; returns 0 if even TL = 1 does not fit
 static int pick_tile(int h, int w, int H, int W, int C, int budget_bytes, int& region_elems) {
     const float sy = (float)H / (float)h, sx = (float)W / (float)w;
@@ -378,7 +475,7 @@ extern "C" int sh_hiera2_loss_fwd(const float* logits, int ldl, const uint8_t* l
 
 extern "C" int sh_hiera2_loss_bwd(const float* logits, int ldl, const uint8_t* labels, const int* buckets_host, int n_fine,
                                   int n_coarse, const double* sums, const float* gscale_dev, float gscale, float* dlogits,
-                                  int lddl, int N, int h, int w, int H, int W, void* stream) {
+                                  int lddl, int N, int h, int w, int H, int W, float* workspace, int64_t workspace_bytes, void* stream) {
     H2Tab T;
     if (!logits || !labels || !sums || !dlogits || N <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SH_EINVAL;
     if (!make_tab(T, buckets_host, n_fine, n_coarse) || ldl < n_fine + n_coarse || lddl < n_fine + n_coarse || lddl > 32) return SH_EINVAL;
@@ -386,6 +483,13 @@ extern "C" int sh_hiera2_loss_bwd(const float* logits, int ldl, const uint8_t* l
     const unsigned nblk = (unsigned)sh_cdiv(total, 256);
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
     hipStream_t st = (hipStream_t)stream;
+    if (workspace && workspace_bytes >= sh_loss_bwd_workspace(N, H, W, lddl) && (h < H || w < W) && h <= H && w <= W && (lddl & 3) == 0 &&
+        (((uintptr_t)workspace | (uintptr_t)dlogits) & 15) == 0) {
+        const int Cr = n_fine + n_coarse;
+        if (Cr <= 8 && lddl <= 8) return launch_loss_bwd_two_pass<8, 0>(logits, ldl, labels, T, Cr, sums, gscale_dev, gscale, dlogits, lddl, N, h, w, H, W, workspace, st);
+        if (Cr <= 16 && lddl <= 16) return launch_loss_bwd_two_pass<16, 0>(logits, ldl, labels, T, Cr, sums, gscale_dev, gscale, dlogits, lddl, N, h, w, H, W, workspace, st);
+        return launch_loss_bwd_two_pass<32, 0>(logits, ldl, labels, T, Cr, sums, gscale_dev, gscale, dlogits, lddl, N, h, w, H, W, workspace, st);
+    }
     {
         const int Cr = n_fine + n_coarse;
         int region = 0;
@@ -506,12 +610,20 @@ extern "C" int sh_ce_loss_fwd(const float* logits, int ldl, const uint8_t* label
     return sh_launch_status();
 }
 extern "C" int sh_ce_loss_bwd(const float* logits, int ldl, const uint8_t* labels, int C, const double* sums, const float* gscale_dev,
-                              float gscale, float* dlogits, int lddl, int N, int h, int w, int H, int W, void* stream) {
+                              float gscale, float* dlogits, int lddl, int N, int h, int w, int H, int W, float* workspace,
+                              int64_t workspace_bytes, void* stream) {
     if (!logits || !labels || !sums || !dlogits || C <= 0 || C > 32 || ldl < C || lddl < C || lddl > 32 || N <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SH_EINVAL;
     const long long total = (long long)N * h * w;
     const unsigned nblk = (unsigned)sh_cdiv(total, 4);
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
     hipStream_t st = (hipStream_t)stream;
+    if (workspace && workspace_bytes >= sh_loss_bwd_workspace(N, H, W, lddl) && (h < H || w < W) && h <= H && w <= W && (lddl & 3) == 0 &&
+        (((uintptr_t)workspace | (uintptr_t)dlogits) & 15) == 0) {
+        H2Tab T{};
+        if (lddl <= 8) return launch_loss_bwd_two_pass<8, 1>(logits, ldl, labels, T, C, sums, gscale_dev, gscale, dlogits, lddl, N, h, w, H, W, workspace, st);
+        if (lddl <= 16) return launch_loss_bwd_two_pass<16, 1>(logits, ldl, labels, T, C, sums, gscale_dev, gscale, dlogits, lddl, N, h, w, H, W, workspace, st);
+        return launch_loss_bwd_two_pass<32, 1>(logits, ldl, labels, T, C, sums, gscale_dev, gscale, dlogits, lddl, N, h, w, H, W, workspace, st);
+    }
     {
         H2Tab T{};
         int region = 0;

@@ -822,15 +822,27 @@ def hiera2_fwd(logits, labels8, n_fine, hiera_index, want_coarse=False):
     return loss, sums, coarse
 
 
+LOSS_BWD_TWO_PASS = os.environ.get("SEGHIERO_LOSS_TWO_PASS", "1") != "0"
+
+
+def _loss_bwd_ws(n, h, w, H, W, ldd, device):
+    """Workspace of the two-pass loss backward (full-resolution gradient, [N*H*W][ldd] fp32) when the logits are upsampled."""
+    if not LOSS_BWD_TWO_PASS or (h >= H and w >= W) or ldd % 4:
+        return None, 0
+    need = LIB.raw("sh_loss_bwd_workspace")(n, H, W, ldd)
+    return workspace(need, device, "lossbwd").data_ptr(), need
+
+
 def hiera2_bwd(logits, labels8, n_fine, hiera_index, sums, gscale_dev, gscale):
     n, c, h, w = logits.shape
     _, H, W = labels8.shape
     lp, ldl = pm(logits)
     d = new_act(n, c, h, w, logits.device, ld=pad4(c))
     dp, ldd = pm(d)
+    ws, nb = _loss_bwd_ws(n, h, w, H, W, ldd, logits.device)
     _call("sh_hiera2_loss_bwd", lp, ldl, labels8.data_ptr(), _buckets(hiera_index), n_fine, len(hiera_index),
           sums.data_ptr(), None if gscale_dev is None else gscale_dev.data_ptr(), float(gscale), dp, ldd,
-          n, h, w, H, W, _st())
+          n, h, w, H, W, ws, nb, _st())
     return d
 
 
@@ -854,8 +866,9 @@ def ce_bwd(logits, labels8, sums, gscale_dev, gscale):
     lp, ldl = pm(logits)
     d = new_act(n, c, h, w, logits.device, ld=pad4(c))
     dp, ldd = pm(d)
+    ws, nb = _loss_bwd_ws(n, h, w, H, W, ldd, logits.device)
     _call("sh_ce_loss_bwd", lp, ldl, labels8.data_ptr(), c, sums.data_ptr(),
-          None if gscale_dev is None else gscale_dev.data_ptr(), float(gscale), dp, ldd, n, h, w, H, W, _st())
+          None if gscale_dev is None else gscale_dev.data_ptr(), float(gscale), dp, ldd, n, h, w, H, W, ws, nb, _st())
     return d
 
 
