@@ -130,10 +130,13 @@ int sh_conv_dgrad_x6(const float* dy, int lddy, const float* wt, const float* ad
  * rows into stat_partials[ceil(N*H*W/64)][2][Cin], i.e. what sh_bn_bwd_reduce would compute from dx and y_prev in a separate
  * pass (torch.nn.BatchNorm2d backward of resnet.py:65-73 / sep_aspp_contrast_head.py:56-61); finish with sh_bn_bwd_finalize and
  * sh_bn_bwd_apply(relu = 0) on g.  y_prev: raw output of the producer conv [N*H*W][ldyp]; mean / invstd / scale / shift: its
- * BatchNorm coefficients [Cin]; relu: 0 / 1.  Stride-1 geometries only; SH_EUNSUPPORTED otherwise. */
+ * BatchNorm coefficients [Cin]; relu: 0 / 1.  out_prev (optional): the ReLU mask is out_prev > 0 instead -- residual blocks, where
+ * out = relu(bn3(y) + identity) (models/backbone/resnet.py via torchvision Bottleneck): then g is also the identity path's
+ * gradient.  Stride-1 geometries only; SH_EUNSUPPORTED otherwise. */
 int sh_conv_dgrad_x6_bnb(const float* dy, int lddy, const float* wt, const float* addend, int ldadd, float* g, int ldg,
-                         const float* y_prev, int ldyp, const float* mean, const float* invstd, const float* scale,
-                         const float* shift, int relu, float* stat_partials, int N, int H, int W, int Cin, int Cout,
+                         const float* y_prev, int ldyp, const float* out_prev, int ldop, const float* mean,
+                         const float* invstd, const float* scale, const float* shift, int relu, float* stat_partials,
+                         int N, int H, int W, int Cin, int Cout,
                          int KH, int KW, int stride, int pad, int dil, float* workspace, int64_t workspace_bytes, void* stream);
 int64_t sh_conv_wgrad_x6_workspace(int N, int H, int W, int Cin, int Cout, int KH, int KW,
                                    int stride, int pad, int dil);
@@ -216,9 +219,13 @@ int sh_bn_eval_coefs(const float* gamma, const float* beta, const float* running
 int sh_stats_partials_count(int64_t M);
 int sh_stats_tile_rows(void);                   /* rows per stat-partial of sh_channel_stats (=256) */
 int sh_channel_stats(const float* y, int ldy, int64_t M, int C, float* partials, void* stream);
-/* out = [relu]( y*scale + shift [+ residual] ).  Replaces BN-apply + ReLU (+ the Bottleneck residual add). */
+/* out = [relu]( y*scale + shift [+ residual] ).  Replaces BN-apply + ReLU (+ the Bottleneck residual add).
+ * res_scale / res_shift (optional, both or neither): `residual` is the RAW output of the block's downsample conv and its
+ * BatchNorm is applied on the fly, residual*res_scale + res_shift (same operation order as applying it first: bit-identical),
+ * so the downsample branch of torchvision's Bottleneck / BasicBlock never materialises its normalised output. */
 int sh_bn_act(const float* y, int ldy, const float* scale, const float* shift, const float* residual,
-              int ldr, float* out, int ldo, int64_t M, int C, int relu, void* stream);
+              int ldr, const float* res_scale, const float* res_shift, float* out, int ldo, int64_t M, int C, int relu,
+              void* stream);
 /* Backward of the above.  g = dout * mask.  relu = 0: no mask; 1: mask = out > 0 (needed when a residual was added);
  * 2: mask = y*scale+shift > 0, the forward's own arithmetic recomputed from y (no residual) -- `out` is not read, which
  * saves one activation-sized HBM read in each of the two passes.  reduce: partials [n][2][C] of (sum g, sum g*xhat);

@@ -63,6 +63,12 @@ def _stage(kind, cin, width, n, stride):
     return nn.Sequential(*blocks), cout
 
 
+# Residual-block form of the fused BatchNorm backward (the next block's first dgrad epilogue masks with this block's output and
+# emits its bn3 statistics).  Measured at the headline shape: the short-K 1x1 dgrads of layer1 / layer2 are epilogue-bound, three
+# extra tile reads there cost more (+1.6 ms of dgrad) than the statistics pass they replace (-0.7 ms) -- off by default.
+BNB_RESIDUAL = __import__("os").environ.get("SEGHIERO_BNB_RESIDUAL", "0") != "0"
+
+
 # ----------------------------------------------------------------------------- hand-scheduled fwd / bwd
 def _block_fwd(blk, x, training):
     chain = blk.chain()
@@ -70,7 +76,8 @@ def _block_fwd(blk, x, training):
     idt, ds_rec = x, None
     if blk.downsample is not None:
         dconv, dbn = blk.downsample[0], blk.downsample[1]
-        idt, ds_rec = L.cba_fwd(x, dconv.weight, L.conv_geom(dconv), dbn, False, training)
+        # the downsample BatchNorm is applied inside the block's final BatchNorm + add + ReLU pass (LazyAffine)
+        idt, ds_rec = L.cba_fwd(x, dconv.weight, L.conv_geom(dconv), dbn, False, training, lazy=True)
     h = x
     for i, (conv, bn) in enumerate(chain):
         last = i == len(chain) - 1
@@ -80,7 +87,11 @@ def _block_fwd(blk, x, training):
     return h, (recs, ds_rec)
 
 
-def _block_bwd(blk, saved, dout, gm):
+def _block_bwd(blk, saved, dout, gm, prev_rec=None):
+    """dout: gradient w.r.t. the block output (tensor, or a GradPack made by the NEXT block's first conv).  prev_rec: last CBARec of
+    the previous block when this block's input is that block's output and no downsample path adds into the input gradient -- the
+    first conv's dgrad epilogue then runs the front half of that block's bn3 backward (mask from its `out`) and the identity
+    gradient needs no separate tensor."""
     recs, ds_rec = saved
     chain = blk.chain()
     # last conv: g = dout * relu-mask feeds BN backward AND (as dres) the identity / downsample path
@@ -91,7 +102,8 @@ def _block_bwd(blk, saved, dout, gm):
         conv, bn = chain[i]
         first = i == 0
         addend = dres if (first and ds_rec is None) else None      # identity path summed in the dgrad epilogue
-        d, dw, dg, db, _ = L.cba_bwd(recs[i], bn, d, need_dx=True, addend=addend)
+        d, dw, dg, db, _ = L.cba_bwd(recs[i], bn, d, need_dx=True, addend=addend,
+                                     pack_for=prev_rec if (first and ds_rec is None) else None)
         gm.put(conv.weight, dw); gm.put(bn.weight, dg); gm.put(bn.bias, db)
     if ds_rec is not None:
         dconv, dbn = blk.downsample[0], blk.downsample[1]
@@ -171,7 +183,10 @@ class _BackboneFn(torch.autograd.Function):
                     ops._call("sh_axpy", d.data_ptr(), _dense(g).data_ptr(), 1.0, d.numel(), ops._st())
             if d is None:
                 continue
-            d = _block_bwd(blk, saved[idx], d, gm)
+            prev_rec = None
+            if BNB_RESIDUAL and idx > 0 and blocks[idx - 1][0] == li and blk.downsample is None:
+                prev_rec = saved[idx - 1][0][-1]                      # previous block of the same stage feeds this one directly
+            d = _block_bwd(blk, saved[idx], d, gm, prev_rec)
             if idx == 0 or blocks[idx - 1][0] != li:                      # first block of a stage: the stage's gradients are final
                 gm.flush(L.params_of(layers[li]))
         if d is not None:

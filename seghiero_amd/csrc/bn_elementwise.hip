@@ -509,7 +509,8 @@ extern "C" int sh_bn_bwd_finalize(const float* partials, int n_partials, int C, 
 template <int V>
 __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y, long long ldy, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, const float* __restrict__ res, long long ldr,
-                                                     float* __restrict__ out, long long ldo, long long M, int C, int relu) {
+                                                     float* __restrict__ out, long long ldo, long long M, int C, int relu,
+                                                     const float* __restrict__ rscale, const float* __restrict__ rshift) {
     const int cv = C / V;
     // chunks of EW_ROWS rows per block iteration; 32-bit (row, column) split inside a chunk
     for (long long m0 = (long long)blockIdx.x * EW_ROWS; m0 < M; m0 += (long long)gridDim.x * EW_ROWS)
@@ -519,12 +520,16 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y
         const int c = (e - r * cv) * V;
         if (V == 4) {
             f32x4 v = ld4(y + m * ldy + c) * ld4(scale + c) + ld4(shift + c);
-            if (res) v += ld4(res + m * ldr + c);
+            if (res) {
+                f32x4 r = ld4(res + m * ldr + c);
+                if (rscale) r = r * ld4(rscale + c) + ld4(rshift + c);      // the downsample path's BatchNorm applied on the fly
+                v += r;
+            }
             if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
             st4(out + m * ldo + c, v);
         } else {
             float v = y[m * ldy + c] * scale[c] + shift[c];
-            if (res) v += res[m * ldr + c];
+            if (res) v += rscale ? res[m * ldr + c] * rscale[c] + rshift[c] : res[m * ldr + c];
             if (relu) v = fmaxf(v, 0.f);
             out[m * ldo + c] = v;
         }
@@ -542,12 +547,14 @@ static inline bool vec4_ok(int C, long long a, long long b = 0, long long c = 0,
 static inline bool ptr16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 extern "C" int sh_bn_act(const float* y, int ldy, const float* scale, const float* shift, const float* residual, int ldr,
-                         float* out, int ldo, int64_t M, int C, int relu, void* stream) {
+                         const float* res_scale, const float* res_shift, float* out, int ldo, int64_t M, int C, int relu, void* stream) {
     if (!y || !scale || !shift || !out || M <= 0 || C <= 0 || ldy < C || ldo < C) return SH_EINVAL;
     if (residual && ldr < C) return SH_EINVAL;
-    const bool v4 = vec4_ok(C, ldy, ldo, residual ? ldr : 0) && ptr16(y) && ptr16(out) && ptr16(scale) && ptr16(shift) && (!residual || ptr16(residual));
-    if (v4) bn_act_kernel<4><<<rows_grid(M, C / 4), 256, 0, (hipStream_t)stream>>>(y, ldy, scale, shift, residual, ldr, out, ldo, M, C, relu);
-    else bn_act_kernel<1><<<rows_grid(M, C), 256, 0, (hipStream_t)stream>>>(y, ldy, scale, shift, residual, ldr, out, ldo, M, C, relu);
+    if ((res_scale == nullptr) != (res_shift == nullptr) || (res_scale && !residual)) return SH_EINVAL;
+    const bool v4 = vec4_ok(C, ldy, ldo, residual ? ldr : 0) && ptr16(y) && ptr16(out) && ptr16(scale) && ptr16(shift) && (!residual || ptr16(residual)) &&
+                    (!res_scale || (ptr16(res_scale) && ptr16(res_shift)));
+    if (v4) bn_act_kernel<4><<<rows_grid(M, C / 4), 256, 0, (hipStream_t)stream>>>(y, ldy, scale, shift, residual, ldr, out, ldo, M, C, relu, res_scale, res_shift);
+    else bn_act_kernel<1><<<rows_grid(M, C), 256, 0, (hipStream_t)stream>>>(y, ldy, scale, shift, residual, ldr, out, ldo, M, C, relu, res_scale, res_shift);
     return sh_launch_status();
 }
 

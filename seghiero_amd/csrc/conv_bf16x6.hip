@@ -796,7 +796,7 @@ extern "C" int sh_weight_transpose_multi(int n, const float* const* w, float* co
 // statistics of the conv epilogue (centred (sum, M2) per 64 rows); for dgrad optionally the front half of the producer layer's
 // BatchNorm backward (BNB: g = relumask * dx stored, (sum g, sum g*xhat) per 64 rows -> partials, see conv_x6p.hip).
 // Block = 64 rows x 64 columns, thread = 4 rows x 4 columns.
-struct BnbQ { const float* y; long long ldy; const float* mean; const float* invstd; const float* scale; const float* shift; int relu; };
+struct BnbQ { const float* y; long long ldy; const float* mean; const float* invstd; const float* scale; const float* shift; int relu; const float* out; long long ldo; };
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, long long ldslab, int S, long long M, int Nn,
                                                             const float* __restrict__ bias, const float* __restrict__ addend, long long ldadd,
                                                             float* __restrict__ out, long long ldc, float* __restrict__ partials, const BnbQ bnb) {
@@ -823,7 +823,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             if (bnb.y != nullptr) {
                 const f32x4 yv = ld4(bnb.y + m * bnb.ldy + n);
                 if (bnb.relu) {
-                    const f32x4 a = yv * b_sc + b_sh;                    // the forward's own arithmetic (bn_act_kernel)
+                    // the forward's own arithmetic (bn_act_kernel), or the stored block output where a residual was added
+                    const f32x4 a = bnb.out != nullptr ? ld4(bnb.out + m * bnb.ldo + n) : yv * b_sc + b_sh;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) if (!(a[j] > 0.f)) o[j] = 0.f;
                 }
@@ -870,7 +871,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // reduce launch shared with conv_x6p.hip
 int sh_x6_splitk_reduce(const ConvQ& p, int mode, hipStream_t st) {
     dim3 rg((unsigned)sh_cdiv(p.M, 64), (unsigned)sh_cdiv(p.Nn, 64));
-    BnbQ bnb{p.bnb_y, p.bnb_ldy, p.bnb_mean, p.bnb_invstd, p.bnb_scale, p.bnb_shift, p.bnb_relu};
+    BnbQ bnb{p.bnb_y, p.bnb_ldy, p.bnb_mean, p.bnb_invstd, p.bnb_scale, p.bnb_shift, p.bnb_relu, p.bnb_out, p.bnb_ldo};
     splitk_reduce_kernel<<<rg, 256, 0, st>>>(p.slab, p.ldslab, p.ksplit, p.M, p.Nn, mode == FPROP ? p.extra : nullptr,
                                              mode == DGRAD ? p.extra : nullptr, p.ldadd, p.c, p.ldc,
                                              (mode == FPROP || p.bnb_y != nullptr) ? p.partials : nullptr, bnb);
@@ -1127,19 +1128,21 @@ extern "C" int sh_conv_dgrad_x6(const float* dy, int lddy, const float* wt, cons
 // y_prev: raw output of the producer conv [N*H*W][ldyp]; mean / invstd / scale / shift: its BatchNorm coefficients [Cin].
 // SH_EUNSUPPORTED: no fused instantiation for this geometry (strided KxK / scatter); the caller runs the unfused sequence.
 extern "C" int sh_conv_dgrad_x6_bnb(const float* dy, int lddy, const float* wt, const float* addend, int ldadd, float* g, int ldg,
-                                    const float* y_prev, int ldyp, const float* mean, const float* invstd, const float* scale,
-                                    const float* shift, int relu, float* stat_partials, int N, int H, int W, int Cin, int Cout,
+                                    const float* y_prev, int ldyp, const float* out_prev, int ldop, const float* mean, const float* invstd,
+                                    const float* scale, const float* shift, int relu, float* stat_partials, int N, int H, int W, int Cin, int Cout,
                                     int KH, int KW, int stride, int pad, int dil, float* workspace, int64_t workspace_bytes, void* stream) {
     ConvQ p{};
     if (!dy || !wt || !g || !y_prev || !mean || !invstd || !scale || !shift || !stat_partials ||
         !geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil)) return SH_EINVAL;
     const int CoutP = (Cout + 3) & ~3;
-    if (lddy < CoutP || (lddy & 3) || ldg < Cin || ldyp < Cin || (addend && ldadd < Cin)) return SH_EINVAL;
+    if (lddy < CoutP || (lddy & 3) || ldg < Cin || ldyp < Cin || (addend && ldadd < Cin) || (out_prev && ldop < Cin)) return SH_EINVAL;
     if (stride != 1) return SH_EUNSUPPORTED;
     p.a = dy; p.b = wt; p.c = g; p.extra = addend; p.ldadd = ldadd; p.lda = lddy; p.ldc = ldg;
     p.Nn = Cin; p.Kc = CoutP; p.K = KH * KW * CoutP; p.M = N * H * W;
     p.partials = stat_partials; p.n_partials = (int)sh_cdiv(p.M, 64);
     p.bnb_y = y_prev; p.bnb_ldy = ldyp; p.bnb_mean = mean; p.bnb_invstd = invstd; p.bnb_scale = scale; p.bnb_shift = shift; p.bnb_relu = relu;
+    p.bnb_out = out_prev; p.bnb_ldo = ldop;
+    if (out_prev && ((ldop & 3) || ((uintptr_t)out_prev & 15))) return SH_EUNSUPPORTED;
     const bool al = ((ldg | ldyp) & 3) == 0 && (((uintptr_t)g | (uintptr_t)y_prev | (uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)scale |
                                                  (uintptr_t)shift) & 15) == 0 && (!addend || ((ldadd & 3) == 0 && ((uintptr_t)addend & 15) == 0));
     if (al) use_splitk(p, workspace, workspace_bytes);

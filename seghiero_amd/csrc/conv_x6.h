@@ -38,6 +38,8 @@ struct ConvQ {
     const float* bnb_scale;
     const float* bnb_shift;
     int bnb_relu;
+    const float* bnb_out;   // optional: ReLU mask from this tensor (> 0) instead of y*scale+shift -- residual blocks, out = relu(bn(y) + identity)
+    long long bnb_ldo;
     // ---- grouped 1x1 fprop (conv_x6p.hip, GRP): ngroups convolutions of the same geometry whose outputs are consecutive column slices of
     // one buffer; group g = output column / group_n reads its own input (through its own BatchNorm + ReLU, or plain: gfloor = -inf,
     // scale 1, shift 0) and its own weights

@@ -336,7 +336,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
                 for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * RS + 32 * j + l31] = acc[i][j][r];
             __syncthreads();
             f32x4 v[NRD];
-            [[maybe_unused]] f32x4 ad[NRD], yv[NRD];
+            [[maybe_unused]] f32x4 ad[NRD], yv[NRD], ov[NRD];
             long long mrow[NRD];
 #pragma unroll
             for (int k = 0; k < NRD; ++k) {
@@ -347,7 +347,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
                     ad[k] = zero4;
                     if (mrow[k] < Mc && nokv) {
                         if (p.extra != nullptr) ad[k] = ld4(p.extra + mrow[k] * p.ldadd + ncv);
-                        if constexpr (EPI == 2) yv[k] = ld4(p.bnb_y + mrow[k] * p.bnb_ldy + ncv);
+                        if constexpr (EPI == 2) {
+                            yv[k] = ld4(p.bnb_y + mrow[k] * p.bnb_ldy + ncv);
+                            if (p.bnb_out != nullptr) ov[k] = ld4(p.bnb_out + mrow[k] * p.bnb_ldo + ncv);
+                        }
                     }
                 }
             }
@@ -361,7 +364,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
                         o += ad[k];
                         if constexpr (EPI == 2) {
                             if (p.bnb_relu) {
-                                const f32x4 a = yv[k] * v_sc + v_sh;                  // the forward's own arithmetic (bn_act_kernel)
+                                // the forward's own arithmetic (bn_act_kernel), or the stored block output where a residual was added
+                                const f32x4 a = p.bnb_out != nullptr ? ov[k] : yv[k] * v_sc + v_sh;
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) if (!(a[e] > 0.f)) o[e] = 0.f;
                             }
@@ -565,7 +569,7 @@ int sh_x6p_launch(int mode, ConvQ& p, hipStream_t st) {
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     p.vec_epi = !p.parity && !p.scatter && (p.Nn & 3) == 0 && (p.ldc & 3) == 0 && al16(p.c) &&
                 (p.extra == nullptr || (al16(p.extra) && (mode == FPROP || (p.ldadd & 3) == 0))) &&
-                (!bnb || ((p.bnb_ldy & 3) == 0 && al16(p.bnb_y) && al16(p.bnb_mean) && al16(p.bnb_invstd) && al16(p.bnb_scale) &&
+                (!bnb || ((p.bnb_ldy & 3) == 0 && al16(p.bnb_y) && (p.bnb_out == nullptr || ((p.bnb_ldo & 3) == 0 && al16(p.bnb_out))) && al16(p.bnb_mean) && al16(p.bnb_invstd) && al16(p.bnb_scale) &&
                           al16(p.bnb_shift) && al16(p.partials)));
     if (bnb && !p.vec_epi) return SH_X6P_NO;
     { static int v = -2; if (v == -2) { const char* e = getenv("SEGHIERO_X6P_VEC"); v = e ? atoi(e) : 1; } if (!v && !bnb) p.vec_epi = 0; }

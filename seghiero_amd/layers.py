@@ -74,6 +74,15 @@ class Lazy:
         return self._out
 
 
+class LazyAffine:
+    """y * scale + shift (BatchNorm, NO ReLU) of a raw conv output, not materialised: the downsample branch of a residual block,
+    consumed only by the block's final BatchNorm + add + ReLU pass (ops.bn_act(..., res_coefs=...))."""
+    __slots__ = ("y", "coefs")
+
+    def __init__(self, y, coefs):
+        self.y, self.coefs = y, coefs
+
+
 class GradPack:
     """Gradient w.r.t. a deferred activation as the dgrad epilogue leaves it (ops.conv_dgrad_bnb): g = relumask * dx and the
     (sum g, sum g*xhat) partials per 64 rows -- the producer's BatchNorm backward starts from its finalize step."""
@@ -117,11 +126,19 @@ def _wgrad(x, dy, dw, s, p, d):
     ops.conv_wgrad(x, dy, dw, s, p, d, side=True)
 
 
-def _dgrad(rec_x, dy, weight, s, p, d, addend=None):
+def _dgrad(rec_x, dy, weight, s, p, d, addend=None, pack_for=None):
     """Gradient w.r.t. a conv input.  For a deferred activation the dgrad epilogue also runs the front half of the producer's
-    BatchNorm backward (-> GradPack); otherwise a plain tensor."""
+    BatchNorm backward (-> GradPack); otherwise a plain tensor.  pack_for: the CBARec of the residual block whose OUTPUT is this
+    conv's input (out = relu(bn(y) + identity)): the same fusion with the mask taken from `out`."""
     n, c, h, w = rec_x.shape
     dev = dy.device
+    if pack_for is not None and FUSE_BN and not isinstance(rec_x, Lazy):
+        g = ops.new_act(n, c, h, w, dev)
+        partials = torch.empty((-(-n * h * w // 64), 2, c), device=dev, dtype=torch.float32)
+        if ops.conv_dgrad_bnb(dy, weight, g, pack_for.y, pack_for.coefs, True, partials, s, p, d, addend=addend, out_prev=pack_for.out):
+            return GradPack(g, partials)
+        ops.conv_dgrad(dy, weight, g, s, p, d, addend=addend)
+        return g
     if isinstance(rec_x, Lazy) and FUSE_BN:
         g = ops.new_act(n, c, h, w, dev)
         partials = torch.empty((-(-n * h * w // 64), 2, c), device=dev, dtype=torch.float32)
@@ -158,13 +175,18 @@ def cba_fwd(x, weight, geom, bn, relu, training, residual=None, out=None, lazy=F
         coefs = _bn_coefs(bn, partials, m, training, o, x.device)
         if lazy and FUSE_BN and training and relu and residual is None and out is None and ops.CONV_IMPL == "x6":
             out = Lazy(y, coefs)
+        elif lazy and FUSE_BN and training and not relu and residual is None and out is None:
+            out = LazyAffine(y, coefs)
         else:
             if out is None:
                 out = ops.new_act(n, o, ho, wo, x.device, ld=ld, zero=ld != o)
-            ops.bn_act(y, coefs, out, relu, residual)
+            if isinstance(residual, LazyAffine):
+                ops.bn_act(y, coefs, out, relu, residual.y, res_coefs=residual.coefs)
+            else:
+                ops.bn_act(y, coefs, out, relu, residual)
     rec = CBARec()
     rec.x, rec.y, rec.coefs, rec.relu, rec.geom, rec.weight = x, y, coefs, relu, geom, weight
-    rec.out = None if isinstance(out, Lazy) else out
+    rec.out = None if isinstance(out, (Lazy, LazyAffine)) else out
     rec.has_res = residual is not None
     return out, rec
 
@@ -177,7 +199,7 @@ def new_grad(param):
     return torch.empty_like(param) if buf is None else buf
 
 
-def cba_bwd(rec, bn, dout, need_dx=True, addend=None, want_dres=False, scatter_into=None):
+def cba_bwd(rec, bn, dout, need_dx=True, addend=None, want_dres=False, scatter_into=None, pack_for=None):
     """-> (dx, dweight, dgamma, dbeta, dres).  `addend` is summed into dx by the dgrad epilogue;
     `scatter_into` (1x1 strided convs) accumulates the result into an existing dx instead."""
     s, p, d = rec.geom
@@ -194,7 +216,7 @@ def cba_bwd(rec, bn, dout, need_dx=True, addend=None, want_dres=False, scatter_i
         ops.conv_dgrad(dy, rec.weight, scatter_into, s, p, d, mode=1)
         dx = scatter_into
     elif need_dx:
-        dx = _dgrad(rec.x, dy, rec.weight, s, p, d, addend=addend)
+        dx = _dgrad(rec.x, dy, rec.weight, s, p, d, addend=addend, pack_for=pack_for)
     if ops.WGRAD_AFTER_DGRAD:
         # enqueued after the dgrad: the side stream then starts this (MFMA-bound) wgrad when the dgrad has finished, i.e.
         # next to the HBM-bound BatchNorm backward of the previous layer instead of next to another MFMA-bound kernel

@@ -311,7 +311,7 @@ def conv_dgrad(dy, weight, dx, stride, pad, dil, addend=None, mode=0):
         _call("sh_conv_dgrad", *args, _st(), cost=cost, key=_ckey(n, h, w, cin, o, kh, stride, dil))
 
 
-def conv_dgrad_bnb(dy, weight, g, y_prev, coefs, relu, partials, stride, pad, dil, addend=None):
+def conv_dgrad_bnb(dy, weight, g, y_prev, coefs, relu, partials, stride, pad, dil, addend=None, out_prev=None):
     """Input gradient + front half of the producer layer's BatchNorm backward in the dgrad epilogue: g <- relumask * (dx [+ addend]),
     partials[ceil(M/64), 2, Cin] <- (sum g, sum g*xhat) per 64 rows.  -> False when the geometry has no fused kernel."""
     if CONV_IMPL != "x6":
@@ -324,11 +324,12 @@ def conv_dgrad_bnb(dy, weight, g, y_prev, coefs, relu, partials, stride, pad, di
     if lddy < pad4(o):
         return False
     ap, lda = (None, 0) if addend is None else pm(addend)
+    opp, ldop = (None, 0) if out_prev is None else pm(out_prev)
     ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
     m = n * ho * wo
     cost = (2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin * (3 if addend is not None else 2) + m * o + o * cin * kh * kw))
     ws, nb = _splitk_ws(1, n, h, w, cin, o, kh, kw, stride, pad, dil, 0, g.device)
-    return _call_fused("sh_conv_dgrad_x6_bnb", dyp, lddy, weight_transpose(weight).data_ptr(), ap, lda, gp, ldg, ypp, ldyp,
+    return _call_fused("sh_conv_dgrad_x6_bnb", dyp, lddy, weight_transpose(weight).data_ptr(), ap, lda, gp, ldg, ypp, ldyp, opp, ldop,
                        coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(), coefs[3].data_ptr(), int(bool(relu)),
                        partials.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, ws, nb, _st(), cost=cost,
                        key=_ckey(n, h, w, cin, o, kh, stride, dil))
@@ -624,12 +625,15 @@ def channel_stats(y):
     return partials
 
 
-def bn_act(y, coefs, out, relu, residual=None):
+def bn_act(y, coefs, out, relu, residual=None, res_coefs=None):
+    """res_coefs: `residual` is a raw conv output whose BatchNorm (no ReLU) is applied on the fly (the downsample branch)."""
     n, c, h, w = y.shape
     yp, ldy = pm(y)
     op, ldo = pm(out)
     rp, ldr = (None, 0) if residual is None else pm(residual)
-    _call("sh_bn_act", yp, ldy, coefs[2].data_ptr(), coefs[3].data_ptr(), rp, ldr, op, ldo, n * h * w, c, int(relu), _st())
+    _call("sh_bn_act", yp, ldy, coefs[2].data_ptr(), coefs[3].data_ptr(), rp, ldr,
+          None if res_coefs is None else res_coefs[2].data_ptr(), None if res_coefs is None else res_coefs[3].data_ptr(),
+          op, ldo, n * h * w, c, int(relu), _st())
 
 
 def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None):
@@ -667,9 +671,11 @@ def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None):
               coefs[1].data_ptr(), float(m), red[0].data_ptr(), red[1].data_ptr(), red[2].data_ptr(), red[3].data_ptr(), _st())
     ld = pad4(c) if dy_ld is None else dy_ld
     dy = new_act(n, c, h, w, dev, ld=ld, zero=ld != c)
-    dres = new_act(n, c, h, w, dev) if want_dres else None
+    dres = None
+    if want_dres:
+        dres = dout if packed else new_act(n, c, h, w, dev)      # packed: g (mask applied) IS the identity path's gradient
     dyp, lddy = pm(dy)
-    drp, lddr = (None, 0) if dres is None else pm(dres)
+    drp, lddr = (None, 0) if (dres is None or packed) else pm(dres)
     _call("sh_bn_bwd_apply", dop, lddo, op, ldo, yp, ldy, coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(),
           coefs[3].data_ptr(), None if gamma is None else gamma.data_ptr(), red[2].data_ptr(), red[3].data_ptr(), dyp, lddy,
           drp, lddr, m, c, relu, _st())
@@ -779,7 +785,7 @@ def dense_copy(t, ld=None):
     ones[1].zero_()
     tp, ldt = pm(t)
     op, ldo = pm(out)
-    _call("sh_bn_act", tp, ldt, ones[0].data_ptr(), ones[1].data_ptr(), None, 0, op, ldo, n * h * w, c, 0, _st())
+    _call("sh_bn_act", tp, ldt, ones[0].data_ptr(), ones[1].data_ptr(), None, 0, None, None, op, ldo, n * h * w, c, 0, _st())
     return out
 
 

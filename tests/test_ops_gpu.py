@@ -172,6 +172,16 @@ def test_conv_fused_batchnorm_hooks(ops, case):
     gb2 = ops.new_act(n, cin, h, w, DEV)
     assert ops.conv_dgrad_bnb(dyg, wg, gb2, rawg, coefs, False, bpart, 1, p, d)
     close(gb2, ar.grad, 1e-4, 1e-4, "no ReLU: g = dx")
+    # residual form: the mask comes from a stored block output (out = relu(bn(y) + identity)), not from y*scale+shift
+    outp = torch.randn(raw.shape, generator=g)
+    gb3 = ops.new_act(n, cin, h, w, DEV)
+    assert ops.conv_dgrad_bnb(dyg, wg, gb3, rawg, coefs, True, bpart, 1, p, d, out_prev=nhwc(outp))
+    g3 = ar.grad * (outp > 0)
+    close(gb3, g3, 1e-4, 1e-4, "mask from out_prev")
+    gk = gb3.cpu().double()
+    sums = bpart.double().sum(0).cpu()
+    np.testing.assert_allclose(sums[1].numpy(), (gk * xhat).sum((0, 2, 3)).numpy(), rtol=1e-5,
+                               atol=1e-5 * float((gk * xhat).abs().sum((0, 2, 3)).max()))
 
 
 def test_conv_reads_and_writes_channel_slices(ops):

@@ -1,2 +1,3 @@
-cd "$GRAFT_REPO_ROOT"; python tests/diag/aspp_host.py 2>&1 | grep -v amdgpu | head -50
-timeout -k 10 600 python -m pytest tests/test_model_gpu.py -m gpu -q -x --timeout=600 -k "head" 2>&1 | tail -8
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -m gpu -q -x --timeout=900 2>&1 | tail -6
+python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['kernel_ms_per_step'])"
