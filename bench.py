@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--steps", type=int, default=150)        # ~5 s timed region: a sustained-clock number
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-units", action="store_true", help="skip the separate north-star unit measurement (profiling runs)")
     ap.add_argument("--batch", type=int, default=CFG["batch"])
     ap.add_argument("--syncbn", action="store_true",
                     help="N > 1: BatchNorm statistics over all ranks (BASELINE configs[2] variant; default = per-rank statistics, "
@@ -174,11 +175,13 @@ def main():
     except Exception:
         pass
     # the north-star unit (BASELINE.json): ASPP depthwise-separable branch forward, timed on its own
-    try:
-        from seghiero_amd import units
-        roof_units = {"aspp_ds_branch": units.measure(device=dev, batch=args.batch)}
-    except Exception as e:                      # never lose the headline line to the side measurement
-        roof_units = {"aspp_ds_branch": {"error": repr(e)}}
+    roof_units = None
+    if not args.no_units:
+        try:
+            from seghiero_amd import units
+            roof_units = {"aspp_ds_branch": units.measure(device=dev, batch=args.batch)}
+        except Exception as e:                  # never lose the headline line to the side measurement
+            roof_units = {"aspp_ds_branch": {"error": repr(e)}}
     breakdown = {k: round(v["ms"], 2) for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])[:12]}
     out = {
         "metric": "images/sec at 512x512 (ResNet-50 2-level), full train step", "value": round(args.batch * world * args.steps / dt, 2),

@@ -201,7 +201,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             u32x2 q1, q2, q3;
+#ifdef SH_ABLATE_BSPLIT      // timing-only build (wrong numerics): what the B-operand split costs -- the ceiling of pre-split weight planes
+            q1[0] = __float_as_uint(R.b[i][0]); q1[1] = __float_as_uint(R.b[i][1]); q2 = q1; q3[0] = __float_as_uint(R.b[i][2]); q3[1] = __float_as_uint(R.b[i][3]);
+#else
             split4(R.b[i], q1, q2, q3);
+#endif
             const int off = off0 + RPP * i * ROWB;
             *reinterpret_cast<u32x2*>(Bs + off) = q1;
             *reinterpret_cast<u32x2*>(Bs + B_PLANE + off) = q2;

@@ -1,3 +1,5 @@
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -m gpu -q -x --timeout=900 2>&1 | tail -6
-python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['kernel_ms_per_step'])"
+for s in sep1.pw sep0.pw l2.conv2 l3.conv3 proj; do
+  python tools/bench_conv.py $s 2>&1 | grep -v "amdgpu\|TOTAL"
+  SEGHIERO_LIB=$PWD/seghiero_amd/csrc/alt/libseghiero_ablate.so python tools/bench_conv.py $s 2>&1 | grep -v "amdgpu\|TOTAL" | sed 's/^/   ablateB: /'
+done
