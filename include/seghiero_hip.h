@@ -259,7 +259,11 @@ int sh_broadcast_hw(const float* x, float* y, int ldy, int N, int HW, int C, voi
 int sh_sum_hw(const float* dy, int lddy, float* dx, int N, int HW, int C, void* stream);
 /* F.interpolate(mode='bilinear', align_corners=False) NHWC (sep_aspp_contrast_head.py:235-238) and its backward. */
 int sh_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int h, int w, int H, int W, int C, void* stream);
-int sh_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int h, int w, int H, int W, int C, void* stream);
+/* workspace (optional, sh_bilinear_bwd_workspace bytes, 16-byte aligned; used when H >= 2h and W >= 2w): backward that reads dy once
+ * (row bands + two partial planes) instead of the gather form's ~4 reads per element. */
+int64_t sh_bilinear_bwd_workspace(int N, int h, int w, int C);
+int sh_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int h, int w, int H, int W, int C, float* workspace,
+                    int64_t workspace_bytes, void* stream);
 /* F.normalize(p=2, dim=1, eps=1e-12) over channels (sep_aspp_contrast_head.py:29). */
 int sh_l2norm_fwd(const float* x, float* y, float* norm, int64_t M, int C, void* stream);
 int sh_l2norm_bwd(const float* dy, const float* y, const float* norm, float* dx, int64_t M, int C, void* stream);
@@ -271,27 +275,34 @@ int sh_l2norm_bwd(const float* dy, const float* y, const float* norm, float* dx,
  *   buckets_host: HOST int32 [n_coarse][2] (start,end).   labels: uint8 [N,H,W] (255 = ignore).
  *   sums (device double[8]) <- {bce_fine, bce_coarse, ce_fine, ce_coarse, n_valid_fine, n_valid_coarse, n_pixels, 0}
  *   loss_out (device float[1]) <- 5*(bce_f/(max(nvf,1)*nf) + bce_c/(max(nvc,1)*nc)) + ce_f/npix + ce_c/npix
- *   partials: float [sh_hiera2_partials(N,H,W)][8] scratch.  coarse_out (optional): uint8 [N,H,W] coarse targets. */
+ *   partials: float [sh_hiera2_partials(N,H,W)][8] scratch.  coarse_out (optional): uint8 [N,H,W] coarse targets.
+ *   grad_out (optional; sh_loss_bwd_workspace(N,H,W,ldg) bytes, 16-byte aligned, ldg % 4 == 0, upsampling only): the same pass
+ *   also writes every full-resolution pixel's d(loss_out)/d(interpolated logits) [N*H*W][ldg] -- its normalisers are label counts,
+ *   taken by a small pre-pass -- so the backward is only the adjoint of the resize (sh_hiera2_loss_bwd, workspace_has_grad = 1)
+ *   and the per-pixel sigmoid / softmax arithmetic (VALU-bound, ~0.3 ms at 16x512x512) runs once per step instead of twice. */
 int sh_hiera2_partials(int N, int H, int W);
 int sh_hiera2_loss_fwd(const float* logits, int ldl, const uint8_t* labels, const int* buckets_host, int n_fine,
                        int n_coarse, double* sums, float* loss_out, float* partials, uint8_t* coarse_out,
-                       int N, int h, int w, int H, int W, void* stream);
+                       int N, int h, int w, int H, int W, float* grad_out, int64_t grad_out_bytes, int ldg, void* stream);
 /* d(loss_out)/d(logits) * gscale * gscale_dev[0] into dlogits [N,h,w,lddl] (gather form, deterministic; lanes
  * >= C of each row are zeroed).  Uses the counts left in `sums` by the forward.  workspace (optional, sh_loss_bwd_workspace
  * bytes, 16-byte aligned; needs lddl % 4 == 0): two streaming passes -- every full-resolution pixel's gradient once into the
  * workspace, then the adjoint of the bilinear resize as a gather -- instead of the LDS-tiled single kernel that recomputes
- * halo pixels (same arithmetic and summation order: bit-identical results, 4-5x faster at the x4 resize of train.py:282-284). */
+ * halo pixels (same arithmetic and summation order: bit-identical results, 4-5x faster at the x4 resize of train.py:282-284).
+ * workspace_has_grad = 1: `workspace` is the grad_out of the forward (unit upstream gradient); only the gather runs, its result
+ * scaled by gscale * gscale_dev[0]. */
 int64_t sh_loss_bwd_workspace(int N, int H, int W, int lddl);
 int sh_hiera2_loss_bwd(const float* logits, int ldl, const uint8_t* labels, const int* buckets_host, int n_fine,
                        int n_coarse, const double* sums, const float* gscale_dev, float gscale, float* dlogits,
-                       int lddl, int N, int h, int w, int H, int W, float* workspace, int64_t workspace_bytes, void* stream);
+                       int lddl, int N, int h, int w, int H, int W, float* workspace, int64_t workspace_bytes,
+                       int workspace_has_grad, void* stream);
 /* Fused bilinear resize + nn.CrossEntropyLoss(ignore_index=255) (valid-pixel mean) of the aux head
  * (train.py:309-313).  sums double[2] = {ce_sum, n_valid}; loss_out = ce_sum / n_valid. */
 int sh_ce_loss_fwd(const float* logits, int ldl, const uint8_t* labels, int C, double* sums, float* loss_out,
-                   float* partials, int N, int h, int w, int H, int W, void* stream);
+                   float* partials, int N, int h, int w, int H, int W, float* grad_out, int64_t grad_out_bytes, int ldg, void* stream);
 int sh_ce_loss_bwd(const float* logits, int ldl, const uint8_t* labels, int C, const double* sums,
                    const float* gscale_dev, float gscale, float* dlogits, int lddl, int N, int h, int w, int H,
-                   int W, float* workspace, int64_t workspace_bytes,
+                   int W, float* workspace, int64_t workspace_bytes, int workspace_has_grad,
                    void* stream);
 /* int64 label map -> uint8 (the reference hands the loss i64 labels, train.py:262). */
 int sh_labels_to_u8(const int64_t* in, uint8_t* out, int64_t n, void* stream);

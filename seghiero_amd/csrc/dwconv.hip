@@ -7,6 +7,7 @@
 // centre-tap degeneration of SURVEY A.1) are skipped block-uniformly.  The forward also emits the per-channel
 // (sum, sum^2) partials of its output for the following train-mode BatchNorm, so the tensor is not re-read.
 #include "common.h"
+#include <stdlib.h>
 
 #define DW_PIX 64          // pixels per block
 #define DW_CH 64           // channels per block (16 float4 lanes)
@@ -282,6 +283,233 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tile_kernel(const float* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------- strip walk (dilation 1)
+// The 8x8 tiles of one 64-channel chunk, ordered strip by strip (a strip = 8 rows of one image, left to right), are cut into
+// contiguous runs, one per block (the launcher makes a run = a strip).  Inside a strip
+// the input halo lives in an LDS ring of 10 columns x 10 rows (25.6 KB): a step replaces the 8 columns the finished tile no
+// longer needs with the 8 NEW ones (10x8 instead of 10x10 pixel rows per tile), and they are fetched into registers BEFORE the
+// current tile is computed, so the loads of tile t+1 are in flight under the LDS reads, FMAs and stores of tile t.  Channel chunk
+// is fastest in the grid (8 chunks -> one chunk per XCD), so runs of neighbouring strips share their halo rows in that XCD's L2.
+// Weights sit in registers.  Statistics partials keep the per-tile layout of dwconv_tile_kernel (one partial per 64 pixels).
+#define DWR 10                    // ring columns: column ix lives in slot (ix + 1) % 10
+__device__ __forceinline__ int dw_slot(int base, int k) { const int i = base + k; return i >= DWR ? i - DWR : i; }   // base < 10, k < 10
+struct DwWalk {
+    int n, ty, c0, c, tiles_x, tiles_y;
+    bool cok;
+    long long t0, t1;             // this block's run of tiles [t0, t1) of its chunk; tile t = strip * tiles_x + tx
+};
+__device__ __forceinline__ void dw_walk_init(DwWalk& q, int H, int W, int C, int N, int cq) {
+    const unsigned nch = (unsigned)((C + DW_CH - 1) / DW_CH), nb = gridDim.x / nch, k = blockIdx.x / nch;
+    q.c0 = (int)(blockIdx.x % nch) * DW_CH; q.c = q.c0 + cq * 4; q.cok = q.c < C;
+    q.tiles_x = W / DT; q.tiles_y = H / DT;
+    const long long T = (long long)N * q.tiles_y * q.tiles_x;
+    q.t0 = T * k / nb; q.t1 = T * (k + 1) / nb;
+}
+__device__ __forceinline__ void dw_walk_strip(DwWalk& q, long long strip) { q.ty = (int)(strip % q.tiles_y); q.n = (int)(strip / q.tiles_y); }
+__device__ __forceinline__ bool dw_walk_inside(const DwWalk& q, int H, int W, int hy, int ix) {
+    return q.cok && (unsigned)(q.ty * DT + hy - 1) < (unsigned)H && (unsigned)ix < (unsigned)W;
+}
+// raw element (zero outside the image); the producer's BatchNorm + ReLU is applied by dw_walk_act when the value goes to LDS,
+// i.e. AFTER the arithmetic of the current tile, so the prefetch stays in flight
+__device__ __forceinline__ f32x4 dw_walk_fetch(const float* __restrict__ x, long long ldx, const DwWalk& q, int H, int W, int hy, int ix) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (dw_walk_inside(q, H, W, hy, ix)) v = ld4(x + (((long long)q.n * H + q.ty * DT + hy - 1) * W + ix) * ldx + q.c);
+    return v;
+}
+__device__ __forceinline__ f32x4 dw_walk_act(f32x4 v, bool aff, bool inside, const f32x4& sc, const f32x4& sh) {
+    if (aff && inside) {            // sh_bn_act's own operation order; zero padding stays zero
+        v = v * sc + sh;
+        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+    }
+    return v;
+}
+// columns 8tx-1 .. 8tx+8 of the strip -> ring slots rb .. rb+9 (start of a run / of a strip); 100 items over 16 pixel lanes
+__device__ __forceinline__ void dw_walk_prologue(float (*xs)[DWR][DW_CH], const float* __restrict__ x, long long ldx, bool aff,
+                                                 const f32x4& sc, const f32x4& sh, const DwWalk& q, int H, int W, int tx, int rb, int pl, int cq) {
+    for (int i = pl; i < (DT + 2) * (DT + 2); i += 16) {
+        const int hy = i / (DT + 2), hx = i - hy * (DT + 2), ix = tx * DT + hx - 1;
+        st4(&xs[hy][dw_slot(rb, hx)][cq * 4], dw_walk_act(dw_walk_fetch(x, ldx, q, H, W, hy, ix), aff, dw_walk_inside(q, H, W, hy, ix), sc, sh));
+    }
+}
+template <int MODE>   // 0 fprop (+stats), 1 dgrad (flipped taps, optional accumulate / BatchNorm-backward epilogue)
+__global__ __launch_bounds__(256) void dwconv_walk_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ w,
+                                                          float* __restrict__ y, long long ldy, float* __restrict__ partials,
+                                                          int N, int H, int W, int C, int accumulate,
+                                                          const float* __restrict__ isc, const float* __restrict__ ish, const DwBnb bnb) {
+    __shared__ __attribute__((aligned(16))) float xs[DT + 2][DWR][DW_CH];
+    __shared__ float red[16][DW_CH];
+    __shared__ float colmean[DW_CH];
+    const int t = threadIdx.x, cq = t & 15, pl = t >> 4;
+    DwWalk q;
+    dw_walk_init(q, H, W, C, N, cq);
+    f32x4 wr[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wr[k][j] = q.cok ? w[(long long)(q.c + j) * 9 + (MODE == 0 ? k : 8 - k)] : 0.f;
+    const bool aff = isc != nullptr;
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
+    if (aff && q.cok) { sc = ld4(isc + q.c); sh = ld4(ish + q.c); }
+    int tx = (int)(q.t0 % q.tiles_x), rb = (tx * DT) % DWR;
+    for (long long tile = q.t0; tile < q.t1; ++tile) {
+        if (tile == q.t0 || tx == 0) {            // the run or a strip begins: the whole 10x10 halo (the loop ends on a barrier)
+            dw_walk_strip(q, tile / q.tiles_x);
+            dw_walk_prologue(xs, x, ldx, aff, sc, sh, q, H, W, tx, rb, pl, cq);
+            __syncthreads();
+        }
+        // columns 8tx+9 .. 8tx+16 (tile tx+1's new ones): 80 items, 5 per thread, in flight during this tile's arithmetic
+        f32x4 nx[5];
+        const bool more = tx + 1 < q.tiles_x && tile + 1 < q.t1;
+        if (more) {
+#pragma unroll
+            for (int it = 0; it < 5; ++it) {
+                const int i = it * 16 + pl;
+                nx[it] = dw_walk_fetch(x, ldx, q, H, W, i >> 3, tx * DT + 9 + (i & 7));
+            }
+        }
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        f32x4 bsg = s, bsq = s;
+        f32x4 kept[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int pidx = it * 16 + pl, py = pidx / DT, px = pidx - py * DT;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+                    acc += ld4(&xs[py + kh][dw_slot(rb, px + kw)][cq * 4]) * wr[kh * 3 + kw];
+            kept[it] = acc;
+            if (q.cok) {
+                const long long m = (((long long)q.n * H + q.ty * DT + py) * W + tx * DT + px);
+                float* dst = y + m * ldy + q.c;
+                if (MODE == 1 && accumulate) acc += ld4(dst);
+                if (MODE == 1 && bnb.y != nullptr) acc = dw_bnb_apply(bnb, m, q.c, acc, bsg, bsq);
+                st4(dst, acc);
+            }
+            s += kept[it];
+        }
+        if (MODE == 1 && bnb.y != nullptr) dw_bnb_store(bnb, red, bsg, bsq, tile, C, q.c0, t, cq, pl);
+        if (MODE == 0 && partials != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[pl][cq * 4 + j] = s[j];
+            __syncthreads();
+            float colsum = 0.f;
+            if (t < DW_CH) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) colsum += red[k][t];
+                colmean[t] = colsum / (float)(DT * DT);
+            }
+            __syncthreads();
+            f32x4 qq = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 mu = ld4(&colmean[cq * 4]);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) { const f32x4 dv = kept[it] - mu; qq += dv * dv; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[pl][cq * 4 + j] = qq[j];
+            __syncthreads();
+            if (t < DW_CH && q.c0 + t < C) {
+                float m2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) m2 += red[k][t];
+                partials[(tile * 2 + 0) * C + q.c0 + t] = colsum;
+                partials[(tile * 2 + 1) * C + q.c0 + t] = m2;
+            }
+        }
+        __syncthreads();                 // every wave is done reading the ring columns the next step overwrites (and `red`)
+        if (more) {
+#pragma unroll
+            for (int it = 0; it < 5; ++it) {
+                const int i = it * 16 + pl;
+                st4(&xs[i >> 3][dw_slot(rb, i & 7)][cq * 4],
+                    dw_walk_act(nx[it], aff, dw_walk_inside(q, H, W, i >> 3, tx * DT + 9 + (i & 7)), sc, sh));
+            }
+            __syncthreads();
+        }
+        if (++tx == q.tiles_x) { tx = 0; rb = 0; } else rb = rb >= 2 ? rb - 2 : rb + 8;       // rb = (8 tx) % 10
+    }
+}
+// wgrad, strip walk: x through the same ring, dy straight from global (prefetched one tile ahead), nine accumulators per thread;
+// one partial [9][C] per block
+__global__ __launch_bounds__(256) void dwconv_wgrad_walk_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ dy,
+                                                               long long lddy, float* __restrict__ partials, int N, int H, int W, int C,
+                                                               const float* __restrict__ isc, const float* __restrict__ ish) {
+    __shared__ __attribute__((aligned(16))) float xs[DT + 2][DWR][DW_CH];
+    __shared__ float red[16][DW_CH];
+    const int t = threadIdx.x, cq = t & 15, pl = t >> 4;
+    DwWalk q;
+    dw_walk_init(q, H, W, C, N, cq);
+    f32x4 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool aff = isc != nullptr;
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
+    if (aff && q.cok) { sc = ld4(isc + q.c); sh = ld4(ish + q.c); }
+    f32x4 g[4];
+    auto fetch_dy = [&](long long tile) {
+        const long long strip = tile / q.tiles_x;
+        const int ftx = (int)(tile - strip * q.tiles_x), fty = (int)(strip % q.tiles_y);
+        const long long fn = strip / q.tiles_y;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int pidx = it * 16 + pl, py = pidx / DT, px = pidx - py * DT;
+            g[it] = q.cok ? ld4(dy + ((fn * H + fty * DT + py) * W + ftx * DT + px) * lddy + q.c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    if (q.t0 < q.t1) fetch_dy(q.t0);
+    int tx = (int)(q.t0 % q.tiles_x), rb = (tx * DT) % DWR;
+    for (long long tile = q.t0; tile < q.t1; ++tile) {
+        if (tile == q.t0 || tx == 0) {
+            dw_walk_strip(q, tile / q.tiles_x);
+            dw_walk_prologue(xs, x, ldx, aff, sc, sh, q, H, W, tx, rb, pl, cq);
+            __syncthreads();
+        }
+        f32x4 nx[5];
+        const bool more = tx + 1 < q.tiles_x && tile + 1 < q.t1;
+        if (more) {
+#pragma unroll
+            for (int it = 0; it < 5; ++it) {
+                const int i = it * 16 + pl;
+                nx[it] = dw_walk_fetch(x, ldx, q, H, W, i >> 3, tx * DT + 9 + (i & 7));
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int pidx = it * 16 + pl, py = pidx / DT, px = pidx - py * DT;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+                    acc[kh * 3 + kw] += g[it] * ld4(&xs[py + kh][dw_slot(rb, px + kw)][cq * 4]);
+        }
+        if (tile + 1 < q.t1) fetch_dy(tile + 1);
+        __syncthreads();
+        if (more) {
+#pragma unroll
+            for (int it = 0; it < 5; ++it) {
+                const int i = it * 16 + pl;
+                st4(&xs[i >> 3][dw_slot(rb, i & 7)][cq * 4],
+                    dw_walk_act(nx[it], aff, dw_walk_inside(q, H, W, i >> 3, tx * DT + 9 + (i & 7)), sc, sh));
+            }
+            __syncthreads();
+        }
+        if (++tx == q.tiles_x) { tx = 0; rb = 0; } else rb = rb >= 2 ? rb - 2 : rb + 8;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[pl][cq * 4 + j] = acc[k][j];
+        __syncthreads();
+        if (t < DW_CH) {
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a += red[r][t];
+            if (q.c0 + t < C) partials[((long long)(blockIdx.x / ((C + DW_CH - 1) / DW_CH)) * 9 + k) * C + q.c0 + t] = a;
+        }
+    }
+}
+
 // wgrad: dw[c][tap] = sum_pix dy[pix][c] * x[pix + tap][c]; per-block partials [P][9][C], then a column reduce.
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ dy,
                                                            long long lddy, float* __restrict__ partials, int H, int W, int C,
@@ -348,6 +576,15 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_reduce_kernel(const float* _
     }
 }
 
+// SEGHIERO_DW_WALK=0: the per-tile kernels (A/B timing)
+static bool dw_walk_on() {
+    static const bool on = [] { const char* e = getenv("SEGHIERO_DW_WALK"); return !(e && e[0] == '0'); }();
+    return on;
+}
+// blocks per channel chunk of the walk kernels = strips.  (Measured: cutting the tile sequence into equal runs, one per resident
+// block, is 10 % SLOWER -- runs that start mid-strip fall out of step with the strips above / below, whose halo rows they then miss
+// in L2.)
+static unsigned dw_walk_blocks(int N, int H, int W, int C) { (void)W; (void)C; return (unsigned)(N * (H / DT)); }
 static bool dw_args_ok(const void* a, const void* b, const void* c, int N, int H, int W, int C, int dil, int ld1, int ld2) {
     return a && b && c && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && dil > 0 && ld1 >= C && ld2 >= C && !(ld1 & 3) && !(ld2 & 3);
 }
@@ -357,7 +594,9 @@ extern "C" int sh_dwconv_fprop(const float* x, int ldx, const float* in_scale, c
     if ((in_scale == nullptr) != (in_shift == nullptr) || (((uintptr_t)in_scale | (uintptr_t)in_shift) & 15)) return SH_EINVAL;
     const long long M = (long long)N * H * W;
     dim3 grid((unsigned)sh_cdiv(M, DW_PIX), (unsigned)sh_cdiv(C, DW_CH));
-    if (dil == 1 && H % DT == 0 && W % DT == 0)       // same partial count: (H/8)*(W/8) tiles of 64 pixels per image
+    if (dil == 1 && H % DT == 0 && W % DT == 0 && dw_walk_on())       // same partial count: (H/8)*(W/8) tiles of 64 pixels per image
+        dwconv_walk_kernel<0><<<dw_walk_blocks(N, H, W, C) * grid.y, 256, 0, (hipStream_t)stream>>>(x, ldx, w, y, ldy, stat_partials, N, H, W, C, 0, in_scale, in_shift, DwBnb{});
+    else if (dil == 1 && H % DT == 0 && W % DT == 0)
         dwconv_tile_kernel<0><<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(x, ldx, w, y, ldy, stat_partials, H, W, C, 0, in_scale, in_shift, DwBnb{});
     else
         dwconv_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, w, y, ldy, stat_partials, H, W, C, dil, M, 0, in_scale, in_shift, DwBnb{});
@@ -367,7 +606,9 @@ static int dw_dgrad_any(const float* dy, int lddy, const float* w, float* dx, in
                         const DwBnb& bnb, void* stream) {
     const long long M = (long long)N * H * W;
     dim3 grid((unsigned)sh_cdiv(M, DW_PIX), (unsigned)sh_cdiv(C, DW_CH));
-    if (dil == 1 && H % DT == 0 && W % DT == 0)
+    if (dil == 1 && H % DT == 0 && W % DT == 0 && dw_walk_on())
+        dwconv_walk_kernel<1><<<dw_walk_blocks(N, H, W, C) * grid.y, 256, 0, (hipStream_t)stream>>>(dy, lddy, w, dx, lddx, nullptr, N, H, W, C, accumulate, nullptr, nullptr, bnb);
+    else if (dil == 1 && H % DT == 0 && W % DT == 0)
         dwconv_tile_kernel<1><<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(dy, lddy, w, dx, lddx, nullptr, H, W, C, accumulate, nullptr, nullptr, bnb);
     else
         dwconv_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(dy, lddy, w, dx, lddx, nullptr, H, W, C, dil, M, accumulate, nullptr, nullptr, bnb);
@@ -396,7 +637,10 @@ extern "C" int sh_dwconv_wgrad(const float* x, int ldx, const float* in_scale, c
     const int cap = (int)sh_cdiv(1024, sh_cdiv(C, DW_CH));          // ~4 blocks per CU over all channel chunks
     if (P > cap) P = cap < 1 ? 1 : cap;
     dim3 grid((unsigned)P, (unsigned)sh_cdiv(C, DW_CH));
-    if (dil == 1 && H % DT == 0 && W % DT == 0)
+    if (dil == 1 && H % DT == 0 && W % DT == 0 && dw_walk_on()) {
+        P = (int)dw_walk_blocks(N, H, W, C);                        // one partial per block (<= M/64 rows of the workspace)
+        dwconv_wgrad_walk_kernel<<<(unsigned)P * grid.y, 256, 0, (hipStream_t)stream>>>(x, ldx, dy, lddy, dw_partials, N, H, W, C, in_scale, in_shift);
+    } else if (dil == 1 && H % DT == 0 && W % DT == 0)
         dwconv_wgrad_tile_kernel<<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(x, ldx, dy, lddy, dw_partials, H, W, C, M / (DT * DT), in_scale, in_shift);
     else
         dwconv_wgrad_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, dy, lddy, dw_partials, H, W, C, dil, M, in_scale, in_shift);

@@ -102,13 +102,38 @@ __device__ __forceinline__ void hiera2_pixel(const float (&z)[MAXC], int f, int 
 }
 
 // ------------------------------------------------------------------------------------------ 2-level forward
-template <int MAXC>
+// valid-label counts ahead of a forward that also emits the gradient (its normalisers): cnt[0] = #fine valid, cnt[1] = #coarse valid
+__global__ __launch_bounds__(256) void label_counts_kernel(const uint8_t* __restrict__ labels, const H2Tab T, int with_coarse, long long total,
+                                                           unsigned long long* __restrict__ cnt) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long a = 0, b = 0;                      // wave-uniform
+    for (long long i0 = (long long)blockIdx.x * 256 + (threadIdx.x & ~63); i0 < total; i0 += (long long)gridDim.x * 256) {
+        const int f = i0 + lane < total ? labels[i0 + lane] : IGN;
+        a += __popcll(__ballot(f != IGN));
+        if (with_coarse) b += __popcll(__ballot(f != IGN && coarse_of(f, T) != IGN));
+    }
+    if (lane == 0) {
+        if (a) atomicAdd(cnt + 0, a);
+        if (with_coarse && b) atomicAdd(cnt + 1, b);
+    }
+}
+// GRAD: every pixel's d(loss_out)/d(interpolated logits) goes to gfull [N*H*W][L] in the same pass (the backward is then only
+// the adjoint of the resize); cnt = the label counts of label_counts_kernel.
+template <int MAXC, bool GRAD>
 __global__ __launch_bounds__(256) void hiera2_fwd_kernel(const float* __restrict__ logits, long long ldl, const uint8_t* __restrict__ labels,
                                                          const H2Tab T, float* __restrict__ partials, uint8_t* __restrict__ coarse_out,
-                                                         int h, int w, int H, int W, float sy, float sx, long long total) {
+                                                         int h, int w, int H, int W, float sy, float sx, long long total,
+                                                         const unsigned long long* __restrict__ cnt, float* __restrict__ gfull, int L) {
     const bool identity = (h == H && w == W);
     const int C = T.nf + T.nc;
     float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float af = 0.f, ac = 0.f, b = 0.f;
+    if (GRAD) {       // the coefficients of loss_grad_fullres_kernel at unit upstream gradient
+        const double nvf = cnt[0] < 1 ? 1.0 : (double)cnt[0], nvc = cnt[1] < 1 ? 1.0 : (double)cnt[1];
+        af = (float)(5.0 / (nvf * T.nf));
+        ac = T.nc > 0 ? (float)(5.0 / (nvc * T.nc)) : 0.f;
+        b = (float)(1.0 / (double)total);
+    }
     const long long base = (long long)blockIdx.x * LOSS_PIX_PER_BLOCK;
 #pragma unroll 1
     for (int it = 0; it < LOSS_PIX_PER_BLOCK / 256; ++it) {
@@ -117,17 +142,29 @@ __global__ __launch_bounds__(256) void hiera2_fwd_kernel(const float* __restrict
         const int f = labels[i];
         const int c = f == IGN ? IGN : coarse_of(f, T);
         if (coarse_out) coarse_out[i] = (uint8_t)c;
-        if (f == IGN) continue;       // coarse is 255 too (255 is in no bucket): nothing contributes
-        const int ox = (int)(i % W);
-        const long long q = i / W;
-        const int oy = (int)(q % H);
-        const long long n = q / H;
-        const Lerp ly = lerp_src(oy, sy, h), lx = lerp_src(ox, sx, w);
-        float z[MAXC], g[MAXC], o[4];
-        fetch_logits<MAXC>(logits + n * h * w * ldl, ldl, w, ly, lx, identity, C, z);
-        hiera2_pixel<MAXC, false>(z, f, c, T, 0.f, 0.f, 0.f, o, g);
-        v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
-        v[4] += 1.f; v[5] += (c != IGN) ? 1.f : 0.f;
+        float g[MAXC];
+        if (GRAD) {
+#pragma unroll
+            for (int j = 0; j < MAXC; ++j) g[j] = 0.f;
+        }
+        if (f != IGN) {       // else coarse is 255 too (255 is in no bucket): nothing contributes
+            const int ox = (int)(i % W);
+            const long long q = i / W;
+            const int oy = (int)(q % H);
+            const long long n = q / H;
+            const Lerp ly = lerp_src(oy, sy, h), lx = lerp_src(ox, sx, w);
+            float z[MAXC], o[4];
+            fetch_logits<MAXC>(logits + n * h * w * ldl, ldl, w, ly, lx, identity, C, z);
+            hiera2_pixel<MAXC, GRAD>(z, f, c, T, af, ac, b, o, g);
+            v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+            v[4] += 1.f; v[5] += (c != IGN) ? 1.f : 0.f;
+        }
+        if (GRAD) {
+            float* dst = gfull + i * L;
+#pragma unroll
+            for (int j = 0; j < MAXC; j += 4)
+                if (j < L) st4(dst + j, f32x4{g[j], g[j + 1], g[j + 2], g[j + 3]});
+        }
     }
     block_reduce_store<6>(v, partials);
 }
@@ -361,10 +398,15 @@ __global__ __launch_bounds__(256) void loss_grad_fullres_kernel(const float* __r
             if (j < L) st4(dst + j, f32x4{g[j], g[j + 1], g[j + 2], g[j + 3]});
     }
 }
-// adjoint of the resize: thread = (low-res pixel, channel quad)
+// adjoint of the resize: thread = (low-res pixel, channel quad).  A row's candidates are taken 8 at a time -- weights first, the 8
+// loads issued together, then the sums in (row, column) order -- so a thread has 8 loads in flight instead of one (the serial form
+// spent its time in L2 latency: 364 us for 268 MB).  post_scale: the workspace holds the gradient at unit upstream gradient
+// (written by the forward), scaled here.
 __global__ __launch_bounds__(256) void resize_adjoint_gather_kernel(const float* __restrict__ gfull, float* __restrict__ dlogits, int L, int h, int w,
-                                                                    int H, int W, float sy, float sx, long long total) {
+                                                                    int H, int W, float sy, float sx, long long total,
+                                                                    const float* __restrict__ gscale_dev, float gscale, int post_scale) {
     const int LQ = L / 4;
+    const float gs = post_scale ? gscale * (gscale_dev ? gscale_dev[0] : 1.f) : 1.f;
     for (long long item = (long long)blockIdx.x * 256 + threadIdx.x; item < total; item += (long long)gridDim.x * 256) {
         const int cq = (int)(item % LQ);
         long long pq = item / LQ;
@@ -380,14 +422,36 @@ __global__ __launch_bounds__(256) void resize_adjoint_gather_kernel(const float*
             const float wy = (ly.i0 == iy ? ly.w0 : 0.f) + (ly.i1 == iy ? ly.w1 : 0.f);
             if (wy == 0.f) continue;
             const float* row = gfull + ((n * H + oy) * W) * L + 4 * cq;
-            for (int ox = cxlo; ox <= cxhi; ++ox) {
-                const Lerp lx = lerp_src(ox, sx, w);
-                const float wx = (lx.i0 == ix ? lx.w0 : 0.f) + (lx.i1 == ix ? lx.w1 : 0.f);
-                if (wx != 0.f) acc += (wy * wx) * ld4(row + (long long)ox * L);
+            for (int ox0 = cxlo; ox0 <= cxhi; ox0 += 8) {
+                f32x4 v[8];
+                float wx[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int ox = ox0 + k, oxc = ox <= cxhi ? ox : cxhi;
+                    const Lerp lx = lerp_src(oxc, sx, w);
+                    wx[k] = ox <= cxhi ? (lx.i0 == ix ? lx.w0 : 0.f) + (lx.i1 == ix ? lx.w1 : 0.f) : 0.f;
+                    v[k] = ld4(row + (long long)oxc * L);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const f32x4 nx = acc + (wy * wx[k]) * v[k];
+                    acc = wx[k] != 0.f ? nx : acc;
+                }
             }
         }
+        if (post_scale) acc = acc * gs;
         st4(dlogits + ((n * h + iy) * w + ix) * L + 4 * cq, acc);
     }
+}
+// the backward when the forward already left the per-pixel gradient (unit upstream gradient) in the workspace
+static int launch_gather_from_grad(const float* gfull, const float* gscale_dev, float gscale, float* dlogits, int lddl, int N, int h, int w,
+                                   int H, int W, hipStream_t st) {
+    const long long low = (long long)N * h * w * (lddl / 4);
+    long long gb = sh_cdiv(low, 256);
+    if (gb > 16384) gb = 16384;
+    resize_adjoint_gather_kernel<<<(unsigned)gb, 256, 0, st>>>(gfull, dlogits, lddl, h, w, H, W, (float)h / (float)H, (float)w / (float)W, low,
+                                                               gscale_dev, gscale, 1);
+    return sh_launch_status();
 }
 template <int MAXC, int MODE>
 static int launch_loss_bwd_two_pass(const float* logits, int ldl, const uint8_t* labels, const H2Tab& T, int C, const double* sums,
@@ -400,7 +464,7 @@ static int launch_loss_bwd_two_pass(const float* logits, int ldl, const uint8_t*
     if (gb > 16384) gb = 16384;
     loss_grad_fullres_kernel<MAXC, MODE><<<(unsigned)ga, 256, 0, st>>>(logits, ldl, labels, T, C, sums, gscale_dev, gscale, workspace, lddl, h, w,
                                                                         H, W, sy, sx, full);
-    resize_adjoint_gather_kernel<<<(unsigned)gb, 256, 0, st>>>(workspace, dlogits, lddl, h, w, H, W, sy, sx, low);
+    resize_adjoint_gather_kernel<<<(unsigned)gb, 256, 0, st>>>(workspace, dlogits, lddl, h, w, H, W, sy, sx, low, nullptr, 1.f, 0);
     return sh_launch_status();
 }
 extern "C" int64_t sh_loss_bwd_workspace(int N, int H, int W, int lddl) {
@@ -453,9 +517,14 @@ static bool make_tab(H2Tab& T, const int* buckets, int nf, int nc) {
     return true;
 }
 
+// grad_out usable? (forward that also emits the per-pixel gradient for the gather-only backward)
+static bool grad_out_ok(const float* grad_out, int64_t bytes, int ldg, int C, int N, int h, int w, int H, int W) {
+    return grad_out && ldg >= C && ldg <= 32 && (ldg & 3) == 0 && ((uintptr_t)grad_out & 15) == 0 && bytes >= sh_loss_bwd_workspace(N, H, W, ldg) &&
+           (h < H || w < W) && h <= H && w <= W;
+}
 extern "C" int sh_hiera2_loss_fwd(const float* logits, int ldl, const uint8_t* labels, const int* buckets_host, int n_fine,
                                   int n_coarse, double* sums, float* loss_out, float* partials, uint8_t* coarse_out,
-                                  int N, int h, int w, int H, int W, void* stream) {
+                                  int N, int h, int w, int H, int W, float* grad_out, int64_t grad_out_bytes, int ldg, void* stream) {
     H2Tab T;
     if (!logits || !labels || !sums || !loss_out || !partials || N <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SH_EINVAL;
     if (!make_tab(T, buckets_host, n_fine, n_coarse) || ldl < n_fine + n_coarse) return SH_EINVAL;
@@ -464,9 +533,18 @@ extern "C" int sh_hiera2_loss_fwd(const float* logits, int ldl, const uint8_t* l
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
     hipStream_t st = (hipStream_t)stream;
     const int C = n_fine + n_coarse;
-    if (C <= 8) hiera2_fwd_kernel<8><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total);
-    else if (C <= 16) hiera2_fwd_kernel<16><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total);
-    else hiera2_fwd_kernel<32><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total);
+    if (grad_out != nullptr) {
+        if (!grad_out_ok(grad_out, grad_out_bytes, ldg, C, N, h, w, H, W)) return SH_EINVAL;
+        // the gradient's normalisers are label counts: taken first, parked (as integers) where the finalize kernel later writes the same counts
+        unsigned long long* cnt = reinterpret_cast<unsigned long long*>(sums + 4);
+        if (hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned long long), st) != hipSuccess) return SH_ELAUNCH;
+        label_counts_kernel<<<1024, 256, 0, st>>>(labels, T, 1, total, cnt);
+        if (C <= 8 && ldg <= 8) hiera2_fwd_kernel<8, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total, cnt, grad_out, ldg);
+        else if (C <= 16 && ldg <= 16) hiera2_fwd_kernel<16, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total, cnt, grad_out, ldg);
+        else hiera2_fwd_kernel<32, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total, cnt, grad_out, ldg);
+    } else if (C <= 8) hiera2_fwd_kernel<8, false><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total, nullptr, nullptr, 0);
+    else if (C <= 16) hiera2_fwd_kernel<16, false><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total, nullptr, nullptr, 0);
+    else hiera2_fwd_kernel<32, false><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total, nullptr, nullptr, 0);
     int rc = sh_launch_status();
     if (rc != SH_OK) return rc;
     hiera2_finalize_kernel<<<1, 256, 0, st>>>(partials, nblk, (double)total, n_fine, n_coarse, sums, loss_out);
@@ -475,10 +553,15 @@ extern "C" int sh_hiera2_loss_fwd(const float* logits, int ldl, const uint8_t* l
 
 extern "C" int sh_hiera2_loss_bwd(const float* logits, int ldl, const uint8_t* labels, const int* buckets_host, int n_fine,
                                   int n_coarse, const double* sums, const float* gscale_dev, float gscale, float* dlogits,
-                                  int lddl, int N, int h, int w, int H, int W, float* workspace, int64_t workspace_bytes, void* stream) {
+                                  int lddl, int N, int h, int w, int H, int W, float* workspace, int64_t workspace_bytes,
+                                  int workspace_has_grad, void* stream) {
     H2Tab T;
     if (!logits || !labels || !sums || !dlogits || N <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SH_EINVAL;
     if (!make_tab(T, buckets_host, n_fine, n_coarse) || ldl < n_fine + n_coarse || lddl < n_fine + n_coarse || lddl > 32) return SH_EINVAL;
+    if (workspace_has_grad) {
+        if (!grad_out_ok(workspace, workspace_bytes, lddl, n_fine + n_coarse, N, h, w, H, W) || ((uintptr_t)dlogits & 15)) return SH_EINVAL;
+        return launch_gather_from_grad(workspace, gscale_dev, gscale, dlogits, lddl, N, h, w, H, W, (hipStream_t)stream);
+    }
     const long long total = (long long)N * h * w;
     const unsigned nblk = (unsigned)sh_cdiv(total, 256);
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
@@ -508,27 +591,41 @@ extern "C" int sh_hiera2_loss_bwd(const float* logits, int ldl, const uint8_t* l
 }
 
 // ------------------------------------------------------------------------------------------ aux CE (valid-pixel mean)
-template <int MAXC>
+template <int MAXC, bool GRAD>      // GRAD: as hiera2_fwd_kernel (cnt[0] = number of valid pixels)
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, long long ldl, const uint8_t* __restrict__ labels, int C,
-                                                     float* __restrict__ partials, int h, int w, int H, int W, float sy, float sx, long long total) {
+                                                     float* __restrict__ partials, int h, int w, int H, int W, float sy, float sx, long long total,
+                                                     const unsigned long long* __restrict__ cnt, float* __restrict__ gfull, int L) {
     const bool identity = (h == H && w == W);
     float v[2] = {0.f, 0.f};
+    const float b = GRAD ? (float)(1.0 / (double)cnt[0]) : 0.f;          // no valid pixel: inf -> NaN gradient, as the separate backward
     const long long base = (long long)blockIdx.x * LOSS_PIX_PER_BLOCK;
 #pragma unroll 1
     for (int it = 0; it < LOSS_PIX_PER_BLOCK / 256; ++it) {
         const long long i = base + it * 256 + threadIdx.x;
         if (i >= total) break;
         const int f = labels[i];
-        if (f == IGN) continue;
-        const int ox = (int)(i % W);
-        const long long q = i / W;
-        const int oy = (int)(q % H);
-        const long long n = q / H;
-        const Lerp ly = lerp_src(oy, sy, h), lx = lerp_src(ox, sx, w);
-        float z[MAXC], g[MAXC];
-        fetch_logits<MAXC>(logits + n * h * w * ldl, ldl, w, ly, lx, identity, C, z);
-        v[0] += softmax_ce<MAXC, false>(z, 0, C, f, 0.f, g);
-        v[1] += 1.f;
+        float g[MAXC];
+        if (GRAD) {
+#pragma unroll
+            for (int j = 0; j < MAXC; ++j) g[j] = 0.f;
+        }
+        if (f != IGN) {
+            const int ox = (int)(i % W);
+            const long long q = i / W;
+            const int oy = (int)(q % H);
+            const long long n = q / H;
+            const Lerp ly = lerp_src(oy, sy, h), lx = lerp_src(ox, sx, w);
+            float z[MAXC];
+            fetch_logits<MAXC>(logits + n * h * w * ldl, ldl, w, ly, lx, identity, C, z);
+            v[0] += softmax_ce<MAXC, GRAD>(z, 0, C, f, b, g);
+            v[1] += 1.f;
+        }
+        if (GRAD) {
+            float* dst = gfull + i * L;
+#pragma unroll
+            for (int j = 0; j < MAXC; j += 4)
+                if (j < L) st4(dst + j, f32x4{g[j], g[j + 1], g[j + 2], g[j + 3]});
+        }
     }
     block_reduce_store<2>(v, partials);
 }
@@ -595,15 +692,23 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
     }
 }
 extern "C" int sh_ce_loss_fwd(const float* logits, int ldl, const uint8_t* labels, int C, double* sums, float* loss_out,
-                              float* partials, int N, int h, int w, int H, int W, void* stream) {
+                              float* partials, int N, int h, int w, int H, int W, float* grad_out, int64_t grad_out_bytes, int ldg, void* stream) {
     if (!logits || !labels || !sums || !loss_out || !partials || C <= 0 || C > 32 || ldl < C || N <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SH_EINVAL;
     const long long total = (long long)N * H * W;
     const int nblk = (int)sh_cdiv(total, LOSS_PIX_PER_BLOCK);
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
     hipStream_t st = (hipStream_t)stream;
-    if (C <= 8) ce_fwd_kernel<8><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total);
-    else if (C <= 16) ce_fwd_kernel<16><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total);
-    else ce_fwd_kernel<32><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total);
+    if (grad_out != nullptr) {
+        if (!grad_out_ok(grad_out, grad_out_bytes, ldg, C, N, h, w, H, W)) return SH_EINVAL;
+        unsigned long long* cnt = reinterpret_cast<unsigned long long*>(sums + 1);       // see sh_hiera2_loss_fwd
+        if (hipMemsetAsync(cnt, 0, sizeof(unsigned long long), st) != hipSuccess) return SH_ELAUNCH;
+        label_counts_kernel<<<1024, 256, 0, st>>>(labels, H2Tab{}, 0, total, cnt);
+        if (ldg <= 8) ce_fwd_kernel<8, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total, cnt, grad_out, ldg);
+        else if (ldg <= 16) ce_fwd_kernel<16, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total, cnt, grad_out, ldg);
+        else ce_fwd_kernel<32, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total, cnt, grad_out, ldg);
+    } else if (C <= 8) ce_fwd_kernel<8, false><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total, nullptr, nullptr, 0);
+    else if (C <= 16) ce_fwd_kernel<16, false><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total, nullptr, nullptr, 0);
+    else ce_fwd_kernel<32, false><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total, nullptr, nullptr, 0);
     int rc = sh_launch_status();
     if (rc != SH_OK) return rc;
     ce_finalize_kernel<<<1, 256, 0, st>>>(partials, nblk, sums, loss_out);
@@ -611,8 +716,12 @@ extern "C" int sh_ce_loss_fwd(const float* logits, int ldl, const uint8_t* label
 }
 extern "C" int sh_ce_loss_bwd(const float* logits, int ldl, const uint8_t* labels, int C, const double* sums, const float* gscale_dev,
                               float gscale, float* dlogits, int lddl, int N, int h, int w, int H, int W, float* workspace,
-                              int64_t workspace_bytes, void* stream) {
+                              int64_t workspace_bytes, int workspace_has_grad, void* stream) {
     if (!logits || !labels || !sums || !dlogits || C <= 0 || C > 32 || ldl < C || lddl < C || lddl > 32 || N <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SH_EINVAL;
+    if (workspace_has_grad) {
+        if (!grad_out_ok(workspace, workspace_bytes, lddl, C, N, h, w, H, W) || ((uintptr_t)dlogits & 15)) return SH_EINVAL;
+        return launch_gather_from_grad(workspace, gscale_dev, gscale, dlogits, lddl, N, h, w, H, W, (hipStream_t)stream);
+    }
     const long long total = (long long)N * h * w;
     const unsigned nblk = (unsigned)sh_cdiv(total, 4);
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;

@@ -67,7 +67,7 @@ class _CEAllPixFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cls_score, label8):
         logits = ops.to_nhwc(cls_score)
-        _, sums = ops.ce_fwd(logits, label8)
+        _, sums, _ = ops.ce_fwd(logits, label8)
         npix = label8.numel()
         ctx.save_for_backward(logits, label8, sums)
         ctx.npix = npix
@@ -143,7 +143,7 @@ class _Hiera2Fn(torch.autograd.Function):
         logits = ops.to_nhwc(cls_score)
         emb = _dense_nhwc(embedding)
         nf, hidx = mod.num_classes, mod.hiera_index
-        main, sums, _ = ops.hiera2_fwd(logits, label8, nf, hidx)
+        main, sums, _, gw = ops.hiera2_fwd(logits, label8, nf, hidx, want_grad=ctx.needs_input_grad[0])
         masks, ok = mod.triplet_loss_fn.tables(logits.device)
         trip, ws = ops.triplet_fwd(emb, label8, masks, ok, 200, 0.6)
         ready = None
@@ -155,6 +155,7 @@ class _Hiera2Fn(torch.autograd.Function):
         factor = triplet_factor(step, 80000)
         total = ops.combine_loss(main, trip, ready, factor, mod.loss_weight)
         ctx.save_for_backward(logits, emb, label8, sums, trip, ws)
+        ctx.grad_ws = gw            # per-pixel gradient left by the forward (None: the backward recomputes it)
         ctx.ready = ready
         ctx.cfg = (nf, hidx, factor, mod.loss_weight)
         mod.last_terms = (main, trip)
@@ -165,7 +166,8 @@ class _Hiera2Fn(torch.autograd.Function):
         logits, emb, label8, sums, trip, ws = ctx.saved_tensors
         nf, hidx, factor, lw = ctx.cfg
         g = g.reshape(1).float()
-        dlogits = ops.hiera2_bwd(logits, label8, nf, hidx, sums, g, lw) if ctx.needs_input_grad[0] else None
+        dlogits = ops.hiera2_bwd(logits, label8, nf, hidx, sums, g, lw, grad_ws=ctx.grad_ws) if ctx.needs_input_grad[0] else None
+        ctx.grad_ws = None
         demb = None
         if ctx.needs_input_grad[1]:
             gt = g if ctx.ready is None else g * (ctx.ready > 0).float()

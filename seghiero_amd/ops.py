@@ -749,7 +749,9 @@ def bilinear_bwd(dy, h, w):
     n, c, H, W = dy.shape
     dyp, ld = pm(dy)
     dx = new_act(n, c, h, w, dy.device)
-    _call("sh_bilinear_bwd", dyp, ld, dx.data_ptr(), c, n, h, w, H, W, c, _st())
+    need = LIB.raw("sh_bilinear_bwd_workspace")(n, h, w, c)
+    ws = workspace(need, dy.device, "bilinear_bwd")
+    _call("sh_bilinear_bwd", dyp, ld, dx.data_ptr(), c, n, h, w, H, W, c, ws.data_ptr(), need, _st())
     return dx
 
 
@@ -811,8 +813,19 @@ def _buckets(hiera_index):
     return (ctypes.c_int * max(len(flat), 1))(*flat)
 
 
-def hiera2_fwd(logits, labels8, n_fine, hiera_index, want_coarse=False):
-    """-> (loss[1] f32, sums[8] f64, coarse u8 or None)."""
+def _loss_grad_out(want_grad, n, c, h, w, H, W, device):
+    """Buffer for the per-pixel gradient a loss forward leaves for its backward ([N*H*W][pad4(C)] fp32, a fresh tensor: it lives
+    from the forward to the backward of one graph), when the logits are upsampled."""
+    if not (want_grad and LOSS_FWD_GRAD and LOSS_BWD_TWO_PASS) or not (h <= H and w <= W and (h < H or w < W)):
+        return None, 0, 0
+    ldg = pad4(c)
+    need = LIB.raw("sh_loss_bwd_workspace")(n, H, W, ldg)
+    return torch.empty((need // 4,), device=device, dtype=torch.float32), need, ldg
+
+
+def hiera2_fwd(logits, labels8, n_fine, hiera_index, want_coarse=False, want_grad=False):
+    """-> (loss[1] f32, sums[8] f64, coarse u8 or None, grad workspace or None).  want_grad: the same pass leaves the per-pixel
+    gradient for hiera2_bwd(grad_ws=...), which is then only the adjoint of the resize."""
     n, c, h, w = logits.shape
     _, H, W = labels8.shape
     lp, ldl = pm(logits)
@@ -822,13 +835,15 @@ def hiera2_fwd(logits, labels8, n_fine, hiera_index, want_coarse=False):
     sums = torch.empty((8,), device=dev, dtype=torch.float64)
     loss = torch.empty((1,), device=dev, dtype=torch.float32)
     coarse = torch.empty_like(labels8) if want_coarse else None
+    gw, gbytes, ldg = _loss_grad_out(want_grad, n, c, h, w, H, W, dev)
     _call("sh_hiera2_loss_fwd", lp, ldl, labels8.data_ptr(), _buckets(hiera_index), n_fine, len(hiera_index),
           sums.data_ptr(), loss.data_ptr(), partials.data_ptr(), None if coarse is None else coarse.data_ptr(),
-          n, h, w, H, W, _st())
-    return loss, sums, coarse
+          n, h, w, H, W, None if gw is None else gw.data_ptr(), gbytes, ldg, _st())
+    return loss, sums, coarse, gw
 
 
 LOSS_BWD_TWO_PASS = os.environ.get("SEGHIERO_LOSS_TWO_PASS", "1") != "0"
+LOSS_FWD_GRAD = os.environ.get("SEGHIERO_LOSS_FWD_GRAD", "1") != "0"    # the loss forward also emits the per-pixel gradient
 
 
 def _loss_bwd_ws(n, h, w, H, W, ldd, device):
@@ -839,20 +854,24 @@ def _loss_bwd_ws(n, h, w, H, W, ldd, device):
     return workspace(need, device, "lossbwd").data_ptr(), need
 
 
-def hiera2_bwd(logits, labels8, n_fine, hiera_index, sums, gscale_dev, gscale):
+def hiera2_bwd(logits, labels8, n_fine, hiera_index, sums, gscale_dev, gscale, grad_ws=None):
     n, c, h, w = logits.shape
     _, H, W = labels8.shape
     lp, ldl = pm(logits)
     d = new_act(n, c, h, w, logits.device, ld=pad4(c))
     dp, ldd = pm(d)
-    ws, nb = _loss_bwd_ws(n, h, w, H, W, ldd, logits.device)
+    if grad_ws is not None:
+        ws, nb, has = grad_ws.data_ptr(), grad_ws.numel() * 4, 1
+    else:
+        (ws, nb), has = _loss_bwd_ws(n, h, w, H, W, ldd, logits.device), 0
     _call("sh_hiera2_loss_bwd", lp, ldl, labels8.data_ptr(), _buckets(hiera_index), n_fine, len(hiera_index),
           sums.data_ptr(), None if gscale_dev is None else gscale_dev.data_ptr(), float(gscale), dp, ldd,
-          n, h, w, H, W, ws, nb, _st())
+          n, h, w, H, W, ws, nb, has, _st())
     return d
 
 
-def ce_fwd(logits, labels8):
+def ce_fwd(logits, labels8, want_grad=False):
+    """-> (loss[1], sums[2] f64, grad workspace or None); want_grad as hiera2_fwd."""
     n, c, h, w = logits.shape
     _, H, W = labels8.shape
     lp, ldl = pm(logits)
@@ -861,20 +880,24 @@ def ce_fwd(logits, labels8):
     partials = torch.empty((nblk, 8), device=dev, dtype=torch.float32)
     sums = torch.empty((2,), device=dev, dtype=torch.float64)
     loss = torch.empty((1,), device=dev, dtype=torch.float32)
+    gw, gbytes, ldg = _loss_grad_out(want_grad, n, c, h, w, H, W, dev)
     _call("sh_ce_loss_fwd", lp, ldl, labels8.data_ptr(), c, sums.data_ptr(), loss.data_ptr(), partials.data_ptr(),
-          n, h, w, H, W, _st())
-    return loss, sums
+          n, h, w, H, W, None if gw is None else gw.data_ptr(), gbytes, ldg, _st())
+    return loss, sums, gw
 
 
-def ce_bwd(logits, labels8, sums, gscale_dev, gscale):
+def ce_bwd(logits, labels8, sums, gscale_dev, gscale, grad_ws=None):
     n, c, h, w = logits.shape
     _, H, W = labels8.shape
     lp, ldl = pm(logits)
     d = new_act(n, c, h, w, logits.device, ld=pad4(c))
     dp, ldd = pm(d)
-    ws, nb = _loss_bwd_ws(n, h, w, H, W, ldd, logits.device)
+    if grad_ws is not None:
+        ws, nb, has = grad_ws.data_ptr(), grad_ws.numel() * 4, 1
+    else:
+        (ws, nb), has = _loss_bwd_ws(n, h, w, H, W, ldd, logits.device), 0
     _call("sh_ce_loss_bwd", lp, ldl, labels8.data_ptr(), c, sums.data_ptr(),
-          None if gscale_dev is None else gscale_dev.data_ptr(), float(gscale), dp, ldd, n, h, w, H, W, ws, nb, _st())
+          None if gscale_dev is None else gscale_dev.data_ptr(), float(gscale), dp, ldd, n, h, w, H, W, ws, nb, has, _st())
     return d
 
 

@@ -32,14 +32,17 @@ class _AuxCEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, label8):
         lg = ops.to_nhwc(logits)
-        loss, sums = ops.ce_fwd(lg, label8)
+        loss, sums, gw = ops.ce_fwd(lg, label8, want_grad=ctx.needs_input_grad[0])
         ctx.save_for_backward(lg, label8, sums)
+        ctx.grad_ws = gw
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
         lg, label8, sums = ctx.saved_tensors
-        return ops.ce_bwd(lg, label8, sums, g.reshape(1).float(), 1.0), None
+        d = ops.ce_bwd(lg, label8, sums, g.reshape(1).float(), 1.0, grad_ws=ctx.grad_ws)
+        ctx.grad_ws = None
+        return d, None
 
 
 def aux_ce_loss(aux_logits, label):

@@ -44,11 +44,11 @@ def test_coarse_targets_bit_exact_g2(sa, tag):
     l8 = T(g[f"{tag}_lab9"]).to(DEV)
     n, h, w = l8.shape
     z = ops.new_act(n, 13, h, w, DEV, zero=True)
-    _, _, coarse = ops.hiera2_fwd(z, l8, 9, hidx, want_coarse=True)
+    _, _, coarse, _ = ops.hiera2_fwd(z, l8, 9, hidx, want_coarse=True)
     assert np.array_equal(coarse.cpu().numpy(), g[f"{tag}_coarse"])
     lg = T(g["gap_lab"]).to(DEV)
     zg = ops.new_act(1, 7, 16, 16, DEV, zero=True)
-    _, _, cg = ops.hiera2_fwd(zg, lg, 5, [[0, 3], [4, 5]], want_coarse=True)
+    _, _, cg, _ = ops.hiera2_fwd(zg, lg, 5, [[0, 3], [4, 5]], want_coarse=True)
     assert np.array_equal(cg.cpu().numpy(), g["gap_coarse"])
 
 
@@ -81,7 +81,7 @@ def test_hiera_bce_and_ce_g4(sa, tag):
     l8 = T(g[f"{tag}_lab"]).to(DEV)
     # the fused kernel returns hiera + ce_f + ce_c; check the parts through the sums it leaves behind
     zn = ops.to_nhwc(z.detach())
-    total, sums, _ = ops.hiera2_fwd(zn, l8, 4, HIDX2)
+    total, sums, _, _ = ops.hiera2_fwd(zn, l8, 4, HIDX2)
     s = sums.cpu().numpy()
     hiera = 5.0 * (s[0] / (max(s[4], 1) * 4) + s[1] / (max(s[5], 1) * 2))
     close(hiera, g[f"{tag}_hiera"], 1e-5, 0)
@@ -164,6 +164,27 @@ def test_fused_resize_loss_matches_oracle(sa, lo, hi):
     close(eg.grad, er.grad, 1e-4, 1e-8)
 
 
+@pytest.mark.parametrize("lo,hi", [((16, 16), (64, 64)), ((5, 4), (75, 51)), ((32, 32), (128, 128))])
+def test_hiera2_forward_emits_gradient_for_gather_only_backward(sa, lo, hi):
+    """sh_hiera2_loss_fwd with grad_out: same loss / sums bits as the plain forward, and the gather-only backward equals the
+    two-pass backward (full-resolution gradient recomputed, then the same gather) bit for bit at unit upstream gradient; with an
+    upstream gradient != 1 the two differ by one rounding (scale applied after instead of before the sum)."""
+    _, loss, ops = sa
+    g = torch.Generator().manual_seed(lo[0] + hi[1])
+    hidx = [[0, 4], [4, 7], [7, 8], [8, 9]]
+    zn = ops.to_nhwc((1.5 * torch.randn(2, 13, *lo, generator=g)).to(DEV), cpad=16)
+    l8 = ops.labels_u8(_blocky(g, 2, *hi, 9).to(DEV))
+    val, sums, _, none = ops.hiera2_fwd(zn, l8, 9, hidx)
+    val2, sums2, _, gw = ops.hiera2_fwd(zn, l8, 9, hidx, want_grad=True)
+    assert none is None and gw is not None
+    assert torch.equal(val, val2) and torch.equal(sums, sums2)
+    d = ops.hiera2_bwd(zn, l8, 9, hidx, sums, None, 1.0)
+    assert torch.equal(ops.hiera2_bwd(zn, l8, 9, hidx, sums2, None, 1.0, grad_ws=gw), d)
+    gs = torch.tensor([0.37], device=DEV)
+    want = ops.hiera2_bwd(zn, l8, 9, hidx, sums, gs, 2.0)
+    close(ops.hiera2_bwd(zn, l8, 9, hidx, sums2, gs, 2.0, grad_ws=gw), want, 1e-6, 1e-6 * float(want.abs().max()))
+
+
 @pytest.mark.parametrize("lo,hi", [((8, 8), (128, 128)), ((5, 4), (75, 51)), ((16, 16), (16, 16))])
 def test_aux_ce_fused_resize(sa, lo, hi):
     _, loss, ops = sa
@@ -175,10 +196,21 @@ def test_aux_ce_fused_resize(sa, lo, hi):
     ref.backward()
     zn = ops.to_nhwc(z.to(DEV), cpad=12)
     l8 = ops.labels_u8(label.to(DEV))
-    val, sums = ops.ce_fwd(zn, l8)
+    val, sums, _ = ops.ce_fwd(zn, l8)
     close(val[0], ref, 1e-5, 0)
     d = ops.ce_bwd(zn, l8, sums, None, 1.0)
     close(d, zr.grad, 2e-4, 1e-9)
+    # forward that also leaves the per-pixel gradient: same loss bits; the gather-only backward equals the two-pass one bit for bit at
+    # unit upstream gradient and to rounding (one extra multiply) otherwise
+    val2, sums2, gw = ops.ce_fwd(zn, l8, want_grad=True)
+    assert torch.equal(val2, val) and torch.equal(sums2, sums)
+    if lo != hi:
+        assert gw is not None
+        assert torch.equal(ops.ce_bwd(zn, l8, sums2, None, 1.0, grad_ws=gw), d)
+        gs = torch.tensor([0.4], device=DEV)
+        close(ops.ce_bwd(zn, l8, sums2, gs, 1.0, grad_ws=gw), 0.4 * zr.grad, 2e-4, 1e-9)
+    else:
+        assert gw is None
 
 
 def test_pixel_metrics(sa):

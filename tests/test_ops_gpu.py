@@ -196,7 +196,8 @@ def test_conv_reads_and_writes_channel_slices(ops):
 
 
 @pytest.mark.parametrize("shape,dil", [((2, 64, 16, 16), 1), ((2, 64, 16, 16), 12), ((2, 32, 16, 16), 24),
-                                       ((2, 560, 9, 11), 1), ((1, 8, 5, 7), 2), ((2, 72, 16, 24), 1), ((3, 64, 8, 8), 1)])
+                                       ((2, 560, 9, 11), 1), ((1, 8, 5, 7), 2), ((2, 72, 16, 24), 1), ((3, 64, 8, 8), 1),
+                                       ((1, 136, 16, 40), 1)])
 def test_dwconv(ops, shape, dil):
     n, c, h, w = shape
     g = torch.Generator().manual_seed(c + dil)
@@ -223,7 +224,8 @@ def test_dwconv(ops, shape, dil):
     close(dw, wt.grad, 1e-4, 1e-4)
 
 
-@pytest.mark.parametrize("shape,dil", [((2, 64, 16, 16), 1), ((2, 64, 16, 16), 12), ((1, 72, 9, 11), 1), ((2, 128, 24, 16), 1)])
+@pytest.mark.parametrize("shape,dil", [((2, 64, 16, 16), 1), ((2, 64, 16, 16), 12), ((1, 72, 9, 11), 1), ((2, 128, 24, 16), 1),
+                                       ((1, 136, 16, 40), 1)])
 def test_dwconv_fused_batchnorm_hooks(ops, shape, dil):
     """Depthwise conv reading its input through the producer's BatchNorm + ReLU (fprop, wgrad) and emitting the producer's
     BatchNorm-backward statistics + mask from its dgrad epilogue (sep_aspp_contrast_head.py:56-61, 200-203) against torch."""

@@ -1,5 +1,3 @@
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-for s in sep1.pw sep0.pw l2.conv2 l3.conv3 proj; do
-  python tools/bench_conv.py $s 2>&1 | grep -v "amdgpu\|TOTAL"
-  SEGHIERO_LIB=$PWD/seghiero_amd/csrc/alt/libseghiero_ablate.so python tools/bench_conv.py $s 2>&1 | grep -v "amdgpu\|TOTAL" | sed 's/^/   ablateB: /'
-done
+timeout -k 10 900 python -m pytest tests/test_loss_gpu.py tests/test_ops_gpu.py tests/test_model_gpu.py -x -q -m gpu > gpurun_out/gputest_diag17.log 2>&1; echo "tests exit $?"; tail -5 gpurun_out/gputest_diag17.log
+python bench.py --steps 60 --warmup 5 --no-cpu-baseline > gpurun_out/bench_diag17.json 2> gpurun_out/bench_diag17.err; echo "bench exit $?"; cut -c1-300 gpurun_out/bench_diag17.json
