@@ -138,6 +138,20 @@ int sh_conv_dgrad_x6_bnb(const float* dy, int lddy, const float* wt, const float
                          const float* invstd, const float* scale, const float* shift, int relu, float* stat_partials,
                          int N, int H, int W, int Cin, int Cout,
                          int KH, int KW, int stride, int pad, int dil, float* workspace, int64_t workspace_bytes, void* stream);
+/* Deferred BatchNorm-backward apply (1x1, stride 1): the gradient operand dy of a conv -> BN layer's conv is NOT stored; the loaders
+ * evaluate dy = lin[0][c]*g + lin[1][c]*(y - lin[2][c]) + lin[3][c] (= gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)), the second
+ * half of torch.nn.BatchNorm2d's backward, coefficients from sh_bn_bwd_finalize) from the masked gradient g and the raw conv output
+ * y.  Replaces sh_bn_bwd_apply + the dy tensor for Bottleneck conv1 / conv3 (resnet.py via torchvision) and the pointwise convs of
+ * sep_aspp_contrast_head.py:47-61.  dgrad: optional BatchNorm-backward epilogue for the producer of the conv's input as in
+ * sh_conv_dgrad_x6_bnb (y_prev == NULL: plain dx [+ addend]).  wgrad: x optionally through the producer's BatchNorm + ReLU.
+ * SH_EUNSUPPORTED: no instantiation for the geometry -- materialise dy with sh_bn_bwd_apply(relu = 0) on g. */
+int sh_conv_dgrad_x6_lin(const float* g, int ldg, const float* y, int ldy, const float* lin, const float* wt, const float* addend,
+                         int ldadd, float* dx, int lddx, const float* y_prev, int ldyp, const float* mean, const float* invstd,
+                         const float* scale, const float* shift, int relu, float* stat_partials, int N, int H, int W, int Cin,
+                         int Cout, float* workspace, int64_t workspace_bytes, void* stream);
+int sh_conv_wgrad_x6_lin(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* g, int ldg,
+                         const float* y, int ldy, const float* lin, float* dw, float* workspace, int N, int H, int W, int Cin,
+                         int Cout, int KH, int KW, int stride, int pad, int dil, void* stream);
 int64_t sh_conv_wgrad_x6_workspace(int N, int H, int W, int Cin, int Cout, int KH, int KW,
                                    int stride, int pad, int dil);
 int sh_conv_wgrad_x6(const float* x, int ldx, const float* dy, int lddy, float* dw, float* workspace,
@@ -211,7 +225,8 @@ int sh_bn_finalize_sq(const double* sq, int C, const float* gamma, const float* 
                       float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
                       float* scale, float* shift, void* stream);
 int sh_bn_bwd_finalize_sq(const double* local_sq, const double* global_sq, int C, float* dgamma,
-                          float* dbeta, float* c1, float* c2, void* stream);
+                          float* dbeta, float* c1, float* c2, const float* gamma, const float* invstd, const float* mean,
+                          float* lin, void* stream);
 /* Eval-mode coefficients from the running statistics. */
 int sh_bn_eval_coefs(const float* gamma, const float* beta, const float* running_mean,
                      const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
@@ -229,13 +244,16 @@ int sh_bn_act(const float* y, int ldy, const float* scale, const float* shift, c
 /* Backward of the above.  g = dout * mask.  relu = 0: no mask; 1: mask = out > 0 (needed when a residual was added);
  * 2: mask = y*scale+shift > 0, the forward's own arithmetic recomputed from y (no residual) -- `out` is not read, which
  * saves one activation-sized HBM read in each of the two passes.  reduce: partials [n][2][C] of (sum g, sum g*xhat);
- * finalize: dgamma, dbeta; apply: dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)), optionally dres = g. */
+ * finalize: dgamma, dbeta; apply: dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)), optionally dres = g.
+ * Deferred second half: reduce can also STORE g (g_out, 16-byte layouts only, else SH_EUNSUPPORTED) and finalize can emit
+ * lin[4][C] = (A, B, mean, D) with dy = A*g + B*(y - mean) + D; the 1x1 consumers of dy (sh_conv_dgrad_x6_lin,
+ * sh_conv_wgrad_x6_lin) then evaluate dy in their loaders and sh_bn_bwd_apply / the dy tensor are skipped. */
 int sh_bn_bwd_reduce(const float* dout, int lddo, const float* out, int ldo, const float* y, int ldy,
                      const float* mean, const float* invstd, const float* scale, const float* shift,
-                     float* partials, int64_t M, int C, int relu, void* stream);
+                     float* partials, int64_t M, int C, int relu, float* g_out, int ldg, void* stream);
 int sh_bn_bwd_finalize(const float* partials, int n_partials, int C, const float* gamma,
                        const float* invstd, double count, float* dgamma, float* dbeta, float* c1,
-                       float* c2, void* stream);
+                       float* c2, const float* mean, float* lin, void* stream);
 int sh_bn_bwd_apply(const float* dout, int lddo, const float* out, int ldo, const float* y, int ldy,
                     const float* mean, const float* invstd, const float* scale, const float* shift,
                     const float* gamma, const float* c1, const float* c2, float* dy, int lddy, float* dres,

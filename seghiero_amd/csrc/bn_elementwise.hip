@@ -428,7 +428,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partials_v4_kernel(const float* __
                                                                  const float* __restrict__ out, long long ldo,
                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                 float* __restrict__ partials, long long M, int C, int relu) {
+                                                                 float* __restrict__ partials, long long M, int C, int relu,
+                                                                 float* __restrict__ g_out, long long ldg) {
     __shared__ float red[2][16][64];
     const int t = threadIdx.x, cq = t & 15, rl = t >> 4;
     // 1-D grid, channel chunk fastest: blocks that run together read adjacent 256-byte pieces of the same rows
@@ -457,6 +458,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partials_v4_kernel(const float* __
                 }
                 s += g;
                 q += g * ((yv - mu) * is);
+                if (g_out) st4(g_out + r * ldg + c, g);
             }
         }
     }
@@ -475,32 +477,46 @@ __global__ __launch_bounds__(256) void bn_bwd_partials_v4_kernel(const float* __
 }
 extern "C" int sh_bn_bwd_reduce(const float* dout, int lddo, const float* out, int ldo, const float* y, int ldy,
                                 const float* mean, const float* invstd, const float* scale, const float* shift, float* partials,
-                                int64_t M, int C, int relu, void* stream) {
+                                int64_t M, int C, int relu, float* g_out, int ldg, void* stream) {
     if (!dout || !y || !mean || !invstd || !partials || M <= 0 || C <= 0 || lddo < C || ldy < C) return SH_EINVAL;
+    if (g_out && (ldg < C || (ldg & 3) || ((uintptr_t)g_out & 15))) return SH_EINVAL;
     if (relu < 0 || relu > 2 || (relu == 1 && (!out || ldo < C)) || (relu == 2 && (!scale || !shift))) return SH_EINVAL;
     dim3 grid((unsigned)sh_cdiv(M, STAT_ROWS), (unsigned)sh_cdiv(C, 64));
     const bool v4 = (C & 3) == 0 && ((lddo | ldy | (relu == 1 ? ldo : 0)) & 3) == 0 && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
                     (relu != 1 || ((uintptr_t)out & 15) == 0) && ((uintptr_t)mean & 15) == 0 && ((uintptr_t)invstd & 15) == 0 &&
                     (relu != 2 || ((((uintptr_t)scale | (uintptr_t)shift) & 15) == 0));
-    if (v4) bn_bwd_partials_v4_kernel<<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(y, ldy, dout, lddo, out, ldo, mean, invstd, scale, shift, partials, M, C, relu);
+    if (v4) bn_bwd_partials_v4_kernel<<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(y, ldy, dout, lddo, out, ldo, mean, invstd, scale, shift, partials, M, C, relu, g_out, ldg);
+    else if (g_out) return SH_EUNSUPPORTED;          // the masked gradient is written by the 16-byte kernel only
     else channel_partials_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(y, ldy, dout, lddo, out, ldo, mean, invstd, scale, shift, partials, M, C, relu);
     return sh_launch_status();
 }
 
+// The second half of the BatchNorm backward as ONE per-channel linear form in the two tensors it reads,
+//   dy = gamma*invstd*(g - c1 - xhat*c2) = A*g + B*(y - mean) + D,   A = gamma*invstd, B = -A*invstd*c2, D = -A*c1,
+// lin[0..3][C] = (A, B, mean, D): the 1x1 consumers of dy (sh_conv_dgrad_x6_lin, sh_conv_wgrad_x6_lin) evaluate it in their
+// loaders as fma(y - mean, B, fma(g, A, D)) and the sh_bn_bwd_apply pass with its dy tensor disappears.
+__device__ __forceinline__ void bn_bwd_lin(float* lin, int C, int c, float ga, float is, float mu, float c1, float c2) {
+    const float A = ga * is;
+    lin[c] = A; lin[C + c] = -(A * is) * c2; lin[2 * C + c] = mu; lin[3 * C + c] = -A * c1;
+}
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int P, int C,
                                                               const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                                              double count, float* dgamma, float* dbeta, float* c1, float* c2) {
+                                                              double count, float* dgamma, float* dbeta, float* c1, float* c2,
+                                                              const float* __restrict__ mean, float* __restrict__ lin) {
     reduce_partials_4ch(partials, P, C, blockIdx.x * 4, 0, 0, [&](int c, double s, double q) {
         if (dbeta) dbeta[c] = (float)s;
         if (dgamma) dgamma[c] = (float)q;
-        c1[c] = (float)(s / count);
-        c2[c] = (float)(q / count);
+        const float f1 = (float)(s / count), f2 = (float)(q / count);
+        c1[c] = f1;
+        c2[c] = f2;
+        if (lin) bn_bwd_lin(lin, C, c, gamma ? gamma[c] : 1.f, invstd[c], mean[c], f1, f2);
     });
 }
 extern "C" int sh_bn_bwd_finalize(const float* partials, int n_partials, int C, const float* gamma, const float* invstd,
-                                  double count, float* dgamma, float* dbeta, float* c1, float* c2, void* stream) {
-    if (!partials || n_partials <= 0 || C <= 0 || count <= 0 || !c1 || !c2) return SH_EINVAL;
-    bn_bwd_finalize_kernel<<<(unsigned)sh_cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(partials, n_partials, C, gamma, invstd, count, dgamma, dbeta, c1, c2);
+                                  double count, float* dgamma, float* dbeta, float* c1, float* c2, const float* mean, float* lin,
+                                  void* stream) {
+    if (!partials || n_partials <= 0 || C <= 0 || count <= 0 || !c1 || !c2 || (lin && (!mean || !invstd))) return SH_EINVAL;
+    bn_bwd_finalize_kernel<<<(unsigned)sh_cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(partials, n_partials, C, gamma, invstd, count, dgamma, dbeta, c1, c2, mean, lin);
     return sh_launch_status();
 }
 
@@ -667,18 +683,21 @@ extern "C" int sh_bn_finalize_sq(const double* sq, int C, const float* gamma, co
 }
 // dgamma / dbeta from the LOCAL sums (DDP sums them over ranks later), c1 / c2 from the GLOBAL sums and count
 __global__ __launch_bounds__(256) void bn_bwd_finalize_sq_kernel(const double* __restrict__ local_sq, const double* __restrict__ global_sq, int C,
-                                                                 float* dgamma, float* dbeta, float* c1, float* c2) {
+                                                                 float* dgamma, float* dbeta, float* c1, float* c2, const float* gamma,
+                                                                 const float* invstd, const float* mean, float* lin) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     const double count = global_sq[2 * C];
     if (dbeta) dbeta[c] = (float)local_sq[c];
     if (dgamma) dgamma[c] = (float)local_sq[C + c];
-    c1[c] = (float)(global_sq[c] / count);
-    c2[c] = (float)(global_sq[C + c] / count);
+    const float f1 = (float)(global_sq[c] / count), f2 = (float)(global_sq[C + c] / count);
+    c1[c] = f1;
+    c2[c] = f2;
+    if (lin) bn_bwd_lin(lin, C, c, gamma ? gamma[c] : 1.f, invstd[c], mean[c], f1, f2);
 }
 extern "C" int sh_bn_bwd_finalize_sq(const double* local_sq, const double* global_sq, int C, float* dgamma, float* dbeta,
-                                     float* c1, float* c2, void* stream) {
-    if (!local_sq || !global_sq || C <= 0 || !c1 || !c2) return SH_EINVAL;
-    bn_bwd_finalize_sq_kernel<<<(unsigned)sh_cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(local_sq, global_sq, C, dgamma, dbeta, c1, c2);
+                                     float* c1, float* c2, const float* gamma, const float* invstd, const float* mean, float* lin, void* stream) {
+    if (!local_sq || !global_sq || C <= 0 || !c1 || !c2 || (lin && (!mean || !invstd))) return SH_EINVAL;
+    bn_bwd_finalize_sq_kernel<<<(unsigned)sh_cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(local_sq, global_sq, C, dgamma, dbeta, c1, c2, gamma, invstd, mean, lin);
     return sh_launch_status();
 }

@@ -1151,6 +1151,39 @@ extern "C" int sh_conv_dgrad_x6_bnb(const float* dy, int lddy, const float* wt, 
     return rc == SH_X6P_NO ? SH_EUNSUPPORTED : rc;
 }
 
+// 1x1 stride-1 input gradient whose dy operand is NOT stored: dy = lin[0]*g + lin[1]*(y - lin[2]) + lin[3] per output channel (the
+// deferred second half of the conv's own BatchNorm backward, sh_bn_bwd_finalize's lin[4][Cout]) is evaluated in the loader from
+// the masked gradient g and the raw conv output y -- sh_bn_bwd_apply and the dy tensor disappear (Bottleneck conv1 / conv3,
+// models/backbone/resnet.py via torchvision; the pointwise convs of sep_aspp_contrast_head.py:47-61).  Optional BatchNorm-backward
+// epilogue for the PRODUCER of the conv's input exactly as sh_conv_dgrad_x6_bnb (y_prev == NULL: plain dx [+ addend]).
+// SH_EUNSUPPORTED: no instantiation (Cout % 4, extents >= 2 GiB); the caller materialises dy with sh_bn_bwd_apply.
+extern "C" int sh_conv_dgrad_x6_lin(const float* g, int ldg, const float* y, int ldy, const float* lin, const float* wt, const float* addend,
+                                    int ldadd, float* dx, int lddx, const float* y_prev, int ldyp, const float* mean, const float* invstd,
+                                    const float* scale, const float* shift, int relu, float* stat_partials, int N, int H, int W, int Cin,
+                                    int Cout, float* workspace, int64_t workspace_bytes, void* stream) {
+    ConvQ p{};
+    if (!g || !y || !lin || !wt || !dx || !geom(p, N, H, W, Cin, Cout, 1, 1, 1, 0, 1)) return SH_EINVAL;
+    if (ldg < Cout || ldy < Cout || ((ldg | ldy) & 3) || lddx < Cin || (addend && ldadd < Cin)) return SH_EINVAL;
+    if (y_prev && (!mean || !invstd || !scale || !shift || !stat_partials || ldyp < Cin)) return SH_EINVAL;
+    if ((Cout & 3) || (((uintptr_t)g | (uintptr_t)y | (uintptr_t)lin) & 15)) return SH_EUNSUPPORTED;
+    p.a = g; p.lda = ldg; p.a2 = y; p.lda2 = ldy; p.lin = lin;
+    p.b = wt; p.c = dx; p.extra = addend; p.ldadd = ldadd; p.ldc = lddx;
+    p.Nn = Cin; p.Kc = Cout; p.K = Cout; p.M = N * H * W;
+    bool al = (lddx & 3) == 0 && ((uintptr_t)dx & 15) == 0 && (!addend || ((ldadd & 3) == 0 && ((uintptr_t)addend & 15) == 0));
+    if (y_prev) {
+        p.partials = stat_partials; p.n_partials = (int)sh_cdiv(p.M, 64);
+        p.bnb_y = y_prev; p.bnb_ldy = ldyp; p.bnb_mean = mean; p.bnb_invstd = invstd; p.bnb_scale = scale; p.bnb_shift = shift; p.bnb_relu = relu;
+        al = al && (ldyp & 3) == 0 && (((uintptr_t)y_prev | (uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0;
+    }
+    if (al) use_splitk(p, workspace, workspace_bytes);
+    if (!operand_extents(p, DGRAD)) return SH_EUNSUPPORTED;
+    const long long a2 = ((long long)p.M - 1) * ldy + Cout;
+    if (a2 * 4 >= (1ll << 31)) return SH_EUNSUPPORTED;
+    p.a2_bytes = (unsigned)(a2 * 4);
+    const int rc = sh_x6p_launch(DGRAD, p, (hipStream_t)stream);
+    return rc == SH_X6P_NO ? SH_EUNSUPPORTED : rc;
+}
+
 struct WgX6Plan { int wgm, wgn, splits, kchunk, per_xcd; };
 static WgX6Plan wgrad_plan_x6(int Cout, long long Nn, long long npix) {
     WgX6Plan g;
@@ -1216,11 +1249,17 @@ static int launch_wgrad_x6(ConvQ& p, int splits, hipStream_t st) {
     return sh_launch_status();
 }
 static int wgrad_x6_any(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* dy, int lddy, float* dw,
-                        float* workspace, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, void* stream) {
+                        float* workspace, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, void* stream,
+                        const float* y_lin = nullptr, int ldyl = 0, const float* lin = nullptr) {
     ConvQ p{};
     if (!x || !dy || !dw || !workspace || !geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil)) return SH_EINVAL;
     if (lddy < ((Cout + 3) & ~3) || (lddy & 3) || ldx < Cin || (ldx & 3)) return SH_EINVAL;
     p.a = dy; p.b = x; p.c = workspace; p.lda = lddy; p.ldb = ldx;
+    if (lin) {
+        const long long a2 = (((long long)N * p.Ho * p.Wo) - 1) * ldyl + Cout;
+        if ((Cout & 3) || a2 * 4 >= (1ll << 31)) return SH_EUNSUPPORTED;
+        p.a2 = y_lin; p.lda2 = ldyl; p.a2_bytes = (unsigned)(a2 * 4); p.lin = lin;
+    }
     p.M = Cout; p.Nn = KH * KW * Cin; p.K = N * p.Ho * p.Wo;
     p.aff_scale = in_scale; p.aff_shift = in_shift;
     const WgX6Plan g = wgrad_plan_x6(Cout, p.Nn, p.K);
@@ -1234,7 +1273,7 @@ static int wgrad_x6_any(const float* x, int ldx, const float* in_scale, const fl
         rc = sh_x6p_wgrad_launch(p, g.wgm, g.wgn, g.splits, st);
     }
     if (rc == SH_X6P_NO) {
-        if (in_scale) return SH_EUNSUPPORTED;
+        if (in_scale || lin) return SH_EUNSUPPORTED;
         if (g.wgm == 4 && g.wgn == 1) rc = launch_wgrad_x6<4, 1>(p, g.splits, st);
         else if (g.wgm == 2 && g.wgn == 1) rc = launch_wgrad_x6<2, 1>(p, g.splits, st);
         else if (g.wgm == 2 && g.wgn == 4) rc = launch_wgrad_x6<2, 4>(p, g.splits, st);
@@ -1258,4 +1297,13 @@ extern "C" int sh_conv_wgrad_x6_aff(const float* x, int ldx, const float* in_sca
                                     int pad, int dil, void* stream) {
     if (!in_scale || !in_shift || (((uintptr_t)in_scale | (uintptr_t)in_shift) & 15)) return SH_EINVAL;
     return wgrad_x6_any(x, ldx, in_scale, in_shift, dy, lddy, dw, workspace, N, H, W, Cin, Cout, KH, KW, stride, pad, dil, stream);
+}
+// Weight gradient whose dY operand is lin(g, y) (see sh_conv_dgrad_x6_lin), optionally with x read through the producer's BatchNorm +
+// ReLU (in_scale / in_shift, as sh_conv_wgrad_x6_aff).  SH_EUNSUPPORTED: output width < 16, Cout % 4, extents >= 2 GiB.
+extern "C" int sh_conv_wgrad_x6_lin(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* g, int ldg,
+                                    const float* y, int ldy, const float* lin, float* dw, float* workspace, int N, int H, int W, int Cin,
+                                    int Cout, int KH, int KW, int stride, int pad, int dil, void* stream) {
+    if (!y || !lin || ldy < Cout || (ldy & 3) || (((uintptr_t)y | (uintptr_t)lin) & 15)) return SH_EINVAL;
+    if ((in_scale == nullptr) != (in_shift == nullptr) || (((uintptr_t)in_scale | (uintptr_t)in_shift) & 15)) return SH_EINVAL;
+    return wgrad_x6_any(x, ldx, in_scale, in_shift, g, ldg, dw, workspace, N, H, W, Cin, Cout, KH, KW, stride, pad, dil, stream, y, ldy, lin);
 }

@@ -47,6 +47,10 @@ struct ConvQ {
     const float* ga[6]; unsigned ga_bytes[6]; long long glda[6];
     const float* gb[6];
     const float* gsc[6]; const float* gsh[6];
+    // ---- deferred BatchNorm-backward apply (AFF == 2 dgrad loader, LIN wgrad loader): the gradient operand is not stored; it is
+    // lin(g, y) = lin[0][c]*g + lin[1][c]*(y - lin[2][c]) + lin[3][c] of the masked gradient g (p.a) and the raw conv output y (a2)
+    const float* a2; long long lda2; unsigned a2_bytes;
+    const float* lin;       // [4][Kc (dgrad) / M (wgrad)]
     int vec_epi;            // output / addend / bnb_y rows are 16-byte addressable: row-major float4 epilogue through LDS
     unsigned a_bytes, b_bytes;  // extents of the A / B operands for the buffer descriptors (bytes, < 2^31)
 };

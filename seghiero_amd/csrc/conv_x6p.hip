@@ -21,6 +21,9 @@
 //   AFF : A operand = relu(x * scale[c] + shift[c]) applied in the loader -- the producer's train-mode BatchNorm + ReLU
 //         (reference: every conv -> BN -> ReLU -> conv chain, models/backbone/resnet.py:65-73, sep_aspp_contrast_head.py:56-61),
 //         so the activated tensor is never written or re-read; zero padding stays an exact zero AFTER the activation.
+//   AFF == 2 (1x1 dgrad): A operand = lin(g, y) = A[c]*g + B[c]*(y - mean[c]) + D[c] -- the second half of the BatchNorm backward of
+//         the conv's OWN BatchNorm (sh_bn_bwd_apply) evaluated in the loader from the masked gradient g and the raw conv output y,
+//         so the dy tensor is never written or re-read (coefficients: sh_bn_bwd_finalize's lin).
 //   EPI == 1 : fprop epilogue emits the centred BatchNorm (sum, M2) partials per 64 rows (as conv_x6_kernel).
 //   EPI == 2 : dgrad epilogue is the front half of the BatchNorm backward of the producer layer: g = relumask * dx is stored and
 //              (sum g, sum g * xhat) per 64 rows are emitted, so no separate statistics pass reads dx and y again.
@@ -44,7 +47,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const As = smem;
     unsigned char* const Bs = smem + 3 * A_PLANE;
-    float* const coef = reinterpret_cast<float*>(smem + 3 * (A_PLANE + B_PLANE));     // AFF: scale[Kc], shift[Kc]
+    float* const coef = reinterpret_cast<float*>(smem + 3 * (A_PLANE + B_PLANE));     // AFF 1: scale[Kc], shift[Kc]; AFF 2: lin[4][Kc]
+    static_assert(AFF != 2 || (MODE == DGRAD && TAP == 0 && !GRP), "the deferred BatchNorm-backward loader exists for 1x1 dgrads");
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WGN, wn = wave % WGN, l31 = lane & 31, h = lane >> 5;
@@ -87,6 +91,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
     // a whole phase stays one basic block.  (The host side routes tensors of 2 GiB or more to conv_x6_kernel.)
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_ptr), 0, a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b_ptr), 0, p.b_bytes, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrc_a2 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(AFF == 2 ? p.a2 : a_ptr), 0, AFF == 2 ? p.a2_bytes : a_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     const int kc = t & 3, r0 = t >> 2;
     int a_y[NA], a_x[NA], a_nb[NA];
@@ -114,6 +120,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
         b_row[i] = (GRP ? j - grp * p.group_n : j) * (MODE == FPROP ? p.K : p.Kc);
     }
     int a_off[NA];                                               // element offset of the A row for the current tap
+    [[maybe_unused]] int a_off2[NA];                             // ... and of the y row (AFF == 2: its own pixel stride)
     unsigned a_ok[NA];
     auto set_tap = [&](int tap) {
         int kh, kw;
@@ -135,6 +142,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
                 }
                 a_ok[i] = (ok && th < p.Ho && tw < p.Wo) ? ~0u : 0u;
                 a_off[i] = (a_nb[i] + th * p.Wo + tw) * lda;
+                if constexpr (AFF == 2) a_off2[i] = (a_nb[i] + th * p.Wo + tw) * (int)p.lda2;
             }
         }
     };
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
     };
     if constexpr (TAP == 0) { set_tap(0); cur_tap = 0; }
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    struct Regs { f32x4 a[NA]; f32x4 b[NB]; int cc; unsigned okm; };
+    struct Regs { f32x4 a[NA]; f32x4 a2[AFF == 2 ? NA : 1]; f32x4 b[NB]; int cc; unsigned okm; };
     auto load_half = [&](int q, Regs& R) {
         const int kbase = 16 * q, k = kbase + 4 * kc;
         int tap, cc;
@@ -164,6 +172,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
             const unsigned ok = kok & a_ok[i];
             const unsigned voff = (((unsigned)(a_off[i] + cc) * 4u) & ok) | (OOB & ~ok);
             R.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff, 0, 0));
+            if constexpr (AFF == 2) {
+                const unsigned voff2 = (((unsigned)(a_off2[i] + cc) * 4u) & ok) | (OOB & ~ok);
+                R.a2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a2, voff2, 0, 0));
+            }
             if (AFF) R.okm |= ok & (1u << i);
         }
 #pragma unroll
@@ -180,11 +192,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
     auto store_half = [&](Regs& R, int hb) {
         const int off0 = r0 * ROWB + ((((2 * hb) | (kc >> 1)) ^ swz_w) << 4) + ((kc & 1) << 3);
         f32x4 sc = zero4, sh = zero4;
+        [[maybe_unused]] f32x4 lmu = zero4, ld_ = zero4;
         if constexpr (AFF) { sc = *reinterpret_cast<const f32x4*>(coef + R.cc); sh = *reinterpret_cast<const f32x4*>(coef + p.Kc + R.cc); }
+        if constexpr (AFF == 2) { lmu = *reinterpret_cast<const f32x4*>(coef + 2 * p.Kc + R.cc); ld_ = *reinterpret_cast<const f32x4*>(coef + 3 * p.Kc + R.cc); }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             f32x4 v = R.a[i];
-            if constexpr (AFF) {
+            if constexpr (AFF == 2) {
+                // dy = A*g + B*(y - mean) + D (sc = A, sh = B): rows beyond M / the K tail must stay exact zeros (D != 0)
+                const bool ok = (R.okm >> i) & 1u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float w = fmaf(R.a2[i][e] - lmu[e], sh[e], fmaf(v[e], sc[e], ld_[e])); v[e] = ok ? w : 0.f; }
+            } else if constexpr (AFF) {
                 // bn_act_kernel's own operation order (y * scale + shift, then max with 0): the loader sees exactly the values the
                 // separate BatchNorm + ReLU pass would have written; padded taps / rows beyond M stay exact zeros
                 const bool ok = (R.okm >> i) & 1u;
@@ -246,7 +265,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
     // first, then every MFMA carries a few VALU instructions of the split in its issue shadow; the LDS stores, the global loads
     // and the remaining A-fragment reads are spread over the MFMA stream.
     auto phase_schedule = [&]() {
-        constexpr int NMFMA = TM * TN * 6, NVALU = 30 * (NA + NB) + 8 * AFF * NA, NDSW = 3 * (NA + NB), NVM = NA + NB;
+        constexpr int NMFMA = TM * TN * 6, NVALU = 30 * (NA + NB) + (AFF == 2 ? 16 : 8 * AFF) * NA, NDSW = 3 * (NA + NB), NVM = NA + NB + (AFF == 2 ? NA : 0);
         constexpr int VPM = (NVALU + NMFMA - 1) / NMFMA;
         __builtin_amdgcn_sched_group_barrier(0x100, 3 * TN + 3, 0);             // DS read: B fragments + A fragment 0
 #pragma unroll
@@ -259,7 +278,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
         }
     };
     // ------------------------------------------------------------------ prologue
-    if constexpr (AFF) {
+    if constexpr (AFF == 2) {
+        for (int c = t; c < 4 * p.Kc; c += NT) coef[c] = p.lin[c];
+        __syncthreads();
+    } else if constexpr (AFF) {
         for (int c = t; c < p.Kc; c += NT) { coef[c] = sc_ptr ? sc_ptr[c] : 1.f; coef[p.Kc + c] = sh_ptr ? sh_ptr[c] : 0.f; }
         __syncthreads();
     }
@@ -511,7 +533,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
 template <int MODE, int TM, int TN, int WGM, int WGN, int WPS, int AFF, int EPI, int SK, int TAP, int GRP = 0>
 static int launch_x6p(ConvQ& p, hipStream_t st) {
     constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
-    const size_t lds = 3 * (size_t)(BM + BN) * ROWB + (AFF ? 8 * (size_t)p.Kc : 0);
+    const size_t lds = 3 * (size_t)(BM + BN) * ROWB + (AFF == 2 ? 16 : AFF ? 8 : 0) * (size_t)p.Kc;
     if (lds > 160 * 1024) return SH_X6P_NO;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
@@ -533,12 +555,24 @@ static int launch_x6p(ConvQ& p, hipStream_t st) {
 template <int MODE, int AFF, int EPI, int TAP>
 static int pick_tile_x6p(ConvQ& p, hipStream_t st, int force) {
     (void)force;
-    if (p.Nn > 64) return launch_x6p<MODE, 2, 2, 2, 2, 3, AFF, EPI, 0, TAP>(p, st);      // 128 x 128, 4 waves of 64 x 64, 3 blocks per CU
-    return launch_x6p<MODE, 2, 1, 2, 2, 4, AFF, EPI, 0, TAP>(p, st);                     // 128 x 64, 4 blocks per CU
+    // AFF == 2 carries a second A-operand stream (16 more prefetch registers) and the BatchNorm-backward epilogue (EPI == 2) holds a y
+    // tile next to the accumulators: at 3 blocks per CU (168 VGPRs) they spill 15 / 85 registers -- measured slower than 2 blocks per CU
+    // without spills (AFF == 2: 7.65 vs 6.27 ms per step; EPI == 2: step 35.30 vs 35.07 ms)
+    constexpr int W1 = (AFF == 2 || EPI == 2) ? 2 : 3, W2 = (AFF == 2 || EPI == 2) ? 3 : 4;
+    if (p.Nn > 64) return launch_x6p<MODE, 2, 2, 2, 2, W1, AFF, EPI, 0, TAP>(p, st);     // 128 x 128, 4 waves of 64 x 64, 3 blocks per CU
+    return launch_x6p<MODE, 2, 1, 2, 2, W2, AFF, EPI, 0, TAP>(p, st);                    // 128 x 64, 4 blocks per CU
 }
 
 template <int MODE, int AFF, int EPI>
 static int pick_x6p(ConvQ& p, hipStream_t st, int force) {
+    if constexpr (AFF == 2) {    // deferred BatchNorm-backward loader: 1x1 only
+        if (p.KH * p.KW != 1) return SH_X6P_NO;
+        if (p.ksplit > 1) {
+            const int rc = launch_x6p<MODE, 2, 2, 2, 2, 2, 2, 0, 1, 0>(p, st);
+            return rc == SH_OK ? sh_x6_splitk_reduce(p, MODE, st) : rc;
+        }
+        return pick_tile_x6p<MODE, 2, EPI, 0>(p, st, force);
+    } else {
     if (p.ksplit > 1) {          // K slices (mid-network shapes with an under-filled grid): 128 x 128 tiles into slabs, then the reduce
         int rc;
         if (p.KH * p.KW == 1) rc = launch_x6p<MODE, 2, 2, 2, 2, 3, AFF, 0, 1, 0>(p, st);
@@ -550,6 +584,7 @@ static int pick_x6p(ConvQ& p, hipStream_t st, int force) {
     if ((p.Kc & 15) == 0) return pick_tile_x6p<MODE, AFF, EPI, 1>(p, st, force);
     if (AFF || EPI == 2) return SH_X6P_NO;
     return pick_tile_x6p<MODE, 0, EPI, 2>(p, st, force);
+    }
 }
 
 static int x6p_mode() { static int v = -2; if (v == -2) { const char* e = getenv("SEGHIERO_X6P"); v = e ? atoi(e) : 1; } return v; }
@@ -568,7 +603,7 @@ int sh_x6p_grouped_launch(ConvQ& p, hipStream_t st) {
 // Entry used by sh_conv_fprop_x6 / sh_conv_dgrad_x6: SH_X6P_NO = shape not handled here (the caller falls back to conv_x6_kernel)
 int sh_x6p_launch(int mode, ConvQ& p, hipStream_t st) {
     const bool aff = p.aff_scale != nullptr, bnb = p.bnb_y != nullptr;
-    if (!x6p_mode() && !aff && !bnb) return SH_X6P_NO;
+    if (!x6p_mode() && !aff && !bnb && !p.lin) return SH_X6P_NO;
     const int force = x6p_tile();
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     p.vec_epi = !p.parity && !p.scatter && (p.Nn & 3) == 0 && (p.ldc & 3) == 0 && al16(p.c) &&
@@ -583,6 +618,7 @@ int sh_x6p_launch(int mode, ConvQ& p, hipStream_t st) {
         return pick_x6p<FPROP, 0, 1>(p, st, force);
     }
     if (aff) return SH_EINVAL;
+    if (p.lin != nullptr) return bnb ? pick_x6p<DGRAD, 2, 2>(p, st, force) : pick_x6p<DGRAD, 2, 0>(p, st, force);
     if (bnb) return pick_x6p<DGRAD, 0, 2>(p, st, force);
     return pick_x6p<DGRAD, 0, 0>(p, st, force);
 }
@@ -594,7 +630,10 @@ int sh_x6p_launch(int mode, ConvQ& p, hipStream_t st) {
 // half-tile j, one barrier.  AFF: the X operand is relu(x * scale[c] + shift[c]) of the stored tensor (the producer's train-mode
 // BatchNorm + ReLU, applied in the loader; see AFF above) -- each thread owns one 4-channel chunk, so its coefficients sit in
 // registers for the whole kernel.
-template <int WGM, int WGN, int AFF>
+// LIN: the dY operand is lin(g, y) = A[co]*g + B[co]*(y - mean[co]) + D[co] of the masked gradient g (p.a) and the raw conv output y
+// (p.a2) -- the deferred second half of this conv's own BatchNorm backward (see AFF == 2 above); a thread owns one 4-channel chunk
+// of co for the whole kernel, so the four coefficient vectors sit in registers.
+template <int WGM, int WGN, int AFF, int LIN = 0>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_x6p_kernel(const ConvQ p) {
     constexpr int NT = 64 * WGM * WGN, BM = 64 * WGM, BN = 64 * WGN;
     constexpr int AROWB = 2 * BM + 64, BROWB = 2 * BN + 64;
@@ -620,6 +659,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_x6p_kernel(const
 
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, p.b_bytes, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrc_a2 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(LIN ? p.a2 : p.a), 0, LIN ? p.a2_bytes : p.a_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     const int arc = t % ACPR, ak0 = t / ACPR;
     const int brc = t % BCPR, bk0 = t / BCPR;
@@ -631,6 +672,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_x6p_kernel(const
     const int wg_dh = kh * p.dil - p.pad, wg_dw = kw * p.dil - p.pad;
     f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
     if constexpr (AFF) { if (b_col_ok) { sc = ld4(p.aff_scale + wg_ci); sh = ld4(p.aff_shift + wg_ci); } }
+    [[maybe_unused]] f32x4 lA = sc, lB = sc, lM = sc, lD = sc;
+    if constexpr (LIN) { lA = lB = lM = lD = f32x4{0.f, 0.f, 0.f, 0.f}; if (a_col_ok) { lA = ld4(p.lin + co); lB = ld4(p.lin + p.M + co); lM = ld4(p.lin + 2 * p.M + co); lD = ld4(p.lin + 3 * p.M + co); } }
     // pixel coordinates of this thread's B k-rows for the NEXT half-tile to load, advanced by 16 pixels per load (Wo >= 16 on
     // this path, so a step wraps at most one image row and one image: compare + select, no loops, no divisions)
     int px_ow[NB], px_oh[NB], px_n[NB];
@@ -639,16 +682,21 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_x6p_kernel(const
         const int pix = kbeg + bk0 + BKPP * i;
         px_ow[i] = pix % p.Wo; const int q2 = pix / p.Wo; px_oh[i] = q2 % p.Ho; px_n[i] = q2 / p.Ho;
     }
-    struct Regs { f32x4 a[NA]; f32x4 b[NB]; unsigned okm; };
+    struct Regs { f32x4 a[NA]; f32x4 a2[LIN ? NA : 1]; f32x4 b[NB]; unsigned okm, okl; };
     auto load_half = [&](int q, Regs& R) {
         const int kbase = kbeg + 16 * q;
-        R.okm = 0;
+        R.okm = 0; R.okl = 0;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int pix = kbase + ak0 + AKPP * i;
             const unsigned ok = (unsigned)((pix - kend) >> 31) & a_col_ok;
             const unsigned voff = (((unsigned)(pix * (int)p.lda + co) * 4u) & ok) | (OOB & ~ok);
             R.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff, 0, 0));
+            if constexpr (LIN) {
+                const unsigned voff2 = (((unsigned)(pix * (int)p.lda2 + co) * 4u) & ok) | (OOB & ~ok);
+                R.a2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a2, voff2, 0, 0));
+                R.okl |= ok & (1u << i);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -670,7 +718,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_x6p_kernel(const
         for (int i = 0; i < NA; ++i) {
             const int off = (16 * hb + ak0 + AKPP * i) * AROWB + arc * 8;
             u32x2 q1, q2, q3;
-            split4(R.a[i], q1, q2, q3);
+            f32x4 va = R.a[i];
+            if constexpr (LIN) {      // pixels beyond the K slice stay exact zeros (D != 0)
+                const bool ok = (R.okl >> i) & 1u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float w = fmaf(R.a2[i][e] - lM[e], lB[e], fmaf(va[e], lA[e], lD[e])); va[e] = ok ? w : 0.f; }
+            }
+            split4(va, q1, q2, q3);
             *reinterpret_cast<u32x2*>(As + off) = q1;
             *reinterpret_cast<u32x2*>(As + APLANE + off) = q2;
             *reinterpret_cast<u32x2*>(As + 2 * APLANE + off) = q3;
@@ -724,7 +778,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_x6p_kernel(const
             for (int j = 0; j < 2; ++j) acc[i][j] = mma6(af[i], bfr[j], acc[i][j]);
     };
     auto phase_schedule = [&]() {
-        constexpr int NVALU = (30 + 8 * AFF) * NB + 30 * NA + 8 * NB, NDSW = 3 * (NA + NB), NVM = NA + NB;
+        constexpr int NVALU = (30 + 8 * AFF) * NB + (30 + 16 * LIN) * NA + 8 * NB, NDSW = 3 * (NA + NB), NVM = NA + NB + LIN * NA;
         constexpr int VPM = (NVALU + 23) / 24;
         __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);                     // DS read: first A / B fragment pairs
 #pragma unroll
@@ -767,33 +821,34 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_x6p_kernel(const
             }
         }
 }
-template <int WGM, int WGN, int AFF>
+template <int WGM, int WGN, int AFF, int LIN = 0>
 static int launch_wgrad_x6p(ConvQ& p, int splits, hipStream_t st) {
     constexpr size_t lds = 3 * 32 * (size_t)((2 * 64 * WGM + 64) + (2 * 64 * WGN + 64));
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x6p_kernel<WGM, WGN, AFF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x6p_kernel<WGM, WGN, AFF, LIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     p.tiles_m = (int)sh_cdiv(p.M, 64 * WGM); p.tiles_n = (int)sh_cdiv(p.Nn, 64 * WGN);
     p.ksplit = splits;
     const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n) * (unsigned)(p.scatter ? sh_cdiv(splits, 8) * 8 : splits);
-    conv_wgrad_x6p_kernel<WGM, WGN, AFF><<<grid, 64 * WGM * WGN, lds, st>>>(p);
+    conv_wgrad_x6p_kernel<WGM, WGN, AFF, LIN><<<grid, 64 * WGM * WGN, lds, st>>>(p);
     return sh_launch_status();
 }
-template <int AFF>
+template <int AFF, int LIN = 0>
 static int pick_wgrad_x6p(ConvQ& p, int wgm, int wgn, int splits, hipStream_t st) {
-    if (wgm == 4 && wgn == 1) return launch_wgrad_x6p<4, 1, AFF>(p, splits, st);
-    if (wgm == 2 && wgn == 1) return launch_wgrad_x6p<2, 1, AFF>(p, splits, st);
-    if (wgm == 2 && wgn == 4) return launch_wgrad_x6p<2, 4, AFF>(p, splits, st);
-    if (wgm == 1 && wgn == 4) return launch_wgrad_x6p<1, 4, AFF>(p, splits, st);
-    if (wgm == 1 && wgn == 2) return launch_wgrad_x6p<1, 2, AFF>(p, splits, st);
-    return launch_wgrad_x6p<2, 2, AFF>(p, splits, st);
+    if (wgm == 4 && wgn == 1) return launch_wgrad_x6p<4, 1, AFF, LIN>(p, splits, st);
+    if (wgm == 2 && wgn == 1) return launch_wgrad_x6p<2, 1, AFF, LIN>(p, splits, st);
+    if (wgm == 2 && wgn == 4) return launch_wgrad_x6p<2, 4, AFF, LIN>(p, splits, st);
+    if (wgm == 1 && wgn == 4) return launch_wgrad_x6p<1, 4, AFF, LIN>(p, splits, st);
+    if (wgm == 1 && wgn == 2) return launch_wgrad_x6p<1, 2, AFF, LIN>(p, splits, st);
+    return launch_wgrad_x6p<2, 2, AFF, LIN>(p, splits, st);
 }
 // Entry used by sh_conv_wgrad_x6 (same tile / K-slice plan as conv_wgrad_x6_kernel; the slab reduce stays with the caller)
 int sh_x6p_wgrad_launch(ConvQ& p, int wgm, int wgn, int splits, hipStream_t st) {
     const bool aff = p.aff_scale != nullptr;
-    if (!x6p_mode() && !aff) return SH_X6P_NO;
+    if (!x6p_mode() && !aff && !p.lin) return SH_X6P_NO;
     if (p.Wo < 16 || (p.Cin & 3)) return SH_X6P_NO;
+    if (p.lin != nullptr) return aff ? pick_wgrad_x6p<1, 1>(p, wgm, wgn, splits, st) : pick_wgrad_x6p<0, 1>(p, wgm, wgn, splits, st);
     return aff ? pick_wgrad_x6p<1>(p, wgm, wgn, splits, st) : pick_wgrad_x6p<0>(p, wgm, wgn, splits, st);
 }

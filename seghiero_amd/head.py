@@ -218,7 +218,7 @@ class _HeadFn(torch.autograd.Function):
             part = ops.channel_stats(dl)
             red = torch.empty((4, C), device=dl.device, dtype=torch.float32)
             ops._call("sh_bn_bwd_finalize", part.data_ptr(), part.shape[0], C, None, None, 1.0, red[0].data_ptr(),
-                      red[1].data_ptr(), red[2].data_ptr(), red[3].data_ptr(), ops._st())
+                      red[1].data_ptr(), red[2].data_ptr(), red[3].data_ptr(), None, None, ops._st())
             gm.put(mod.cls_seg.bias, red[1])              # "dbeta" slot = sum over pixels of dlogits
             for j in range(len(mod.sep_bottleneck) - 1, -1, -1):
                 ds = mod.sep_bottleneck[j]

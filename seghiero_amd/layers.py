@@ -118,6 +118,9 @@ def _fprop(x, weight, bias, y, partials, s, p, d):
 
 
 def _wgrad(x, dy, dw, s, p, d):
+    """dy: tensor or ops.DeferredDy (cba_bwd defers only where ops.lin_ok holds; the x-through-BatchNorm loader composes with it)."""
+    if isinstance(dy, ops.DeferredDy) and isinstance(x, Lazy) and not (x._out is None and ops.wgrad_aff_ok(x.y, dw, s, p, d)):
+        dy = dy.materialize()
     if isinstance(x, Lazy):
         if x._out is None and ops.wgrad_aff_ok(x.y, dw, s, p, d):
             ops.conv_wgrad(x.y, dy, dw, s, p, d, side=True, aff=x.coefs)
@@ -131,6 +134,19 @@ def _dgrad(rec_x, dy, weight, s, p, d, addend=None, pack_for=None):
     BatchNorm backward (-> GradPack); otherwise a plain tensor.  pack_for: the CBARec of the residual block whose OUTPUT is this
     conv's input (out = relu(bn(y) + identity)): the same fusion with the mask taken from `out`."""
     n, c, h, w = rec_x.shape
+    if isinstance(dy, ops.DeferredDy):
+        dd, dev = dy, dy.g.device
+        if pack_for is None:
+            if isinstance(rec_x, Lazy) and FUSE_BN:
+                g = ops.new_act(n, c, h, w, dev)
+                partials = torch.empty((-(-n * h * w // 64), 2, c), device=dev, dtype=torch.float32)
+                if ops.conv_dgrad_lin(dd, weight, g, addend=addend, bnb=(rec_x.y, rec_x.coefs, partials)):
+                    return GradPack(g, partials)
+            elif not isinstance(rec_x, Lazy):
+                dx = ops.new_act(n, c, h, w, dev)
+                if ops.conv_dgrad_lin(dd, weight, dx, addend=addend):
+                    return dx
+        dy = dd.materialize()
     dev = dy.device
     if pack_for is not None and FUSE_BN and not isinstance(rec_x, Lazy):
         g = ops.new_act(n, c, h, w, dev)
@@ -206,8 +222,10 @@ def cba_bwd(rec, bn, dout, need_dx=True, addend=None, want_dres=False, scatter_i
     # ReLU mask: from `out` only where a residual was added; otherwise recomputed from y (one activation read less).
     # dout may be a GradPack (mask applied, statistics partials done by the consumer's dgrad epilogue).
     mode = 0 if not rec.relu else (1 if rec.has_res else 2)
+    # second half of the BatchNorm backward in the loaders of this conv's dgrad / wgrad (1x1 convs): no apply pass, no dy tensor
+    defer = FUSE_BN and scatter_into is None and pack_for is None and ops.lin_ok(rec.x.shape, rec.weight, s, p, d)
     dy, dgamma, dbeta, dres = ops.bn_backward(dout, rec.out if mode == 1 else None, rec.y, rec.coefs, bn.weight,
-                                              mode, want_dres)
+                                              mode, want_dres, defer=defer)
     dw = new_grad(rec.weight)
     if not ops.WGRAD_AFTER_DGRAD:
         _wgrad(rec.x, dy, dw, s, p, d)

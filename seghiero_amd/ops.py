@@ -335,6 +335,31 @@ def conv_dgrad_bnb(dy, weight, g, y_prev, coefs, relu, partials, stride, pad, di
                        key=_ckey(n, h, w, cin, o, kh, stride, dil))
 
 
+def conv_dgrad_lin(dd, weight, dx, addend=None, bnb=None):
+    """1x1 stride-1 input gradient with the dy operand evaluated in the loader from a DeferredDy.  bnb = (y_prev, coefs, partials):
+    BatchNorm-backward epilogue for the producer of the conv's input (as conv_dgrad_bnb; dx then receives g).  -> False when the
+    geometry has no fused kernel (the caller materialises dy)."""
+    if CONV_IMPL != "x6":
+        return False
+    n, cin, h, w = dx.shape
+    o = weight.shape[0]
+    gp, ldg = pm(dd.g)
+    yp, ldy = pm(dd.y)
+    dxp, lddx = pm(dx)
+    ap, lda = (None, 0) if addend is None else pm(addend)
+    if bnb is None:
+        bargs = (None, 0, None, None, None, None, 0, None)
+    else:
+        y_prev, cf, partials = bnb
+        ypp, ldyp = pm(y_prev)
+        bargs = (ypp, ldyp, cf[0].data_ptr(), cf[1].data_ptr(), cf[2].data_ptr(), cf[3].data_ptr(), 1, partials.data_ptr())
+    m = n * h * w
+    cost = (2.0 * m * o * cin, 4.0 * (m * cin * (1 + (addend is not None) + (bnb is not None)) + 2 * m * o + o * cin))
+    ws, nb = _splitk_ws(1, n, h, w, cin, o, 1, 1, 1, 0, 1, 0, dx.device)
+    return _call_fused("sh_conv_dgrad_x6_lin", gp, ldg, yp, ldy, dd.lin.data_ptr(), weight_transpose(weight).data_ptr(), ap, lda, dxp, lddx,
+                       *bargs, n, h, w, cin, o, ws, nb, _st(), cost=cost, key=_ckey(n, h, w, cin, o, 1, 1, 1))
+
+
 _WS = {}
 
 
@@ -403,9 +428,12 @@ def conv_wgrad(x, dy, dweight, stride, pad, dil, side=False, aff=None):
     output and the loader applies relu(x * scale + shift) (check wgrad_aff_ok first)."""
     n, cin, h, w = x.shape
     o, _, kh, kw = dweight.shape
+    dd = dy if isinstance(dy, DeferredDy) else None          # dy evaluated in the loader (check lin_ok before deferring)
+    if dd is not None:
+        dy = dd.g
     # tiny output-channel counts (cls_seg, aux head) stay on the f32-MFMA kernel
     x6 = CONV_IMPL == "x6" and o >= 32 and (cin * kh * kw >= 128 or (cin * kh * kw == 64 and o >= 128))
-    if aff is not None:
+    if aff is not None or dd is not None:
         x6 = True
     need = LIB.raw("sh_conv_wgrad_x6_workspace" if x6 else "sh_conv_wgrad_workspace")(n, h, w, cin, o, kh, kw, stride, pad, dil)
     if need < 0:
@@ -419,6 +447,13 @@ def conv_wgrad(x, dy, dweight, stride, pad, dil, side=False, aff=None):
 
     def launch(tag="wgrad"):
         ws = workspace(need, x.device, tag)              # one workspace per stream: its kernels stay in that stream's order
+        if dd is not None:
+            y2p, ldy2 = pm(dd.y)
+            if not _call_fused("sh_conv_wgrad_x6_lin", xp, ldx, None if aff is None else aff[2].data_ptr(), None if aff is None else aff[3].data_ptr(),
+                               dyp, lddy, y2p, ldy2, dd.lin.data_ptr(), dweight.data_ptr(), ws.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil,
+                               _st(), cost=cost, key=_ckey(n, h, w, cin, o, kh, stride, dil)):
+                raise SegHieroHipError("sh_conv_wgrad_x6_lin: unsupported geometry (check lin_ok before deferring the BatchNorm-backward apply)")
+            return
         if aff is not None:
             if not _call_fused("sh_conv_wgrad_x6_aff", xp, ldx, aff[2].data_ptr(), aff[3].data_ptr(), dyp, lddy, dweight.data_ptr(),
                                ws.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, _st(), cost=cost,
@@ -435,7 +470,7 @@ def conv_wgrad(x, dy, dweight, stride, pad, dil, side=False, aff=None):
     st.wait_stream(torch.cuda.current_stream(x.device))     # dy / x were produced on the compute stream
     with torch.cuda.stream(st):
         launch("wgrad%d" % k)
-    for t in (x, dy, dweight):
+    for t in (x, dy, dweight) + (() if dd is None else (dd.y, dd.lin)):
         t.record_stream(st)                                 # the allocator must not recycle them under the side stream
 
 
@@ -636,10 +671,57 @@ def bn_act(y, coefs, out, relu, residual=None, res_coefs=None):
           op, ldo, n * h * w, c, int(relu), _st())
 
 
-def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None):
+class DeferredDy:
+    """Gradient w.r.t. a raw conv output, NOT materialised: dy = lin[0]*g + lin[1]*(y - lin[2]) + lin[3] per channel (the second half
+    of the BatchNorm backward) of the masked gradient g and the raw conv output y.  The 1x1 consumers evaluate it in their loaders
+    (conv_dgrad_lin, conv_wgrad(dy=DeferredDy)); materialize() runs the sh_bn_bwd_apply pass for anything else."""
+    __slots__ = ("g", "y", "lin", "coefs", "gamma", "red", "_dy")
+
+    def __init__(self, g, y, lin, coefs, gamma, red):
+        self.g, self.y, self.lin, self.coefs, self.gamma, self.red, self._dy = g, y, lin, coefs, gamma, red, None
+
+    @property
+    def shape(self):
+        return self.y.shape
+
+    def materialize(self):
+        if self._dy is None:
+            n, c, h, w = self.y.shape
+            ld = pad4(c)
+            dy = new_act(n, c, h, w, self.y.device, ld=ld, zero=ld != c)
+            gp, ldg = pm(self.g)
+            yp, ldy = pm(self.y)
+            dyp, lddy = pm(dy)
+            cf = self.coefs
+            _call("sh_bn_bwd_apply", gp, ldg, None, 0, yp, ldy, cf[0].data_ptr(), cf[1].data_ptr(), cf[2].data_ptr(), cf[3].data_ptr(),
+                  None if self.gamma is None else self.gamma.data_ptr(), self.red[2].data_ptr(), self.red[3].data_ptr(), dyp, lddy,
+                  None, 0, n * h * w, c, 0, _st())
+            self._dy = dy
+        return self._dy
+
+
+DEFER_APPLY = os.environ.get("SEGHIERO_DEFER_APPLY", "1") != "0"     # BatchNorm-backward apply in the 1x1 consumers' loaders
+# The dgrad re-evaluates dy once per 128-column tile of its OUTPUT (Cin / 128 times), the apply pass once: deferring pays where the
+# dy tensor is wide and the dgrad output narrow (Bottleneck conv3: 4P -> P), not the other way round (conv1: P -> 4P)
+DEFER_RATIO = float(os.environ.get("SEGHIERO_DEFER_RATIO", "1"))
+
+
+def lin_ok(x_shape, weight, stride, pad, dil):
+    """Can the dgrad AND the wgrad of this conv read their dy operand as a DeferredDy?  (x6 kernels, 1x1 stride 1, 16-byte channel
+    counts, output width >= 16 for the pipelined wgrad, operands below the 2 GiB buffer-descriptor range)"""
+    n, cin, h, w = x_shape
+    o, _, kh, kw = weight.shape
+    return (DEFER_APPLY and CONV_IMPL == "x6" and kh == 1 and kw == 1 and stride == 1 and pad == 0 and o % 4 == 0 and cin % 4 == 0
+            and o >= 32 and cin >= 64 and w >= 16 and n * h * w * max(pad4(o), pad4(cin)) * 4 < (1 << 31)
+            and o * DEFER_RATIO >= cin)
+
+
+def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None, defer=False):
     """-> (dy, dgamma, dbeta, dres).  relu: 0 none, 1 mask from `out` (residual blocks), 2 mask recomputed from y and
     the forward coefficients (out may be None).  dout may be a layers.GradPack: the ReLU mask is already applied and the
-    (sum g, sum g*xhat) partials were produced by the consumer's dgrad epilogue, so the statistics pass is skipped."""
+    (sum g, sum g*xhat) partials were produced by the consumer's dgrad epilogue, so the statistics pass is skipped.
+    defer=True: dy is returned as a DeferredDy (no apply pass, no dy tensor) -- the statistics pass then also stores the masked
+    gradient g where a mask applies."""
     relu = int(relu)
     if relu == 2:
         out = None
@@ -657,18 +739,38 @@ def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None):
         dop, lddo = pm(dout)
         p = LIB.raw("sh_stats_partials_count")(m)
         partials = torch.empty((p, 2, c), device=dev, dtype=torch.float32)
-        _call("sh_bn_bwd_reduce", dop, lddo, op, ldo, yp, ldy, coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(),
-              coefs[3].data_ptr(), partials.data_ptr(), m, c, relu, _st())
+        gmask = None
+        if defer and relu:
+            gmask = new_act(n, c, h, w, dev)
+            if not _call_fused("sh_bn_bwd_reduce", dop, lddo, op, ldo, yp, ldy, coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(),
+                               coefs[3].data_ptr(), partials.data_ptr(), m, c, relu, gmask.data_ptr(), c, _st()):
+                gmask, defer = None, False
+        if gmask is None:
+            _call("sh_bn_bwd_reduce", dop, lddo, op, ldo, yp, ldy, coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(),
+                  coefs[3].data_ptr(), partials.data_ptr(), m, c, relu, None, 0, _st())
+        else:
+            dout, relu, op, ldo = gmask, 0, None, 0          # from here on as a packed gradient: mask applied
+            dop, lddo = pm(dout)
+            packed = True
+    if defer and (lddo % 4 or dop % 16 or c % 4):
+        defer = False
     red = torch.empty((4, c), device=dev, dtype=torch.float32)           # dgamma, dbeta, c1, c2
+    lin = torch.empty((4, c), device=dev, dtype=torch.float32) if defer else None
+    linp = None if lin is None else lin.data_ptr()
     if _sync_on():
         local = torch.empty((2 * c + 1,), device=dev, dtype=torch.float64)
         _call("sh_bn_reduce_partials", partials.data_ptr(), p, c, float(m), 0, local.data_ptr(), _st())
         glob = _all_reduce_sq(local.clone())
         _call("sh_bn_bwd_finalize_sq", local.data_ptr(), glob.data_ptr(), c,
-              red[0].data_ptr(), red[1].data_ptr(), red[2].data_ptr(), red[3].data_ptr(), _st())
+              red[0].data_ptr(), red[1].data_ptr(), red[2].data_ptr(), red[3].data_ptr(),
+              None if gamma is None else gamma.data_ptr(), coefs[1].data_ptr(), coefs[0].data_ptr(), linp, _st())
     else:
         _call("sh_bn_bwd_finalize", partials.data_ptr(), p, c, None if gamma is None else gamma.data_ptr(),
-              coefs[1].data_ptr(), float(m), red[0].data_ptr(), red[1].data_ptr(), red[2].data_ptr(), red[3].data_ptr(), _st())
+              coefs[1].data_ptr(), float(m), red[0].data_ptr(), red[1].data_ptr(), red[2].data_ptr(), red[3].data_ptr(),
+              coefs[0].data_ptr(), linp, _st())
+    if defer:
+        # relu == 0 here: dout is the masked gradient (packed, or stored by the statistics pass), or no mask applies
+        return DeferredDy(dout, y, lin, coefs, gamma, red), red[0], red[1], (dout if want_dres else None)
     ld = pad4(c) if dy_ld is None else dy_ld
     dy = new_act(n, c, h, w, dev, ld=ld, zero=ld != c)
     dres = None

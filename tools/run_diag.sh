@@ -1,3 +1,6 @@
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_loss_gpu.py tests/test_ops_gpu.py tests/test_model_gpu.py -x -q -m gpu > gpurun_out/gputest_diag17.log 2>&1; echo "tests exit $?"; tail -5 gpurun_out/gputest_diag17.log
-python bench.py --steps 60 --warmup 5 --no-cpu-baseline > gpurun_out/bench_diag17.json 2> gpurun_out/bench_diag17.err; echo "bench exit $?"; cut -c1-300 gpurun_out/bench_diag17.json
+for i in 1 2; do
+for r in 1 1000 0.5 2; do
+SEGHIERO_DEFER_RATIO=$r python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-units 2>/dev/null | cut -c1-200 | sed "s/^/ratio $r: /" | cut -c1-20,100-200
+done
+done
