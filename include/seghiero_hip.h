@@ -173,16 +173,21 @@ int sh_dw_tile_rows(void);                      /* rows per stat-partial of sh_d
  * zero), see sh_conv_fprop_x6_aff. */
 int sh_dwconv_fprop(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* w, float* y, int ldy,
                     float* stat_partials, int N, int H, int W, int C, int dil, void* stream);
-int sh_dwconv_dgrad(const float* dy, int lddy, const float* w, float* dx, int lddx,
+/* y_lin / lin (optional, both or neither; dgrad, dgrad_bnb, wgrad): deferred BatchNorm-backward apply of the depthwise conv's own
+ * BatchNorm -- `dy` holds the masked gradient g and the loader evaluates dy = lin[0][c]*g + lin[1][c]*(y_lin - lin[2][c]) + lin[3][c]
+ * (sh_bn_bwd_finalize's lin; y_lin = the conv's raw output), so sh_bn_bwd_apply and the dy tensor are skipped
+ * (sep_aspp_contrast_head.py:43-61).  dil == 1 with H, W multiples of 8 only; SH_EUNSUPPORTED otherwise. */
+int sh_dwconv_dgrad(const float* dy, int lddy, const float* y_lin, int ldyl, const float* lin, const float* w, float* dx, int lddx,
                     int N, int H, int W, int C, int dil, int accumulate, void* stream);
 /* ... with the front half of the producer layer's BatchNorm backward in the epilogue (see sh_conv_dgrad_x6_bnb):
  * g <- relumask(y_prev*scale + shift) * dx, stat_partials[sh_dw_partials(N,H,W)][2][C] <- (sum g, sum g*xhat) per 64 pixels. */
-int sh_dwconv_dgrad_bnb(const float* dy, int lddy, const float* w, float* g, int ldg, const float* y_prev, int ldyp,
-                        const float* mean, const float* invstd, const float* scale, const float* shift,
+int sh_dwconv_dgrad_bnb(const float* dy, int lddy, const float* y_lin, int ldyl, const float* lin, const float* w, float* g, int ldg,
+                        const float* y_prev, int ldyp, const float* mean, const float* invstd, const float* scale, const float* shift,
                         float* stat_partials, int N, int H, int W, int C, int dil, void* stream);
 /* dw_partials: [sh_dw_partials(N,H,W)][9][C] floats; dw: [C][9] */
 int sh_dwconv_wgrad(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* dy, int lddy,
-                    float* dw_partials, float* dw, int N, int H, int W, int C, int dil, void* stream);
+                    const float* y_lin, int ldyl, const float* lin, float* dw_partials, float* dw, int N, int H, int W, int C, int dil,
+                    void* stream);
 
 /* batch norm ------------------------------------------------------------------------------ */
 /* Train-mode nn.BatchNorm2d (every BN of the path; math: SURVEY A.2).  Combines the centred stat partials

@@ -316,6 +316,21 @@ __device__ __forceinline__ f32x4 dw_walk_fetch(const float* __restrict__ x, long
     if (dw_walk_inside(q, H, W, hy, ix)) v = ld4(x + (((long long)q.n * H + q.ty * DT + hy - 1) * W + ix) * ldx + q.c);
     return v;
 }
+// deferred BatchNorm-backward apply (dgrad / wgrad of a depthwise conv -> BN layer): the gradient operand is lin(g, y) =
+// A*g + B*(y - mean) + D per channel (sh_bn_bwd_finalize's lin[4][C]) of the masked gradient g and the raw conv output y
+struct DwLin { const float* y; long long ldy; const float* lin; };
+struct DwLinC { f32x4 a, b, mu, d; };
+__device__ __forceinline__ DwLinC dw_lin_coefs(const DwLin& L, int C, int c, bool cok) {
+    DwLinC k; k.a = k.b = k.mu = k.d = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (L.lin != nullptr && cok) { k.a = ld4(L.lin + c); k.b = ld4(L.lin + C + c); k.mu = ld4(L.lin + 2 * C + c); k.d = ld4(L.lin + 3 * C + c); }
+    return k;
+}
+__device__ __forceinline__ f32x4 dw_lin_eval(f32x4 g, f32x4 y, bool inside, const DwLinC& k) {
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = inside ? fmaf(y[e] - k.mu[e], k.b[e], fmaf(g[e], k.a[e], k.d[e])) : 0.f;      // padding stays zero
+    return r;
+}
 __device__ __forceinline__ f32x4 dw_walk_act(f32x4 v, bool aff, bool inside, const f32x4& sc, const f32x4& sh) {
     if (aff && inside) {            // sh_bn_act's own operation order; zero padding stays zero
         v = v * sc + sh;
@@ -325,23 +340,29 @@ __device__ __forceinline__ f32x4 dw_walk_act(f32x4 v, bool aff, bool inside, con
 }
 // columns 8tx-1 .. 8tx+8 of the strip -> ring slots rb .. rb+9 (start of a run / of a strip); 100 items over 16 pixel lanes
 __device__ __forceinline__ void dw_walk_prologue(float (*xs)[DWR][DW_CH], const float* __restrict__ x, long long ldx, bool aff,
-                                                 const f32x4& sc, const f32x4& sh, const DwWalk& q, int H, int W, int tx, int rb, int pl, int cq) {
+                                                 const f32x4& sc, const f32x4& sh, const DwWalk& q, int H, int W, int tx, int rb, int pl, int cq,
+                                                 const DwLin* L = nullptr, const DwLinC* lc = nullptr) {
     for (int i = pl; i < (DT + 2) * (DT + 2); i += 16) {
         const int hy = i / (DT + 2), hx = i - hy * (DT + 2), ix = tx * DT + hx - 1;
-        st4(&xs[hy][dw_slot(rb, hx)][cq * 4], dw_walk_act(dw_walk_fetch(x, ldx, q, H, W, hy, ix), aff, dw_walk_inside(q, H, W, hy, ix), sc, sh));
+        f32x4 v = dw_walk_fetch(x, ldx, q, H, W, hy, ix);
+        if (L != nullptr && L->lin != nullptr) v = dw_lin_eval(v, dw_walk_fetch(L->y, L->ldy, q, H, W, hy, ix), dw_walk_inside(q, H, W, hy, ix), *lc);
+        st4(&xs[hy][dw_slot(rb, hx)][cq * 4], dw_walk_act(v, aff, dw_walk_inside(q, H, W, hy, ix), sc, sh));
     }
 }
 template <int MODE>   // 0 fprop (+stats), 1 dgrad (flipped taps, optional accumulate / BatchNorm-backward epilogue)
 __global__ __launch_bounds__(256) void dwconv_walk_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ w,
                                                           float* __restrict__ y, long long ldy, float* __restrict__ partials,
                                                           int N, int H, int W, int C, int accumulate,
-                                                          const float* __restrict__ isc, const float* __restrict__ ish, const DwBnb bnb) {
+                                                          const float* __restrict__ isc, const float* __restrict__ ish, const DwBnb bnb,
+                                                          const DwLin lin) {
     __shared__ __attribute__((aligned(16))) float xs[DT + 2][DWR][DW_CH];
     __shared__ float red[16][DW_CH];
     __shared__ float colmean[DW_CH];
     const int t = threadIdx.x, cq = t & 15, pl = t >> 4;
     DwWalk q;
     dw_walk_init(q, H, W, C, N, cq);
+    const bool has_lin = MODE == 1 && lin.lin != nullptr;
+    const DwLinC lc = dw_lin_coefs(lin, C, q.c, q.cok);
     f32x4 wr[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k)
@@ -354,17 +375,19 @@ __global__ __launch_bounds__(256) void dwconv_walk_kernel(const float* __restric
     for (long long tile = q.t0; tile < q.t1; ++tile) {
         if (tile == q.t0 || tx == 0) {            // the run or a strip begins: the whole 10x10 halo (the loop ends on a barrier)
             dw_walk_strip(q, tile / q.tiles_x);
-            dw_walk_prologue(xs, x, ldx, aff, sc, sh, q, H, W, tx, rb, pl, cq);
+            dw_walk_prologue(xs, x, ldx, aff, sc, sh, q, H, W, tx, rb, pl, cq, &lin, &lc);
             __syncthreads();
         }
         // columns 8tx+9 .. 8tx+16 (tile tx+1's new ones): 80 items, 5 per thread, in flight during this tile's arithmetic
         f32x4 nx[5];
+        [[maybe_unused]] f32x4 ny[5];
         const bool more = tx + 1 < q.tiles_x && tile + 1 < q.t1;
         if (more) {
 #pragma unroll
             for (int it = 0; it < 5; ++it) {
                 const int i = it * 16 + pl;
                 nx[it] = dw_walk_fetch(x, ldx, q, H, W, i >> 3, tx * DT + 9 + (i & 7));
+                if (MODE == 1 && has_lin) ny[it] = dw_walk_fetch(lin.y, lin.ldy, q, H, W, i >> 3, tx * DT + 9 + (i & 7));
             }
         }
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -421,8 +444,10 @@ __global__ __launch_bounds__(256) void dwconv_walk_kernel(const float* __restric
 #pragma unroll
             for (int it = 0; it < 5; ++it) {
                 const int i = it * 16 + pl;
-                st4(&xs[i >> 3][dw_slot(rb, i & 7)][cq * 4],
-                    dw_walk_act(nx[it], aff, dw_walk_inside(q, H, W, i >> 3, tx * DT + 9 + (i & 7)), sc, sh));
+                const bool inside = dw_walk_inside(q, H, W, i >> 3, tx * DT + 9 + (i & 7));
+                f32x4 v = nx[it];
+                if (MODE == 1 && has_lin) v = dw_lin_eval(v, ny[it], inside, lc);
+                st4(&xs[i >> 3][dw_slot(rb, i & 7)][cq * 4], dw_walk_act(v, aff, inside, sc, sh));
             }
             __syncthreads();
         }
@@ -433,19 +458,21 @@ __global__ __launch_bounds__(256) void dwconv_walk_kernel(const float* __restric
 // one partial [9][C] per block
 __global__ __launch_bounds__(256) void dwconv_wgrad_walk_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ dy,
                                                                long long lddy, float* __restrict__ partials, int N, int H, int W, int C,
-                                                               const float* __restrict__ isc, const float* __restrict__ ish) {
+                                                               const float* __restrict__ isc, const float* __restrict__ ish, const DwLin lin) {
     __shared__ __attribute__((aligned(16))) float xs[DT + 2][DWR][DW_CH];
     __shared__ float red[16][DW_CH];
     const int t = threadIdx.x, cq = t & 15, pl = t >> 4;
     DwWalk q;
     dw_walk_init(q, H, W, C, N, cq);
+    const bool has_lin = lin.lin != nullptr;
+    const DwLinC lc = dw_lin_coefs(lin, C, q.c, q.cok);
     f32x4 acc[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool aff = isc != nullptr;
     f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
     if (aff && q.cok) { sc = ld4(isc + q.c); sh = ld4(ish + q.c); }
-    f32x4 g[4];
+    f32x4 g[4], gy[4];         // dy of the next tile (raw g and, deferred apply, y: the linear form is evaluated when the tile is used)
     auto fetch_dy = [&](long long tile) {
         const long long strip = tile / q.tiles_x;
         const int ftx = (int)(tile - strip * q.tiles_x), fty = (int)(strip % q.tiles_y);
@@ -453,7 +480,9 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_walk_kernel(const float* __r
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int pidx = it * 16 + pl, py = pidx / DT, px = pidx - py * DT;
-            g[it] = q.cok ? ld4(dy + ((fn * H + fty * DT + py) * W + ftx * DT + px) * lddy + q.c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const long long m = (fn * H + fty * DT + py) * W + ftx * DT + px;
+            g[it] = q.cok ? ld4(dy + m * lddy + q.c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            gy[it] = (has_lin && q.cok) ? ld4(lin.y + m * lin.ldy + q.c) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     if (q.t0 < q.t1) fetch_dy(q.t0);
@@ -476,11 +505,12 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_walk_kernel(const float* __r
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int pidx = it * 16 + pl, py = pidx / DT, px = pidx - py * DT;
+            const f32x4 gv = has_lin ? dw_lin_eval(g[it], gy[it], q.cok, lc) : g[it];
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw)
-                    acc[kh * 3 + kw] += g[it] * ld4(&xs[py + kh][dw_slot(rb, px + kw)][cq * 4]);
+                    acc[kh * 3 + kw] += gv * ld4(&xs[py + kh][dw_slot(rb, px + kw)][cq * 4]);
         }
         if (tile + 1 < q.t1) fetch_dy(tile + 1);
         __syncthreads();
@@ -595,42 +625,51 @@ extern "C" int sh_dwconv_fprop(const float* x, int ldx, const float* in_scale, c
     const long long M = (long long)N * H * W;
     dim3 grid((unsigned)sh_cdiv(M, DW_PIX), (unsigned)sh_cdiv(C, DW_CH));
     if (dil == 1 && H % DT == 0 && W % DT == 0 && dw_walk_on())       // same partial count: (H/8)*(W/8) tiles of 64 pixels per image
-        dwconv_walk_kernel<0><<<dw_walk_blocks(N, H, W, C) * grid.y, 256, 0, (hipStream_t)stream>>>(x, ldx, w, y, ldy, stat_partials, N, H, W, C, 0, in_scale, in_shift, DwBnb{});
+        dwconv_walk_kernel<0><<<dw_walk_blocks(N, H, W, C) * grid.y, 256, 0, (hipStream_t)stream>>>(x, ldx, w, y, ldy, stat_partials, N, H, W, C, 0, in_scale, in_shift, DwBnb{}, DwLin{});
     else if (dil == 1 && H % DT == 0 && W % DT == 0)
         dwconv_tile_kernel<0><<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(x, ldx, w, y, ldy, stat_partials, H, W, C, 0, in_scale, in_shift, DwBnb{});
     else
         dwconv_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, w, y, ldy, stat_partials, H, W, C, dil, M, 0, in_scale, in_shift, DwBnb{});
     return sh_launch_status();
 }
+static bool dw_lin_args_ok(const float* y_lin, int ldyl, const float* lin, int C) {
+    return (lin == nullptr && y_lin == nullptr) || (lin && y_lin && ldyl >= C && !(ldyl & 3) && !(((uintptr_t)y_lin | (uintptr_t)lin) & 15));
+}
 static int dw_dgrad_any(const float* dy, int lddy, const float* w, float* dx, int lddx, int N, int H, int W, int C, int dil, int accumulate,
-                        const DwBnb& bnb, void* stream) {
+                        const DwBnb& bnb, void* stream, const DwLin lin = DwLin{}) {
     const long long M = (long long)N * H * W;
     dim3 grid((unsigned)sh_cdiv(M, DW_PIX), (unsigned)sh_cdiv(C, DW_CH));
     if (dil == 1 && H % DT == 0 && W % DT == 0 && dw_walk_on())
-        dwconv_walk_kernel<1><<<dw_walk_blocks(N, H, W, C) * grid.y, 256, 0, (hipStream_t)stream>>>(dy, lddy, w, dx, lddx, nullptr, N, H, W, C, accumulate, nullptr, nullptr, bnb);
+        dwconv_walk_kernel<1><<<dw_walk_blocks(N, H, W, C) * grid.y, 256, 0, (hipStream_t)stream>>>(dy, lddy, w, dx, lddx, nullptr, N, H, W, C, accumulate, nullptr, nullptr, bnb, lin);
+    else if (lin.lin != nullptr) return SH_EUNSUPPORTED;          // the deferred-apply loader exists in the strip-walk kernels only
     else if (dil == 1 && H % DT == 0 && W % DT == 0)
         dwconv_tile_kernel<1><<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(dy, lddy, w, dx, lddx, nullptr, H, W, C, accumulate, nullptr, nullptr, bnb);
     else
         dwconv_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(dy, lddy, w, dx, lddx, nullptr, H, W, C, dil, M, accumulate, nullptr, nullptr, bnb);
     return sh_launch_status();
 }
-extern "C" int sh_dwconv_dgrad(const float* dy, int lddy, const float* w, float* dx, int lddx, int N, int H, int W, int C,
-                               int dil, int accumulate, void* stream) {
-    if (!dw_args_ok(dy, w, dx, N, H, W, C, dil, lddy, lddx)) return SH_EINVAL;
-    return dw_dgrad_any(dy, lddy, w, dx, lddx, N, H, W, C, dil, accumulate, DwBnb{}, stream);
+// y_lin / lin (optional, both or neither): deferred BatchNorm-backward apply -- `dy` holds the masked gradient g and the loader evaluates
+// dy = lin[0]*g + lin[1]*(y_lin - lin[2]) + lin[3] (sh_bn_bwd_finalize's lin[4][C]); dil == 1 and H, W multiples of 8, else SH_EUNSUPPORTED
+extern "C" int sh_dwconv_dgrad(const float* dy, int lddy, const float* y_lin, int ldyl, const float* lin, const float* w, float* dx, int lddx,
+                               int N, int H, int W, int C, int dil, int accumulate, void* stream) {
+    if (!dw_args_ok(dy, w, dx, N, H, W, C, dil, lddy, lddx) || !dw_lin_args_ok(y_lin, ldyl, lin, C)) return SH_EINVAL;
+    return dw_dgrad_any(dy, lddy, w, dx, lddx, N, H, W, C, dil, accumulate, DwBnb{}, stream, DwLin{y_lin, ldyl, lin});
 }
 // ... with the front half of the producer layer's BatchNorm backward in the epilogue (see sh_conv_dgrad_x6_bnb): g <- relumask * dx,
 // stat_partials[sh_dw_partials(N,H,W)][2][C] <- (sum g, sum g * xhat) per 64-pixel block.  y_prev: raw output of the producer conv.
-extern "C" int sh_dwconv_dgrad_bnb(const float* dy, int lddy, const float* w, float* g, int ldg, const float* y_prev, int ldyp,
-                                   const float* mean, const float* invstd, const float* scale, const float* shift, float* stat_partials,
-                                   int N, int H, int W, int C, int dil, void* stream) {
-    if (!dw_args_ok(dy, w, g, N, H, W, C, dil, lddy, ldg) || !y_prev || !mean || !invstd || !scale || !shift || !stat_partials) return SH_EINVAL;
+extern "C" int sh_dwconv_dgrad_bnb(const float* dy, int lddy, const float* y_lin, int ldyl, const float* lin, const float* w, float* g, int ldg,
+                                   const float* y_prev, int ldyp, const float* mean, const float* invstd, const float* scale, const float* shift,
+                                   float* stat_partials, int N, int H, int W, int C, int dil, void* stream) {
+    if (!dw_args_ok(dy, w, g, N, H, W, C, dil, lddy, ldg) || !y_prev || !mean || !invstd || !scale || !shift || !stat_partials ||
+        !dw_lin_args_ok(y_lin, ldyl, lin, C)) return SH_EINVAL;
     if (ldyp < C || (ldyp & 3) || (((uintptr_t)y_prev | (uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)scale | (uintptr_t)shift) & 15)) return SH_EINVAL;
-    return dw_dgrad_any(dy, lddy, w, g, ldg, N, H, W, C, dil, 0, DwBnb{y_prev, ldyp, mean, invstd, scale, shift, stat_partials}, stream);
+    return dw_dgrad_any(dy, lddy, w, g, ldg, N, H, W, C, dil, 0, DwBnb{y_prev, ldyp, mean, invstd, scale, shift, stat_partials}, stream,
+                        DwLin{y_lin, ldyl, lin});
 }
 extern "C" int sh_dwconv_wgrad(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* dy, int lddy,
-                               float* dw_partials, float* dw, int N, int H, int W, int C, int dil, void* stream) {
-    if (!dw_args_ok(x, dy, dw, N, H, W, C, dil, ldx, lddy) || !dw_partials) return SH_EINVAL;
+                               const float* y_lin, int ldyl, const float* lin, float* dw_partials, float* dw, int N, int H, int W, int C, int dil,
+                               void* stream) {
+    if (!dw_args_ok(x, dy, dw, N, H, W, C, dil, ldx, lddy) || !dw_partials || !dw_lin_args_ok(y_lin, ldyl, lin, C)) return SH_EINVAL;
     if ((in_scale == nullptr) != (in_shift == nullptr) || (((uintptr_t)in_scale | (uintptr_t)in_shift) & 15)) return SH_EINVAL;
     const long long M = (long long)N * H * W;
     int P = (int)sh_cdiv(M, DW_PIX);
@@ -639,8 +678,10 @@ extern "C" int sh_dwconv_wgrad(const float* x, int ldx, const float* in_scale, c
     dim3 grid((unsigned)P, (unsigned)sh_cdiv(C, DW_CH));
     if (dil == 1 && H % DT == 0 && W % DT == 0 && dw_walk_on()) {
         P = (int)dw_walk_blocks(N, H, W, C);                        // one partial per block (<= M/64 rows of the workspace)
-        dwconv_wgrad_walk_kernel<<<(unsigned)P * grid.y, 256, 0, (hipStream_t)stream>>>(x, ldx, dy, lddy, dw_partials, N, H, W, C, in_scale, in_shift);
-    } else if (dil == 1 && H % DT == 0 && W % DT == 0)
+        dwconv_wgrad_walk_kernel<<<(unsigned)P * grid.y, 256, 0, (hipStream_t)stream>>>(x, ldx, dy, lddy, dw_partials, N, H, W, C, in_scale, in_shift,
+                                                                                        DwLin{y_lin, ldyl, lin});
+    } else if (lin != nullptr) return SH_EUNSUPPORTED;
+    else if (dil == 1 && H % DT == 0 && W % DT == 0)
         dwconv_wgrad_tile_kernel<<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(x, ldx, dy, lddy, dw_partials, H, W, C, M / (DT * DT), in_scale, in_shift);
     else
         dwconv_wgrad_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, dy, lddy, dw_partials, H, W, C, dil, M, in_scale, in_shift);

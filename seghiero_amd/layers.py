@@ -271,7 +271,8 @@ def dw_fwd(x, weight, dil, bn, training, lazy=False):
 
 def dw_bwd(rec, bn, dout, dx_accumulate_into=None):
     """-> (dx, dweight, dgamma, dbeta); with dx_accumulate_into the input gradient is added into that tensor."""
-    dy, dgamma, dbeta, _ = ops.bn_backward(dout, None, rec.y, rec.coefs, bn.weight, 2)
+    # second half of the BatchNorm backward in the loaders of the depthwise dgrad / wgrad (strip-walk kernels): no apply pass
+    dy, dgamma, dbeta, _ = ops.bn_backward(dout, None, rec.y, rec.coefs, bn.weight, 2, defer=FUSE_BN and ops.dw_lin_ok(rec.y.shape, rec.dil))
     dw = new_grad(rec.weight)
     if isinstance(rec.x, Lazy) and rec.x._out is None:
         ops.dwconv_wgrad(rec.x.y, dy, dw, rec.dil, side=True, aff=rec.x.coefs)

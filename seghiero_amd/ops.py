@@ -492,20 +492,32 @@ def dwconv_fprop(x, weight, y, partials, dil, aff=None):
           weight.data_ptr(), yp, ldy, None if partials is None else partials.data_ptr(), n, h, w, c, dil, _st())
 
 
+def dw_lin_ok(shape, dil):
+    """Can the depthwise dgrad / wgrad read their dy operand as a DeferredDy?  (strip-walk kernels: dilation 1, H and W multiples of 8)"""
+    n, c, h, w = shape
+    return DEFER_APPLY and dil == 1 and h % 8 == 0 and w % 8 == 0 and c % 4 == 0
+
+
+def _lin_args(dy):
+    """(g pointer, ldg, y pointer, ldy, lin pointer) of a DeferredDy, or (dy pointer, lddy, None, 0, None) of a tensor."""
+    if isinstance(dy, DeferredDy):
+        return pm(dy.g) + pm(dy.y) + (dy.lin.data_ptr(),)
+    return pm(dy) + (None, 0, None)
+
+
 def dwconv_dgrad(dy, weight, dx, dil, accumulate=False):
+    """dy: tensor or DeferredDy (check dw_lin_ok first)."""
     n, c, h, w = dx.shape
-    dyp, lddy = pm(dy)
     dxp, lddx = pm(dx)
-    _call("sh_dwconv_dgrad", dyp, lddy, weight.data_ptr(), dxp, lddx, n, h, w, c, dil, int(accumulate), _st())
+    _call("sh_dwconv_dgrad", *_lin_args(dy), weight.data_ptr(), dxp, lddx, n, h, w, c, dil, int(accumulate), _st())
 
 
 def dwconv_dgrad_bnb(dy, weight, g, y_prev, coefs, partials, dil):
     """depthwise input gradient + front half of the producer's BatchNorm backward: g <- relumask * dx, partials <- (sum g, sum g*xhat)."""
     n, c, h, w = g.shape
-    dyp, lddy = pm(dy)
     gp, ldg = pm(g)
     ypp, ldyp = pm(y_prev)
-    _call("sh_dwconv_dgrad_bnb", dyp, lddy, weight.data_ptr(), gp, ldg, ypp, ldyp, coefs[0].data_ptr(), coefs[1].data_ptr(),
+    _call("sh_dwconv_dgrad_bnb", *_lin_args(dy), weight.data_ptr(), gp, ldg, ypp, ldyp, coefs[0].data_ptr(), coefs[1].data_ptr(),
           coefs[2].data_ptr(), coefs[3].data_ptr(), partials.data_ptr(), n, h, w, c, dil, _st())
 
 
@@ -515,12 +527,15 @@ def dwconv_wgrad(x, dy, dweight, dil, side=False, aff=None):
     n, c, h, w = x.shape
     p = dw_partials_rows(n, h, w)
     xp, ldx = pm(x)
-    dyp, lddy = pm(dy)
+    largs = _lin_args(dy)
+    dd = dy if isinstance(dy, DeferredDy) else None
+    if dd is not None:
+        dy = dd.g
 
     def launch(tag="dwwgrad"):
         ws = workspace(p * 9 * c * 4, x.device, tag)
         _call("sh_dwconv_wgrad", xp, ldx, None if aff is None else aff[2].data_ptr(), None if aff is None else aff[3].data_ptr(),
-              dyp, lddy, ws.data_ptr(), dweight.data_ptr(), n, h, w, c, dil, _st())
+              *largs, ws.data_ptr(), dweight.data_ptr(), n, h, w, c, dil, _st())
 
     if not (side and WGRAD_ASYNC and x.is_cuda):
         launch()
@@ -529,7 +544,7 @@ def dwconv_wgrad(x, dy, dweight, dil, side=False, aff=None):
     st.wait_stream(torch.cuda.current_stream(x.device))
     with torch.cuda.stream(st):
         launch("dwwgrad%d" % k)
-    for t in (x, dy, dweight):
+    for t in (x, dy, dweight) + (() if dd is None else (dd.y, dd.lin)):
         t.record_stream(st)
 
 

@@ -321,6 +321,43 @@ def test_dwconv_fused_batchnorm_hooks(ops, shape, dil):
 
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 16, 16), (1, 136, 16, 40), (2, 128, 24, 16)])
+def test_dwconv_deferred_batchnorm_backward_apply(ops, shape):
+    """Depthwise dgrad / dgrad+BNB / wgrad with their dy operand evaluated in the loader from (g, y, lin) (ops.DeferredDy: the second
+    half of the depthwise conv's own BatchNorm backward, sep_aspp_contrast_head.py:43-61) against the same kernels on the
+    materialised dy."""
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(c + h)
+    gm, y = nhwc(torch.randn(shape, generator=g)), nhwc(torch.randn(shape, generator=g))
+    lin = torch.stack([0.5 + torch.rand(c, generator=g), 0.3 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g),
+                       0.1 * torch.randn(c, generator=g)]).to(DEV).contiguous()
+    v = lambda t: t.view(1, -1, 1, 1)
+    dy = nhwc((v(lin[0]) * gm + v(lin[1]) * (y - v(lin[2])) + v(lin[3])).cpu())
+    dd = ops.DeferredDy(gm, y, lin, None, None, None)
+    assert ops.dw_lin_ok(shape, 1)
+    wt = (torch.randn(c, 1, 3, 3, generator=g) / 3).to(DEV).contiguous()
+    x = nhwc(torch.randn(shape, generator=g))
+    a, b = ops.new_act(n, c, h, w, DEV), ops.new_act(n, c, h, w, DEV)
+    ops.dwconv_dgrad(dy, wt, a, 1)
+    ops.dwconv_dgrad(dd, wt, b, 1)
+    tol = 3e-6 * float(a.abs().max())
+    close(b, a, 0, tol, "dgrad")
+    pc = torch.stack([0.2 * torch.randn(c, generator=g), 0.5 + torch.rand(c, generator=g), torch.randn(c, generator=g),
+                      0.3 * torch.randn(c, generator=g)]).to(DEV).contiguous()
+    pa, pb = (torch.empty((ops.dw_partials_rows(n, h, w), 2, c), device=DEV) for _ in range(2))
+    ops.dwconv_dgrad_bnb(dy, wt, a, x, pc, pa, 1)
+    ops.dwconv_dgrad_bnb(dd, wt, b, x, pc, pb, 1)
+    close(b, a, 0, tol, "dgrad + producer's BN-backward front half")
+    close(pb.sum(0), pa.sum(0), 0, 3e-5 * float(pa.sum(0).abs().max()), "its partial sums")
+    dwa, dwb = torch.empty_like(wt), torch.empty_like(wt)
+    ops.dwconv_wgrad(x, dy, dwa, 1)
+    ops.dwconv_wgrad(x, dd, dwb, 1)
+    close(dwb, dwa, 0, 1e-5 * float(dwa.abs().max()), "wgrad")
+    ops.dwconv_wgrad(x, dy, dwa, 1, aff=pc)
+    ops.dwconv_wgrad(x, dd, dwb, 1, aff=pc)
+    close(dwb, dwa, 0, 1e-5 * float(dwa.abs().max()), "wgrad, x through its BatchNorm")
+
+
 @pytest.mark.parametrize("shape", [(4, 64, 12, 12), (2, 9, 7, 5), (16, 32, 1, 1)])
 @pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False)])
 def test_batchnorm_train_fwd_bwd(ops, shape, relu, res):
