@@ -161,6 +161,7 @@ def main():
     # profile records the hash of csrc/ it was taken with, and a number from other kernel sources is flagged stale.
     fam = {"sh_conv_fprop_x6": "conv_fprop_x6", "sh_conv_dgrad_x6": "conv_dgrad_x6", "sh_conv_wgrad_x6": "conv_wgrad_x6",
            "sh_conv_fprop_x6_aff": "conv_fprop_x6", "sh_conv_dgrad_x6_bnb": "conv_dgrad_x6", "sh_conv_wgrad_x6_aff": "conv_wgrad_x6",
+           "sh_conv_dgrad_x6_lin": "conv_dgrad_x6", "sh_conv_wgrad_x6_lin": "conv_wgrad_x6",
            "sh_conv_fprop": "conv_fprop_f32", "sh_conv_dgrad": "conv_dgrad_f32", "sh_conv_wgrad": "conv_wgrad_f32"}.get(dom)
     try:
         import glob

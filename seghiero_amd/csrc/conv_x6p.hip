@@ -17,6 +17,11 @@
 // Loader mapping: thread = (row, 16-byte k chunk of a half-tile); the two half-tiles of a 128-byte line are fetched by the
 // same thread in consecutive phases.
 //
+// Tried and dropped (round 2): B fragments straight from pre-split, fragment-ordered bf16 weight planes in global memory (no split, no
+// LDS image, no staging registers for B; bit-identical results).  Each wave then fetches its own 6 x 1 KiB of fragments per phase --
+// 3x the L2 -> CU bytes of the fp32 tile staged once per block -- and the vector-memory path becomes the limit: fprop 512->512
+// @16x128^2 1016 vs 714 us, step 34.7 vs 33.8 ms.  (A timing build that merely skipped the B split ran fprop / dgrad 6 % faster.)
+//
 // Fused BatchNorm hooks (the reason the loaders go through registers at all):
 //   AFF : A operand = relu(x * scale[c] + shift[c]) applied in the loader -- the producer's train-mode BatchNorm + ReLU
 //         (reference: every conv -> BN -> ReLU -> conv chain, models/backbone/resnet.py:65-73, sep_aspp_contrast_head.py:56-61),
@@ -34,6 +39,10 @@
 // a ds_write_b64 group -- 4 consecutive rows x the 4 chunks-halves of ONE k-half -- cover all 32 store banks once.
 __device__ __forceinline__ int swz_row(int row) { return ((row >> 2) & 3) ^ (row & 2); }
 
+#ifndef SH_W1          // blocks per CU (launch bounds) of the 128 x 128 / 128 x 64 instantiations; -D overrides for experiments
+#define SH_W1(AFF, EPI) ((AFF) == 2 ? 2 : 3)
+#define SH_W2(AFF, EPI) (((AFF) == 2 || (EPI) == 2) ? 3 : 4)
+#endif
 // TAP: 0 = 1x1 (one tap), 1 = KxK with Kc % 16 == 0 (a half-tile never straddles taps: scalar tap math, switched by a block-uniform
 // branch at the start of a phase), 2 = general (per-lane tap; stem 7x7 with 4 channels)
 template <int MODE, int TM, int TN, int WGM, int WGN, int WPS, int AFF, int EPI, int SK, int TAP, int GRP = 0>
@@ -361,45 +370,51 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
 #pragma unroll
                 for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * RS + 32 * j + l31] = acc[i][j][r];
             __syncthreads();
-            f32x4 v[NRD];
-            [[maybe_unused]] f32x4 ad[NRD], yv[NRD], ov[NRD];
-            long long mrow[NRD];
+            // the strip's NRD row groups in chunks: the BatchNorm-backward epilogue holds four tiles per row group (accumulator strip,
+            // addend, y, out) next to the 64 accumulator registers -- all 8 groups at once spilled 85 registers
+            constexpr int CH = (EPI == 2 && NRD > 4) ? 4 : NRD;
+            [[maybe_unused]] f32x4 gs = zero4, gq = zero4;
 #pragma unroll
-            for (int k = 0; k < NRD; ++k) {
-                const int row = k * RPI + rr;
-                mrow[k] = m0 + wm * 32 * TM + 32 * i + row;
-                v[k] = *reinterpret_cast<const f32x4*>(stage + row * RS + c4);
+            for (int k0 = 0; k0 < NRD; k0 += CH) {
+            f32x4 v[CH];
+            [[maybe_unused]] f32x4 ad[CH], yv[CH], ov[CH];
+            long long mrow[CH];
+#pragma unroll
+            for (int kk = 0; kk < CH; ++kk) {
+                const int row = (k0 + kk) * RPI + rr;
+                mrow[kk] = m0 + wm * 32 * TM + 32 * i + row;
+                v[kk] = *reinterpret_cast<const f32x4*>(stage + row * RS + c4);
                 if constexpr (MODE == DGRAD) {
-                    ad[k] = zero4;
-                    if (mrow[k] < Mc && nokv) {
-                        if (p.extra != nullptr) ad[k] = ld4(p.extra + mrow[k] * p.ldadd + ncv);
+                    ad[kk] = zero4;
+                    if (mrow[kk] < Mc && nokv) {
+                        if (p.extra != nullptr) ad[kk] = ld4(p.extra + mrow[kk] * p.ldadd + ncv);
                         if constexpr (EPI == 2) {
-                            yv[k] = ld4(p.bnb_y + mrow[k] * p.bnb_ldy + ncv);
-                            if (p.bnb_out != nullptr) ov[k] = ld4(p.bnb_out + mrow[k] * p.bnb_ldo + ncv);
+                            yv[kk] = ld4(p.bnb_y + mrow[kk] * p.bnb_ldy + ncv);
+                            if (p.bnb_out != nullptr) ov[kk] = ld4(p.bnb_out + mrow[kk] * p.bnb_ldo + ncv);
                         }
                     }
                 }
             }
-            [[maybe_unused]] f32x4 gs = zero4, gq = zero4;
 #pragma unroll
-            for (int k = 0; k < NRD; ++k) {
-                if (mrow[k] < Mc && nokv) {
-                    f32x4 o = v[k];
+            for (int kk = 0; kk < CH; ++kk) {
+                if (mrow[kk] < Mc && nokv) {
+                    f32x4 o = v[kk];
                     if constexpr (MODE == FPROP) o += vb;
                     else {
-                        o += ad[k];
+                        o += ad[kk];
                         if constexpr (EPI == 2) {
                             if (p.bnb_relu) {
                                 // the forward's own arithmetic (bn_act_kernel), or the stored block output where a residual was added
-                                const f32x4 a = p.bnb_out != nullptr ? ov[k] : yv[k] * v_sc + v_sh;
+                                const f32x4 a = p.bnb_out != nullptr ? ov[kk] : yv[kk] * v_sc + v_sh;
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) if (!(a[e] > 0.f)) o[e] = 0.f;
                             }
-                            gs += o; gq += o * ((yv[k] - v_mu) * v_is);
+                            gs += o; gq += o * ((yv[kk] - v_mu) * v_is);
                         }
                     }
-                    st4(p.c + mrow[k] * p.ldc + ncv, o);
+                    st4(p.c + mrow[kk] * p.ldc + ncv, o);
                 }
+            }
             }
             if constexpr (EPI == 2) {      // column sums over the strip's 32 rows: across the RPI row groups of the wave
 #pragma unroll
@@ -555,10 +570,11 @@ static int launch_x6p(ConvQ& p, hipStream_t st) {
 template <int MODE, int AFF, int EPI, int TAP>
 static int pick_tile_x6p(ConvQ& p, hipStream_t st, int force) {
     (void)force;
-    // AFF == 2 carries a second A-operand stream (16 more prefetch registers) and the BatchNorm-backward epilogue (EPI == 2) holds a y
-    // tile next to the accumulators: at 3 blocks per CU (168 VGPRs) they spill 15 / 85 registers -- measured slower than 2 blocks per CU
-    // without spills (AFF == 2: 7.65 vs 6.27 ms per step; EPI == 2: step 35.30 vs 35.07 ms)
-    constexpr int W1 = (AFF == 2 || EPI == 2) ? 2 : 3, W2 = (AFF == 2 || EPI == 2) ? 3 : 4;
+    // AFF == 2 carries a second A-operand stream (16 more prefetch registers): at 3 blocks per CU (168 VGPRs) it spills 15 registers into
+    // the main loop -- measured 7.65 vs 6.27 ms per step at 2 blocks per CU.  (Plain kernels run equally fast at 2 and 3 blocks per CU.)
+    // The BatchNorm-backward epilogue (EPI == 2) spilled 85 registers until its row groups were processed in chunks; 128 x 64 tiles with
+    // it still need 3 instead of 4 blocks per CU (18 spills at 128 VGPRs).
+    constexpr int W1 = SH_W1(AFF, EPI), W2 = SH_W2(AFF, EPI);
     if (p.Nn > 64) return launch_x6p<MODE, 2, 2, 2, 2, W1, AFF, EPI, 0, TAP>(p, st);     // 128 x 128, 4 waves of 64 x 64, 3 blocks per CU
     return launch_x6p<MODE, 2, 1, 2, 2, W2, AFF, EPI, 0, TAP>(p, st);                    // 128 x 64, 4 blocks per CU
 }

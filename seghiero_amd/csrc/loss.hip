@@ -105,16 +105,29 @@ __device__ __forceinline__ void hiera2_pixel(const float (&z)[MAXC], int f, int 
 // valid-label counts ahead of a forward that also emits the gradient (its normalisers): cnt[0] = #fine valid, cnt[1] = #coarse valid
 __global__ __launch_bounds__(256) void label_counts_kernel(const uint8_t* __restrict__ labels, const H2Tab T, int with_coarse, long long total,
                                                            unsigned long long* __restrict__ cnt) {
-    const int lane = threadIdx.x & 63;
-    unsigned long long a = 0, b = 0;                      // wave-uniform
-    for (long long i0 = (long long)blockIdx.x * 256 + (threadIdx.x & ~63); i0 < total; i0 += (long long)gridDim.x * 256) {
-        const int f = i0 + lane < total ? labels[i0 + lane] : IGN;
-        a += __popcll(__ballot(f != IGN));
-        if (with_coarse) b += __popcll(__ballot(f != IGN && coarse_of(f, T) != IGN));
+    __shared__ unsigned int red[2][4];
+    unsigned int a = 0, b = 0;
+    const bool al4 = ((uintptr_t)labels & 3) == 0;
+    const long long n4 = al4 ? total / 4 : 0;                   // 4 labels per load; the tail (and unaligned maps) byte-wise
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const unsigned int v = reinterpret_cast<const unsigned int*>(labels)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int f = (v >> (8 * k)) & 255;
+            if (f != IGN) { ++a; if (with_coarse && coarse_of(f, T) != IGN) ++b; }
+        }
     }
-    if (lane == 0) {
-        if (a) atomicAdd(cnt + 0, a);
-        if (with_coarse && b) atomicAdd(cnt + 1, b);
+    for (long long i = 4 * n4 + (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int f = labels[i];
+        if (f != IGN) { ++a; if (with_coarse && coarse_of(f, T) != IGN) ++b; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {          // one atomic per block and counter (8192 per-wave atomics on one address cost 80 us)
+        atomicAdd(cnt + 0, (unsigned long long)(red[0][0] + red[0][1] + red[0][2] + red[0][3]));
+        if (with_coarse) atomicAdd(cnt + 1, (unsigned long long)(red[1][0] + red[1][1] + red[1][2] + red[1][3]));
     }
 }
 // GRAD: every pixel's d(loss_out)/d(interpolated logits) goes to gfull [N*H*W][L] in the same pass (the backward is then only
@@ -538,7 +551,7 @@ extern "C" int sh_hiera2_loss_fwd(const float* logits, int ldl, const uint8_t* l
         // the gradient's normalisers are label counts: taken first, parked (as integers) where the finalize kernel later writes the same counts
         unsigned long long* cnt = reinterpret_cast<unsigned long long*>(sums + 4);
         if (hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned long long), st) != hipSuccess) return SH_ELAUNCH;
-        label_counts_kernel<<<1024, 256, 0, st>>>(labels, T, 1, total, cnt);
+        label_counts_kernel<<<256, 256, 0, st>>>(labels, T, 1, total, cnt);
         if (C <= 8 && ldg <= 8) hiera2_fwd_kernel<8, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total, cnt, grad_out, ldg);
         else if (C <= 16 && ldg <= 16) hiera2_fwd_kernel<16, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total, cnt, grad_out, ldg);
         else hiera2_fwd_kernel<32, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total, cnt, grad_out, ldg);
@@ -702,7 +715,7 @@ extern "C" int sh_ce_loss_fwd(const float* logits, int ldl, const uint8_t* label
         if (!grad_out_ok(grad_out, grad_out_bytes, ldg, C, N, h, w, H, W)) return SH_EINVAL;
         unsigned long long* cnt = reinterpret_cast<unsigned long long*>(sums + 1);       // see sh_hiera2_loss_fwd
         if (hipMemsetAsync(cnt, 0, sizeof(unsigned long long), st) != hipSuccess) return SH_ELAUNCH;
-        label_counts_kernel<<<1024, 256, 0, st>>>(labels, H2Tab{}, 0, total, cnt);
+        label_counts_kernel<<<256, 256, 0, st>>>(labels, H2Tab{}, 0, total, cnt);
         if (ldg <= 8) ce_fwd_kernel<8, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total, cnt, grad_out, ldg);
         else if (ldg <= 16) ce_fwd_kernel<16, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total, cnt, grad_out, ldg);
         else ce_fwd_kernel<32, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total, cnt, grad_out, ldg);
