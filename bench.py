@@ -183,7 +183,7 @@ def main():
             roof_units = {"aspp_ds_branch": units.measure(device=dev, batch=args.batch)}
         except Exception as e:                  # never lose the headline line to the side measurement
             roof_units = {"aspp_ds_branch": {"error": repr(e)}}
-    breakdown = {k: round(v["ms"], 2) for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])[:12]}
+    breakdown = {k: round(v["ms"], 2) for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])[:16]}
     out = {
         "metric": "images/sec at 512x512 (ResNet-50 2-level), full train step", "value": round(args.batch * world * args.steps / dt, 2),
         "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -89,15 +89,17 @@ extern "C" int sh_axpy(float* y, const float* x, float a, int64_t n, void* strea
 // partials: [P][2][C] floats.  Block = 4 channels x 256 row-groups; f64 accumulation; LDS tree.
 // Writes sums[0][c], sums[1][c] (double) into LDS-resident result then calls the functor on thread < 4.
 // CENTRED != 0: partial = (sum, M2 about its own mean) over n_p = min(R, M - p*R) rows -> returns (sum, sum of squares about 0)
-template <typename F>
+// NT threads per block (256, or 1024 for long partial lists: the kernel is a latency-bound strided gather -- 16 bytes per row --
+// and the layers with 4096+ partials and 64 channels run only 16 blocks, so more threads per block is the parallelism there is)
+template <int NT = 256, typename F>
 __device__ __forceinline__ void reduce_partials_4ch(const float* __restrict__ partials, int P, int C, int c0, int R, long long M, F&& fin, long long ldp = 0) {
     if (ldp == 0) ldp = C;                 // row length of the partials (> C: this tensor is a column slice of a wider set)
-    __shared__ double red[8][4];   // [stat*4+ch][wave]
+    __shared__ double red[8][NT / 64];   // [stat*4+ch][wave]
     const int t = threadIdx.x;
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool vec = (C & 3) == 0 && (ldp & 3) == 0 && ((uintptr_t)partials & 15) == 0;
 #pragma unroll 4                    // the loads of successive partials are independent: keep several in flight (latency-bound kernel)
-    for (int p = t; p < P; p += 256) {
+    for (int p = t; p < P; p += NT) {
         const float* r0 = partials + ((long long)p * 2 + 0) * ldp + c0;
         const float* r1 = partials + ((long long)p * 2 + 1) * ldp + c0;
         double inv_n = 0.0;
@@ -120,8 +122,12 @@ __device__ __forceinline__ void reduce_partials_4ch(const float* __restrict__ pa
     }
     __syncthreads();
     if (t < 4 && c0 + t < C) {
-        const double s = red[t][0] + red[t][1] + red[t][2] + red[t][3];
-        const double q = red[4 + t][0] + red[4 + t][1] + red[4 + t][2] + red[4 + t][3];
+        double s = 0, q = 0;
+#pragma unroll
+        for (int wv = 0; wv < NT / 64; wv += 4) {
+            s += (red[t][wv] + red[t][wv + 1]) + (red[t][wv + 2] + red[t][wv + 3]);
+            q += (red[4 + t][wv] + red[4 + t][wv + 1]) + (red[4 + t][wv + 2] + red[4 + t][wv + 3]);
+        }
         fin(c0 + t, s, q);
     }
 }
@@ -131,13 +137,14 @@ __device__ __forceinline__ void reduce_partials_4ch(const float* __restrict__ pa
 // The coefficients are then emitted in the x domain so that every consumer can work on x itself:
 //   mean = mean_x, invstd = w * invstd_y  (=> xhat_y = (x - mean) * invstd, and gamma * invstd * (...) is already d/dx),
 //   scale = w * gamma * invstd_y, shift = beta - mean_y * gamma * invstd_y  (=> y_bn = x * scale + shift);  isy[c] = invstd_y.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int P, int C, double count,
+template <int NT>
+__global__ __launch_bounds__(NT) void bn_finalize_kernel(const float* __restrict__ partials, int P, int C, double count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, float momentum, float* running_mean,
                                                           float* running_var, float* mean, float* invstd, float* scale,
                                                           float* shift, int R, long long ldp, const float* __restrict__ wmul, int wstride,
                                                           float* __restrict__ isy) {
-    reduce_partials_4ch(partials, P, C, blockIdx.x * 4, R, (long long)count, [&](int c, double s, double q) {
+    reduce_partials_4ch<NT>(partials, P, C, blockIdx.x * 4, R, (long long)count, [&](int c, double s, double q) {
         const double mu = s / count;
         double var = q / count - mu * mu;
         if (var < 0) var = 0;
@@ -166,9 +173,14 @@ extern "C" int sh_bn_finalize(const float* partials, int n_partials, int C, doub
     if (!partials || n_partials <= 0 || C <= 0 || count <= 0 || !mean || !invstd || !scale || !shift || rows_per_partial <= 0) return SH_EINVAL;
     if ((long long)n_partials != sh_cdiv((long long)count, rows_per_partial)) return SH_EINVAL;
     if ((running_mean == nullptr) != (running_var == nullptr) || (partials_ld != 0 && partials_ld < C)) return SH_EINVAL;
-    bn_finalize_kernel<<<(unsigned)sh_cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(
-        partials, n_partials, C, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, rows_per_partial,
-        partials_ld, nullptr, 0, nullptr);
+    if (n_partials >= 1024)
+        bn_finalize_kernel<1024><<<(unsigned)sh_cdiv(C, 4), 1024, 0, (hipStream_t)stream>>>(
+            partials, n_partials, C, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, rows_per_partial,
+            partials_ld, nullptr, 0, nullptr);
+    else
+        bn_finalize_kernel<256><<<(unsigned)sh_cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(
+            partials, n_partials, C, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, rows_per_partial,
+            partials_ld, nullptr, 0, nullptr);
     return sh_launch_status();
 }
 // Several BatchNorm layers of C channels each finalized in ONE launch (the grouped ASPP unit: its four pointwise BatchNorms share one
@@ -244,7 +256,7 @@ extern "C" int sh_bn_finalize_scaled(const float* partials, int n_partials, int 
         rows_per_partial <= 0) return SH_EINVAL;
     if ((long long)n_partials != sh_cdiv((long long)count, rows_per_partial)) return SH_EINVAL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return SH_EINVAL;
-    bn_finalize_kernel<<<(unsigned)sh_cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(
+    bn_finalize_kernel<256><<<(unsigned)sh_cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(
         partials, n_partials, C, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, rows_per_partial,
         0, chan_mul, chan_stride, isy);
     return sh_launch_status();
@@ -499,11 +511,12 @@ __device__ __forceinline__ void bn_bwd_lin(float* lin, int C, int c, float ga, f
     const float A = ga * is;
     lin[c] = A; lin[C + c] = -(A * is) * c2; lin[2 * C + c] = mu; lin[3 * C + c] = -A * c1;
 }
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int P, int C,
+template <int NT>
+__global__ __launch_bounds__(NT) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int P, int C,
                                                               const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                               double count, float* dgamma, float* dbeta, float* c1, float* c2,
                                                               const float* __restrict__ mean, float* __restrict__ lin) {
-    reduce_partials_4ch(partials, P, C, blockIdx.x * 4, 0, 0, [&](int c, double s, double q) {
+    reduce_partials_4ch<NT>(partials, P, C, blockIdx.x * 4, 0, 0, [&](int c, double s, double q) {
         if (dbeta) dbeta[c] = (float)s;
         if (dgamma) dgamma[c] = (float)q;
         const float f1 = (float)(s / count), f2 = (float)(q / count);
@@ -516,7 +529,10 @@ extern "C" int sh_bn_bwd_finalize(const float* partials, int n_partials, int C, 
                                   double count, float* dgamma, float* dbeta, float* c1, float* c2, const float* mean, float* lin,
                                   void* stream) {
     if (!partials || n_partials <= 0 || C <= 0 || count <= 0 || !c1 || !c2 || (lin && (!mean || !invstd))) return SH_EINVAL;
-    bn_bwd_finalize_kernel<<<(unsigned)sh_cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(partials, n_partials, C, gamma, invstd, count, dgamma, dbeta, c1, c2, mean, lin);
+    if (n_partials >= 1024)
+        bn_bwd_finalize_kernel<1024><<<(unsigned)sh_cdiv(C, 4), 1024, 0, (hipStream_t)stream>>>(partials, n_partials, C, gamma, invstd, count, dgamma, dbeta, c1, c2, mean, lin);
+    else
+        bn_bwd_finalize_kernel<256><<<(unsigned)sh_cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(partials, n_partials, C, gamma, invstd, count, dgamma, dbeta, c1, c2, mean, lin);
     return sh_launch_status();
 }
 
