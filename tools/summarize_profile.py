@@ -52,3 +52,12 @@ json.dump({"csrc_sha": _h.hexdigest()[:12], "source": f"rocprofv3 --pmc FETCH_SI
                      "(gfx950 wide-read correction), KiB -> bytes", "per_kernel_family": top}, open(f"profiles/{tag}_hbm_traffic.json", "w"), indent=1)
 for fam, d in list(top.items())[:14]:
     print(f"{fam:28s} launches/step {d['launches_per_step']:6.1f}  read {d['hbm_read_bytes_per_step']/1e9:7.2f} GB  write {d['hbm_write_bytes_per_step']/1e9:7.2f} GB")
+
+# the north-star unit's own trace (tools/profile_round.sh step 4), if it was taken
+import os
+au = glob.glob(f"{src}/aspp/*/*_kernel_stats.csv")
+if au:
+    shutil.copy(au[0], f"profiles/{tag}_aspp_unit_kernel_stats.csv")
+    if os.path.exists(f"gpurun_out/aspp_unit_{tag}.json"):
+        txt = open(f"gpurun_out/aspp_unit_{tag}.json").read()
+        open(f"profiles/{tag}_aspp_unit.json", "w").write(txt[txt.index("{"):])
