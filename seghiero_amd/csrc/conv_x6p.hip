@@ -20,7 +20,11 @@
 // Tried and dropped (round 2): B fragments straight from pre-split, fragment-ordered bf16 weight planes in global memory (no split, no
 // LDS image, no staging registers for B; bit-identical results).  Each wave then fetches its own 6 x 1 KiB of fragments per phase --
 // 3x the L2 -> CU bytes of the fp32 tile staged once per block -- and the vector-memory path becomes the limit: fprop 512->512
-// @16x128^2 1016 vs 714 us, step 34.7 vs 33.8 ms.  (A timing build that merely skipped the B split ran fprop / dgrad 6 % faster.)
+// @16x128^2 1016 vs 714 us, step 34.7 vs 33.8 ms.  The same planes staged through LDS like the fp32 tile (three 16-byte loads and
+// ds_write_b128 per thread instead of two loads, the split and six ds_write_b64; bit-identical): dgrad -3 %, fprop +3.7 %, step
+// 34.2 vs 33.9 ms with the per-step pack kernel -- also dropped.  (A timing build that merely skipped the B split, with the fp32
+// loads unchanged, ran fprop / dgrad 6 % faster: the loop is balanced across VALU, LDS and vector memory, and moving work from one
+// to another does not shorten it.)
 //
 // Fused BatchNorm hooks (the reason the loaders go through registers at all):
 //   AFF : A operand = relu(x * scale[c] + shift[c]) applied in the loader -- the producer's train-mode BatchNorm + ReLU
