@@ -64,9 +64,10 @@ def _stage(kind, cin, width, n, stride):
 
 
 # Residual-block form of the fused BatchNorm backward (the next block's first dgrad epilogue masks with this block's output and
-# emits its bn3 statistics).  Measured at the headline shape: the short-K 1x1 dgrads of layer1 / layer2 are epilogue-bound, three
-# extra tile reads there cost more (+1.6 ms of dgrad) than the statistics pass they replace (-0.7 ms) -- off by default.
-BNB_RESIDUAL = __import__("os").environ.get("SEGHIERO_BNB_RESIDUAL", "0") != "0"
+# emits its bn3 statistics).  Measured at the headline shape (same-box A/B): while the epilogue spilled 85 registers this cost more
+# (+1.6 ms of dgrad) than the statistics pass it replaces (-0.7 ms); with the epilogue processed in row-group chunks (no spills) it
+# wins: dgrad +0.6 ms, statistics pass -1.0 ms, step 33.94 -> 33.45 ms -- on by default.
+BNB_RESIDUAL = __import__("os").environ.get("SEGHIERO_BNB_RESIDUAL", "1") != "0"
 
 
 # ----------------------------------------------------------------------------- hand-scheduled fwd / bwd

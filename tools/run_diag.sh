@@ -1,8 +1,11 @@
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_ops_gpu.py -x -q -m gpu > gpurun_out/gputest_diag36.log 2>&1; echo "tests exit $?"; tail -5 gpurun_out/gputest_diag36.log
-for i in 1 2 3; do
-python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-units 2>/dev/null | cut -c100-200 | sed 's/^/new /'
-(cd .ab_old && python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-units 2>/dev/null | cut -c100-200 | sed 's/^/old /')
+for i in 1 2; do
+python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-units 2>/dev/null | cut -c100-200 | sed 's/^/base /'
+SEGHIERO_BNB_RESIDUAL=1 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-units 2>/dev/null | cut -c100-200 | sed 's/^/resid /'
 done
-python tools/shape_table.py > gpurun_out/shape_table_new.txt 2>&1
-(cd .ab_old && python tools/shape_table.py > ../gpurun_out/shape_table_old.txt 2>&1)
+SEGHIERO_BNB_RESIDUAL=1 python - <<'PY'
+import json,subprocess,sys
+out=subprocess.run([sys.executable,"bench.py","--steps","20","--warmup","3","--no-cpu-baseline","--no-units"],capture_output=True,text=True).stdout
+d=json.loads(out.strip().splitlines()[-1])
+for k,v in d["kernel_ms_per_step"].items(): print(k,v)
+PY
