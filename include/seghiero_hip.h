@@ -366,11 +366,13 @@ int64_t sh_rmi_workspace(int N, int C, int H, int W);
 int64_t sh_rmi_values_offset(int N, int C, int H, int W);
 int sh_rmi_loss(const float* probs, const uint8_t* labels, const int* f2m_host, const int* f2h_host, int n_fine, int n_mid,
                 int n_high, void* workspace, float* rmi_out, float* dprob, int N, int H, int W, void* stream);
-/* dlogits [N,h,w,lddl] <- gscale*gscale_dev[0] * d(loss_out + rmi_coef * <dprob, P>)/d(logits)  (tiled gather form). */
+/* dlogits [N,h,w,lddl] <- gscale*gscale_dev[0] * d(loss_out + rmi_coef * <dprob, P>)/d(logits)  (tiled gather form; with a
+ * workspace of sh_loss_bwd_workspace(N,H,W,lddl) bytes and upsampled logits: the two streaming passes of sh_hiera2_loss_bwd,
+ * bit-identical). */
 int sh_hiera3_loss_bwd(const float* logits, int ldl, const uint8_t* labels, const int* f2m_host, const int* f2h_host,
                        int n_fine, int n_mid, int n_high, const double* sums, const float* dprob, float rmi_coef,
                        const float* gscale_dev, float gscale, float* dlogits, int lddl, int N, int h, int w, int H, int W,
-                       void* stream);
+                       float* workspace, int64_t workspace_bytes, void* stream);
 /* out = (a + alpha*b[0]) -- device scalar combine used for lambda*rmi + rest. */
 int sh_scalar_axpy(const float* a, const float* b, float alpha, float* out, void* stream);
 

@@ -456,6 +456,14 @@ __global__ __launch_bounds__(256) void resize_adjoint_gather_kernel(const float*
         st4(dlogits + ((n * h + iy) * w + ix) * L + 4 * cq, acc);
     }
 }
+int sh_launch_resize_adjoint_gather(const float* gfull, float* dlogits, int lddl, int N, int h, int w, int H, int W, hipStream_t st) {
+    const long long low = (long long)N * h * w * (lddl / 4);
+    long long gb = sh_cdiv(low, 256);
+    if (gb > 16384) gb = 16384;
+    resize_adjoint_gather_kernel<<<(unsigned)gb, 256, 0, st>>>(gfull, dlogits, lddl, h, w, H, W, (float)h / (float)H, (float)w / (float)W, low,
+                                                               nullptr, 1.f, 0);
+    return sh_launch_status();
+}
 // the backward when the forward already left the per-pixel gradient (unit upstream gradient) in the workspace
 static int launch_gather_from_grad(const float* gfull, const float* gscale_dev, float gscale, float* dlogits, int lddl, int N, int h, int w,
                                    int H, int W, hipStream_t st) {

@@ -502,6 +502,49 @@ __global__ __launch_bounds__(256) void rmi_dprob_kernel(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------ two-pass backward, pass A
+// every full-resolution pixel's gradient w.r.t. its (interpolated) logits, once, to gfull [N*H*W][L] (as loss_grad_fullres_kernel of
+// the 2-level loss; pass B = the shared resize-adjoint gather) -- the tile kernel below recomputes a halo per 80 KB LDS tile
+template <int MAXC>
+__global__ __launch_bounds__(256) void hiera3_grad_fullres_kernel(const float* __restrict__ logits, long long ldl, const uint8_t* __restrict__ labels,
+                                                                  const H3Tab T, const double* __restrict__ sums, const float* __restrict__ dprob,
+                                                                  float rmi_coef, const float* __restrict__ gscale_dev, float gscale,
+                                                                  float* __restrict__ gfull, int L, int h, int w, int H, int W, float sy, float sx,
+                                                                  long long total) {
+    const int C = T.nf + T.nm + T.nh;
+    const bool identity = (h == H && w == W);
+    const float gs = gscale * (gscale_dev ? gscale_dev[0] : 1.f);
+    const double nv = sums[6] < 1.0 ? 1.0 : sums[6];
+    const float a0 = gs * 0.5f * (float)(5.0 / (nv * T.nf)), a1 = gs * 0.5f * (float)(5.0 / (nv * T.nm)), a2 = gs * 0.5f * (float)(5.0 / (nv * T.nh));
+    const float b = gs * (float)(1.0 / sums[7]);
+    const float rc = gs * rmi_coef;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        float g[MAXC];
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j) g[j] = 0.f;
+        const int f = labels[i];
+        if (f != IGN) {
+            const int ox = (int)(i % W);
+            const long long q = i / W;
+            const int oy = (int)(q % H);
+            const long long n = q / H;
+            const Lerp ly = lerp_src(oy, sy, h), lx = lerp_src(ox, sx, w);
+            float z[MAXC], o[6];
+            fetch_logits<MAXC>(logits + n * h * w * ldl, ldl, w, ly, lx, identity, C, z);
+            hiera3_pixel<MAXC, true>(z, f, T, a0, a1, a2, b, o, g);
+            if (dprob != nullptr) {          // RMI: dL/dz = dL/dP * valid * sigmoid'(z)   (the tile kernel's own expression)
+#pragma unroll
+                for (int j = 0; j < MAXC; ++j)
+                    if (j < C) { const float pj = sigmoidf_(z[j]); g[j] += rc * dprob[((n * C + j) * H + oy) * W + ox] * pj * (1.f - pj); }
+            }
+        }
+        float* dst = gfull + i * L;
+#pragma unroll
+        for (int j = 0; j < MAXC; j += 4)
+            if (j < L) st4(dst + j, f32x4{g[j], g[j + 1], g[j + 2], g[j + 3]});
+    }
+}
+
 // ------------------------------------------------------------------------------------------ tiled backward
 template <int MAXC>
 __global__ __launch_bounds__(256) void hiera3_bwd_tile_kernel(const float* __restrict__ logits, long long ldl, const uint8_t* __restrict__ labels,
@@ -665,11 +708,28 @@ static int pick_tile3(int h, int w, int H, int W, int C, int budget_bytes, int& 
 // d/dlogits of  gscale*gscale_dev[0] * ( 0.5*hiera3 + ce_f + ce_m + ce_h + rmi_coef * sum_pixels dprob*dP/dz ), into [N,h,w,lddl]
 extern "C" int sh_hiera3_loss_bwd(const float* logits, int ldl, const uint8_t* labels, const int* f2m_host, const int* f2h_host, int n_fine,
                                   int n_mid, int n_high, const double* sums, const float* dprob, float rmi_coef, const float* gscale_dev,
-                                  float gscale, float* dlogits, int lddl, int N, int h, int w, int H, int W, void* stream) {
+                                  float gscale, float* dlogits, int lddl, int N, int h, int w, int H, int W, float* workspace,
+                                  int64_t workspace_bytes, void* stream) {
     H3Tab T;
     if (!logits || !labels || !sums || !dlogits || N <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || h > H || w > W) return SH_EINVAL;
     const int C = n_fine + n_mid + n_high;
     if (!make_tab3(T, f2m_host, f2h_host, n_fine, n_mid, n_high) || ldl < C || lddl < C || lddl > 32) return SH_EINVAL;
+    if (workspace && workspace_bytes >= (int64_t)N * H * W * lddl * 4 && (h < H || w < W) && (lddl & 3) == 0 &&
+        (((uintptr_t)workspace | (uintptr_t)dlogits) & 15) == 0) {
+        // two streaming passes (see sh_hiera2_loss_bwd): same arithmetic and summation order as the tile kernel => bit-identical
+        const long long full = (long long)N * H * W;
+        long long ga = sh_cdiv(full, 256);
+        if (ga > 16384) ga = 16384;
+        const float sy2 = (float)h / (float)H, sx2 = (float)w / (float)W;
+        hipStream_t st2 = (hipStream_t)stream;
+        if (C <= 16 && lddl <= 16)
+            hiera3_grad_fullres_kernel<16><<<(unsigned)ga, 256, 0, st2>>>(logits, ldl, labels, T, sums, dprob, rmi_coef, gscale_dev, gscale, workspace, lddl, h, w, H, W, sy2, sx2, full);
+        else
+            hiera3_grad_fullres_kernel<32><<<(unsigned)ga, 256, 0, st2>>>(logits, ldl, labels, T, sums, dprob, rmi_coef, gscale_dev, gscale, workspace, lddl, h, w, H, W, sy2, sx2, full);
+        const int rc2 = sh_launch_status();
+        if (rc2 != SH_OK) return rc2;
+        return sh_launch_resize_adjoint_gather(workspace, dlogits, lddl, N, h, w, H, W, st2);
+    }
     int region = 0;
     const int TL = pick_tile3(h, w, H, W, C, 80 * 1024, region);
     if (TL <= 0) return SH_EINVAL;

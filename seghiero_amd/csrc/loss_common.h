@@ -81,6 +81,9 @@ __device__ __forceinline__ void fetch_logits(const float* __restrict__ base, lon
     }
 }
 
+// loss.hip: adjoint of the bilinear resize as a gather from a full-resolution gradient [N*H*W][lddl] (not scaled)
+int sh_launch_resize_adjoint_gather(const float* gfull, float* dlogits, int lddl, int N, int h, int w, int H, int W, hipStream_t st);
+
 // log-softmax CE of z[off..off+n) against target tgt: returns -log p_tgt; optionally adds coef*(softmax - onehot) to g
 template <int MAXC, bool GRAD>
 __device__ __forceinline__ float softmax_ce(const float (&z)[MAXC], int off, int n, int tgt, float coef, float (&g)[MAXC]) {

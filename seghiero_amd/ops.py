@@ -1127,9 +1127,10 @@ def hiera3_bwd(logits, labels8, n_fine, n_mid, n_high, f2m, f2h, sums, dprob, rm
     lp, ldl = pm(logits)
     d = new_act(n, c, h, w, logits.device, ld=pad4(c))
     dp, ldd = pm(d)
+    ws, nb = _loss_bwd_ws(n, h, w, H, W, ldd, logits.device)
     _call("sh_hiera3_loss_bwd", lp, ldl, labels8.data_ptr(), _ints(f2m), _ints(f2h), n_fine, n_mid, n_high, sums.data_ptr(),
           None if dprob is None else dprob.data_ptr(), float(rmi_coef), None if gscale_dev is None else gscale_dev.data_ptr(),
-          float(gscale), dp, ldd, n, h, w, H, W, _st())
+          float(gscale), dp, ldd, n, h, w, H, W, ws, nb, _st())
     return d
 
 

@@ -304,6 +304,25 @@ def test_rmi_loss_fused_resize_matches_oracle(sa):
     close(eg.grad, er.grad, 1e-4, 1e-8)
 
 
+@pytest.mark.parametrize("lam", [0.0, 0.5])
+def test_three_level_backward_two_pass_equals_tile_kernel(sa, lam, monkeypatch):
+    """sh_hiera3_loss_bwd with a workspace (full-resolution gradient once, then the resize-adjoint gather) against the LDS-tile
+    kernel on the same inputs: same arithmetic, same summation order -- bit-identical."""
+    _, loss, ops = sa
+    g = torch.Generator().manual_seed(31)
+    z = 1.5 * torch.randn(2, 12, 24, 20, generator=g)
+    e = F.normalize(torch.randn(2, 16, 6, 5, generator=g), dim=1)
+    label = _blocky(g, 2, 96, 80, 7, cell=8)
+    grads = []
+    for two_pass in (True, False):
+        monkeypatch.setattr(ops, "LOSS_BWD_TWO_PASS", two_pass)
+        zg = z.to(DEV).requires_grad_(True)
+        fn = loss.RMIHieraTripletLoss(7, 3, 2, torch.tensor(F2M), torch.tensor(F2H), loss_weight_lambda=lam).to(DEV)
+        fn(20000, e.to(DEV), None, zg, label.to(DEV)).backward()
+        grads.append(zg.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+
+
 def test_rmi_loss_wide_image_matches_oracle(sa):
     """Several 64-column strips and 64-row chunks of Gram partials, and dprob blocks away from / at every border:
     full-resolution logits (identity resize) at 140 x 200 against the oracle."""
