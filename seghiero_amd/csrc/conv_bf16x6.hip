@@ -881,9 +881,11 @@ int sh_x6_splitk_reduce(const ConvQ& p, int mode, hipStream_t st) {
 static int splitk_plan(long long M, long long N, long long K, int parity, int scatter) {
     if (parity || scatter || (N & 3)) return 1;
     const long long tiles = sh_cdiv(M, 128) * sh_cdiv(N, 128), nkt = sh_cdiv(K, 32);
-    if (tiles >= 384 || nkt < 32) return 1;
-    long long S = sh_cdiv(512, tiles);
-    if (S > nkt / 16) S = nkt / 16;          // >= 16 K tiles per slice
+    static int target = 0, minkt = 0;
+    if (!target) { const char* e = getenv("SEGHIERO_SK_TARGET"); target = e ? atoi(e) : 512; e = getenv("SEGHIERO_SK_MINKT"); minkt = e ? atoi(e) : 16; }
+    if (tiles >= (target * 3) / 4 || nkt < 2 * minkt) return 1;
+    long long S = sh_cdiv(target, tiles);
+    if (S > nkt / minkt) S = nkt / minkt;    // >= minkt K tiles per slice
     if (S > 8) S = 8;
     return S < 2 ? 1 : (int)S;
 }
