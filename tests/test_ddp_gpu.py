@@ -15,16 +15,17 @@ HEAD_KW = dict(in_channels=512, c1_in_channels=64, c1_channels=16, aspp_channels
 B, S = 4, 96
 
 
-def _run(lo, hi, sync):
-    """forward/backward of R18 trunk + head on images [lo, hi) of the fixed seeded batch"""
+def _run(lo, hi, sync, depth=18, B=B, S=S):
+    """forward/backward of the ResNet-`depth` trunk + head on images [lo, hi) of the fixed seeded batch"""
     from seghiero_amd import ops
     from seghiero_amd.backbone import ResNetBackbone
     from seghiero_amd.head import DepthwiseSeparableASPPContrastHead
     ops.SYNC_BN = sync
     torch.manual_seed(0)
     dev = torch.device("cuda", torch.cuda.current_device())
-    bb = ResNetBackbone(depth=18).to(dev).train()
-    head = DepthwiseSeparableASPPContrastHead(**HEAD_KW).to(dev).train()
+    bb = ResNetBackbone(depth=depth).to(dev).train()
+    kw = dict(HEAD_KW) if depth < 50 else dict(HEAD_KW, in_channels=2048, c1_in_channels=256)
+    head = DepthwiseSeparableASPPContrastHead(**kw).to(dev).train()
     g = torch.Generator().manual_seed(7)
     x = torch.randn(B, 3, S, S, generator=g)
     x = x[lo:hi].to(dev)                                         # the trunk never differentiates the image (stem dgrad skipped)
@@ -36,7 +37,55 @@ def _run(lo, hi, sync):
     named = list(bb.named_parameters()) + list(head.named_parameters())
     return dict(logits=logits.detach().cpu().numpy(), emb=emb.detach().cpu().numpy(),
                 grads={k: p.grad.detach().cpu().numpy().copy() for k, p in named if p.grad is not None},
-                rm=bb.layer4[1].bn2.running_mean.cpu().numpy(), rv=head.sep_bottleneck[1].bn_pw.running_var.cpu().numpy())
+                rm=bb.layer4[1].bn2.running_mean.cpu().numpy(), rv=head.sep_bottleneck[1].bn_pw.running_var.cpu().numpy(),
+                rm1=bb.layer1[0].bn3.running_mean.cpu().numpy() if depth >= 50 else None)
+
+
+def _run_blocks(lo, hi, sync):
+    """Bottleneck blocks of ResNet-50 ALONE (layer1.1: identity shortcut; layer2.0: stride-2 downsample branch), forward and
+    hand-scheduled backward on images [lo, hi) of a fixed batch: the paths a whole random ResNet-50 is too ill-conditioned to
+    pin -- BatchNorm + ReLU in the conv loaders, dgrad-epilogue statistics, the deferred BatchNorm-backward apply (conv3, width >= 16)
+    with its coefficients from the all-reduced sums."""
+    from seghiero_amd import layers as L, ops
+    from seghiero_amd.backbone import ResNetBackbone, _block_bwd, _block_fwd
+    ops.SYNC_BN = sync
+    torch.manual_seed(3)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    bb = ResNetBackbone(depth=50, pretrained=False).to(dev).train()
+    for m in bb.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            torch.nn.init.uniform_(m.weight, 0.5, 1.5)
+            torch.nn.init.normal_(m.bias, 0.0, 0.2)
+    g = torch.Generator().manual_seed(11)
+    out = {}
+    for name, blk, cin, hw in (("l1.1", bb.layer1[1], 256, 32), ("l2.0", bb.layer2[0], 256, 32)):
+        x = torch.randn(B, cin, hw, hw, generator=g)
+        y, saved = _block_fwd(blk, ops.to_nhwc(x[lo:hi].to(dev)), True)
+        dout = torch.randn(B, *y.shape[1:], generator=g)
+        gm = L.GradMap()
+        dx = _block_bwd(blk, saved, L.grad_as_nhwc_padded(dout[lo:hi].to(dev), y.shape[1]), gm)
+        ops.join_wgrad()
+        torch.cuda.synchronize()
+        out[name] = dict(y=y.cpu().numpy(), dx=dx.cpu().numpy(),
+                         grads={k: gm.g[id(p)].reshape(p.shape).cpu().numpy().copy() for k, p in blk.named_parameters()},
+                         rm=blk.bn3.running_mean.cpu().numpy())
+    return out
+
+
+def _block_worker(rank, world, port, q, cuts):
+    _env(rank, world, port, "gloo")
+    import torch.distributed as dist
+    from seghiero_amd import ddp
+    ddp.init_from_env(backend="gloo")
+    try:
+        out = _run_blocks(cuts[rank], cuts[rank + 1], sync=True)
+    except Exception as e:
+        import traceback
+        out = "rank %d failed: %s\n%s" % (rank, e, traceback.format_exc())
+    q.put((rank, out))
+    if not isinstance(out, str):
+        dist.barrier()
+    dist.destroy_process_group()
 
 
 def _backends():
@@ -52,14 +101,14 @@ def _env(rank, world, port, backend):
         torch.cuda.set_device(rank)
 
 
-def _worker(rank, world, port, q, backend="gloo", cuts=None):
+def _worker(rank, world, port, q, backend="gloo", cuts=None, depth=18, batch=B, size=S):
     _env(rank, world, port, backend)
     import torch.distributed as dist
     from seghiero_amd import ddp
     ddp.init_from_env(backend=backend)
-    cuts = cuts or [r * (B // world) for r in range(world + 1)]
+    cuts = cuts or [r * (batch // world) for r in range(world + 1)]
     try:
-        out = _run(cuts[rank], cuts[rank + 1], sync=True)
+        out = _run(cuts[rank], cuts[rank + 1], sync=True, depth=depth, B=batch, S=size)
     except Exception as e:                                       # report instead of leaving the parent to time out
         import traceback
         out = "rank %d failed: %s\n%s" % (rank, e, traceback.format_exc())
@@ -74,10 +123,12 @@ def _rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
-@pytest.mark.parametrize("backend,cuts", [("gloo", None), ("gloo", [0, 3, 4]), ("nccl", None)])
-def test_syncbn_two_ranks_equals_full_batch(backend, cuts):
+@pytest.mark.parametrize("backend,cuts,depth", [("gloo", None, 18), ("gloo", [0, 3, 4], 18), ("nccl", None, 18)])
+def test_syncbn_two_ranks_equals_full_batch(backend, cuts, depth):
     """cuts = [0, 3, 4]: rank 0 holds three images and rank 1 one -- the pixel counts travel with the sums, so uneven
-    shards give the full-batch statistics too."""
+    shards give the full-batch statistics too.  (A randomly initialised ResNet-50 amplifies a 1e-6 relative perturbation of its
+    input to 5 % of its parameter gradients at any batch / image size -- tests/diag/sens50.py -- so the Bottleneck paths are
+    checked block by block: test_syncbn_bottleneck_blocks_two_ranks.)"""
     if not torch.cuda.is_available():
         pytest.skip("needs the MI355X")
     if backend not in _backends():
@@ -85,8 +136,8 @@ def test_syncbn_two_ranks_equals_full_batch(backend, cuts):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29800 + os.getpid() % 150 + (3 if cuts else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend, cuts)) for r in range(2)]
+    port = 29800 + os.getpid() % 150 + (3 if cuts else 0) + (7 if depth >= 50 else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend, cuts, depth)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=240) for _ in procs)
@@ -94,12 +145,12 @@ def test_syncbn_two_ranks_equals_full_batch(backend, cuts):
         p.join(60)
     for r in res.values():
         assert not isinstance(r, str), r
-    full = _run(0, B, sync=False)
+    full = _run(0, B, sync=False, depth=depth)
     for k in ("logits", "emb"):
         got = np.concatenate([res[0][k], res[1][k]], 0)
         assert _rel(got, full[k]) < 2e-4, k          # fp32 sums in a different order; conv itself is the same arithmetic
     # running statistics use the global batch on every rank
-    for k in ("rm", "rv"):
+    for k in ("rm", "rv") + (("rm1",) if depth >= 50 else ()):
         np.testing.assert_allclose(res[0][k], res[1][k], rtol=0, atol=0)
         np.testing.assert_allclose(res[0][k], full[k], rtol=1e-4, atol=1e-6)
     assert set(res[0]["grads"]) == set(full["grads"])
@@ -225,3 +276,33 @@ def test_rccl_backend_world1_runs_every_collective_of_the_step():
     np.testing.assert_allclose(l3, losses, rtol=2e-5)
     tot = _rel(np.concatenate([a.ravel() for a in p3]), np.concatenate([b.ravel() for b in params]))
     assert tot < 1e-4, tot
+
+
+@pytest.mark.parametrize("cuts", [[0, 2, 4], [0, 1, 4]])
+def test_syncbn_bottleneck_blocks_two_ranks(cuts):
+    """SyncBN through the fused Bottleneck paths (see _run_blocks): two ranks with 2 + 2 or 1 + 3 images reproduce the single-rank
+    full batch -- outputs, input gradients (per-image rows), summed parameter gradients, running statistics."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 150 + cuts[1]
+    procs = [ctx.Process(target=_block_worker, args=(r, 2, port, q, cuts)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+    for r in res.values():
+        assert not isinstance(r, str), r
+    full = _run_blocks(0, B, sync=False)
+    for name in full:
+        for k in ("y", "dx"):
+            got = np.concatenate([res[0][name][k], res[1][name][k]], 0)
+            assert _rel(got, full[name][k]) < 2e-5, (name, k, _rel(got, full[name][k]))
+        np.testing.assert_allclose(res[0][name]["rm"], res[1][name]["rm"], rtol=0, atol=0)
+        np.testing.assert_allclose(res[0][name]["rm"], full[name]["rm"], rtol=1e-4, atol=1e-6)
+        for k, want in full[name]["grads"].items():
+            e = _rel(res[0][name]["grads"][k] + res[1][name]["grads"][k], want)
+            assert e < 2e-4, (name, k, e)

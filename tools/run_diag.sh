@@ -1,4 +1,2 @@
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu | tail -2
-bash tests/diag/run2ranks.sh 2>&1 | tail -12
-BENCH_EXTRA=--syncbn bash tests/diag/run2ranks.sh 2>&1 | tail -6
+timeout -k 10 900 python -m pytest tests/test_ddp_gpu.py -x -q -m gpu > gpurun_out/ddpblk.log 2>&1; tail -25 gpurun_out/ddpblk.log | cut -c1-250
