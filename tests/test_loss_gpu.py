@@ -237,8 +237,8 @@ F2M, F2H = [0, 1, 1, 1, 1, 2, 2], [0, 1, 1, 1, 1, 1, 1]
 @pytest.mark.parametrize("lam", [0.0, 0.5])
 @pytest.mark.parametrize("step", [0, 30000])
 def test_rmi_hiera_triplet_loss_g6(sa, tag, lam, step):
-    """Loss rtol 1e-5; gradient w.r.t. the logits rtol 2e-3 of the tensor's max (f64 Gram matrices are near-singular and
-    the reference differentiates through log(diag(chol)+1e-8) while the kernel uses the closed form)."""
+    """Loss rtol 1e-5; gradient w.r.t. the logits within 1e-5 of the tensor's max (measured: 2.4e-7, tests/diag/rmi_dz_err.py -- the
+    reference differentiates through log(diag(chol)+1e-8) while the kernel uses the closed form; both in f64)."""
     _, loss, ops = sa
     g = load_golden("g6_rmi_hiera_triplet_loss")
     fn = loss.RMIHieraTripletLoss(7, 3, 2, torch.tensor(F2M), torch.tensor(F2H), loss_weight_lambda=lam).to(DEV)
@@ -249,7 +249,7 @@ def test_rmi_hiera_triplet_loss_g6(sa, tag, lam, step):
     key = f"{tag}_lam{lam}_s{step}"
     close(val, g[f"{key}_loss"], 1e-5, 0)
     ref = g[f"{key}_dz"]
-    np.testing.assert_allclose(z.grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * float(np.abs(ref).max()))
+    np.testing.assert_allclose(z.grad.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * float(np.abs(ref).max()))
     close(e.grad, g[f"{key}_demb"], 1e-4, 1e-8)
 
 
@@ -300,7 +300,7 @@ def test_rmi_loss_fused_resize_matches_oracle(sa):
     val.backward()
     close(val, ref, 1e-5, 0)
     r = zr.grad.numpy()
-    np.testing.assert_allclose(zg.grad.cpu().numpy(), r, rtol=2e-3, atol=2e-3 * float(np.abs(r).max()))
+    np.testing.assert_allclose(zg.grad.cpu().numpy(), r, rtol=1e-3, atol=1e-4 * float(np.abs(r).max()))
     close(eg.grad, er.grad, 1e-4, 1e-8)
 
 
@@ -340,4 +340,4 @@ def test_rmi_loss_wide_image_matches_oracle(sa):
     val.backward()
     close(val, ref, 1e-5, 0)
     r = zr.grad.numpy()
-    np.testing.assert_allclose(zg.grad.cpu().numpy(), r, rtol=2e-3, atol=2e-3 * float(np.abs(r).max()))
+    np.testing.assert_allclose(zg.grad.cpu().numpy(), r, rtol=1e-3, atol=1e-4 * float(np.abs(r).max()))
