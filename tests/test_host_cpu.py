@@ -50,6 +50,29 @@ def test_abi_rejects_bad_arguments_without_launching(built):
     assert LIB.raw("sh_resize_bilinear_coeffs")(0, 8, None, None, 0) < 0
 
 
+def test_header_is_plain_c_and_links_from_c(built, tmp_path):
+    """include/seghiero_hip.h is the boundary a non-Python host binds: it must compile as C99 and as C++, and a C program that
+    takes the address of entry points must link against the shared library (no C++ name mangling, no torch types)."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "include", "seghiero_hip.h")
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    subprocess.check_call(["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror", hdr])
+    subprocess.check_call(["g++", "-fsyntax-only", "-x", "c++", hdr])
+    src = tmp_path / "host.c"
+    src.write_text('#include "seghiero_hip.h"\n#include <stdio.h>\n'
+                   'int main(void) { void* f[] = {(void*)sh_conv_fprop_x6, (void*)sh_conv_dgrad_x6_lin, (void*)sh_hiera2_loss_fwd,\n'
+                   '                              (void*)sh_bn_finalize, (void*)sh_sgd_step};\n'
+                   '  printf("%d\\n", (int)(sizeof f / sizeof f[0]) + (sh_stats_tile_rows() > 0)); return 0; }\n')
+    lib = os.path.join(root, "seghiero_amd", "libseghiero_hip.so")
+    exe = tmp_path / "host"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.dirname(hdr), str(src), lib, "-o", str(exe), "-Wl,-rpath," + os.path.dirname(lib),
+                           "-Wl,--allow-shlib-undefined"])
+
+
 def test_hierarchy_helpers_bit_exact_vs_reference_golden(golden):
     import seghiero_amd as sa
     g = golden("g1_maps")
