@@ -717,8 +717,10 @@ class DeferredDy:
 
 DEFER_APPLY = os.environ.get("SEGHIERO_DEFER_APPLY", "1") != "0"     # BatchNorm-backward apply in the 1x1 consumers' loaders
 # The dgrad re-evaluates dy once per 128-column tile of its OUTPUT (Cin / 128 times), the apply pass once: deferring pays where the
-# dy tensor is wide and the dgrad output narrow (Bottleneck conv3: 4P -> P), not the other way round (conv1: P -> 4P)
-DEFER_RATIO = float(os.environ.get("SEGHIERO_DEFER_RATIO", "1"))
+# dy tensor is wide and the dgrad output narrow (Bottleneck conv3: 4P -> P), not the other way round (conv1: P -> 4P).  Deferred
+# when Cout * DEFER_RATIO >= Cin; measured (same-box A/B, ms per step): always 33.85, ratio 1 (also 512 -> 512) 33.7 / 34.0,
+# ratio 0.5 (Cout >= 2 Cin) 33.6 / 33.8 -- the two-stream loader costs the square pointwise convs what the apply pass saved.
+DEFER_RATIO = float(os.environ.get("SEGHIERO_DEFER_RATIO", "0.5"))
 
 
 def lin_ok(x_shape, weight, stride, pad, dil):
