@@ -92,7 +92,7 @@ int64_t sh_conv_x6_workspace(int which /* 0 fprop, 1 dgrad */, int N, int H, int
                              int stride, int pad, int dil, int dgrad_mode);
 int sh_conv_fprop_x6(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
                      float* stat_partials, int N, int H, int W, int Cin, int Cout, int KH, int KW,
-                     int stride, int pad, int dil, float* workspace, int64_t workspace_bytes, void* stream);
+                     int stride, int pad, int dil, float* workspace, int64_t workspace_bytes, int act_flags, void* stream);
 /* Inference forward with eval-mode BatchNorm (+ Bottleneck residual add) (+ ReLU) fused into the epilogue:
  * out = [relu]( conv(x, w) * scale[co] + shift[co] [+ residual] ), scale / shift from sh_bn_eval_coefs.  Same operation
  * order as sh_conv_fprop_x6 followed by sh_bn_act, so the result is bit-identical while y is never written or re-read. */
@@ -106,7 +106,8 @@ int sh_conv_fprop_x6_act(const float* x, int ldx, const float* w, const float* s
  * SH_EUNSUPPORTED = no fused instantiation for this geometry (run sh_bn_act, then sh_conv_fprop_x6). */
 int sh_conv_fprop_x6_aff(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* w,
                          const float* bias, float* y, int ldy, float* stat_partials, int N, int H, int W, int Cin, int Cout,
-                         int KH, int KW, int stride, int pad, int dil, float* workspace, int64_t workspace_bytes, void* stream);
+                         int KH, int KW, int stride, int pad, int dil, float* workspace, int64_t workspace_bytes, int act_flags,
+                         void* stream);
 /* ngroups (<= 6) pointwise convolutions of ONE geometry in one launch -- the ASPP branches of
  * models/head/sep_aspp_contrast_head.py:100-131 (the 1x1 branch + the pointwise convs of the three depthwise-separable branches):
  * group g: y[:, g*Cout:(g+1)*Cout] = conv1x1(in_g, w[g]), in_g = relu(x[g]*in_scale[g] + in_shift[g]) (the producer's BatchNorm +
@@ -137,7 +138,8 @@ int sh_conv_dgrad_x6_bnb(const float* dy, int lddy, const float* wt, const float
                          const float* y_prev, int ldyp, const float* out_prev, int ldop, const float* mean,
                          const float* invstd, const float* scale, const float* shift, int relu, float* stat_partials,
                          int N, int H, int W, int Cin, int Cout,
-                         int KH, int KW, int stride, int pad, int dil, float* workspace, int64_t workspace_bytes, void* stream);
+                         int KH, int KW, int stride, int pad, int dil, float* workspace, int64_t workspace_bytes, int act_flags,
+                         void* stream);
 /* Deferred BatchNorm-backward apply (1x1, stride 1): the gradient operand dy of a conv -> BN layer's conv is NOT stored; the loaders
  * evaluate dy = lin[0][c]*g + lin[1][c]*(y - lin[2][c]) + lin[3][c] (= gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)), the second
  * half of torch.nn.BatchNorm2d's backward, coefficients from sh_bn_bwd_finalize) from the masked gradient g and the raw conv output
@@ -148,20 +150,20 @@ int sh_conv_dgrad_x6_bnb(const float* dy, int lddy, const float* wt, const float
 int sh_conv_dgrad_x6_lin(const float* g, int ldg, const float* y, int ldy, const float* lin, const float* wt, const float* addend,
                          int ldadd, float* dx, int lddx, const float* y_prev, int ldyp, const float* mean, const float* invstd,
                          const float* scale, const float* shift, int relu, float* stat_partials, int N, int H, int W, int Cin,
-                         int Cout, float* workspace, int64_t workspace_bytes, void* stream);
+                         int Cout, float* workspace, int64_t workspace_bytes, int act_flags, void* stream);
 int sh_conv_wgrad_x6_lin(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* g, int ldg,
                          const float* y, int ldy, const float* lin, float* dw, float* workspace, int N, int H, int W, int Cin,
-                         int Cout, int KH, int KW, int stride, int pad, int dil, void* stream);
+                         int Cout, int KH, int KW, int stride, int pad, int dil, int act_flags, void* stream);
 int64_t sh_conv_wgrad_x6_workspace(int N, int H, int W, int Cin, int Cout, int KH, int KW,
                                    int stride, int pad, int dil);
 int sh_conv_wgrad_x6(const float* x, int ldx, const float* dy, int lddy, float* dw, float* workspace,
                      int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                     int dil, void* stream);
+                     int dil, int act_flags, void* stream);
 /* ... of a conv whose input is read through the producer's BatchNorm + ReLU (see sh_conv_fprop_x6_aff): x = raw output of
  * the previous convolution, loader applies relu(x * in_scale[c] + in_shift[c]).  SH_EUNSUPPORTED: output width < 16. */
 int sh_conv_wgrad_x6_aff(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* dy, int lddy,
                          float* dw, float* workspace, int N, int H, int W, int Cin, int Cout, int KH, int KW,
-                         int stride, int pad, int dil, void* stream);
+                         int stride, int pad, int dil, int act_flags, void* stream);
 
 /* depthwise 3x3 (groups = C), stride 1, padding = dilation ---------------------------------- */
 /* Replaces DepthwiseSeparableConv.depthwise (models/head/sep_aspp_contrast_head.py:43-46, :56).
@@ -189,6 +191,16 @@ int sh_dwconv_wgrad(const float* x, int ldx, const float* in_scale, const float*
                     const float* y_lin, int ldyl, const float* lin, float* dw_partials, float* dw, int N, int H, int W, int C, int dil,
                     void* stream);
 
+/* bf16 ACTIVATION STORAGE (BASELINE configs[4]).  Raw conv outputs and block outputs may be stored as bf16 -- half the HBM bytes of the
+ * streaming kernels and of the HBM-bound layer-1 convolutions; all arithmetic, the BatchNorm statistics (taken from the fp32
+ * accumulators before the rounding) and every gradient stay fp32.  Entry points that can take such tensors have an `int act_flags`
+ * bit mask (bit i set = the i-th activation tensor named in that entry point's comment is bf16; 0 = everything fp32); a pointer to
+ * a bf16 tensor is passed as `const float*` / `float*`, its pixel stride counts ELEMENTS, 16-byte layouts only
+ * (SH_EUNSUPPORTED otherwise).
+ *   sh_bn_act: bit 0 y, 1 residual, 2 out.   sh_bn_bwd_reduce / sh_bn_bwd_apply: bit 0 y, 1 out.   sh_maxpool_fwd: bit 0 x, 1 y.
+ *   sh_conv_fprop_x6 / _aff: bit 0 x, 1 y (statistics from the fp32 accumulators).   sh_conv_dgrad_x6_bnb: bit 0 y_prev, 1 out_prev.
+ *   sh_conv_dgrad_x6_lin: bit 0 y, 1 y_prev.   sh_conv_wgrad_x6 / _aff: bit 0 x.   sh_conv_wgrad_x6_lin: bit 0 x, 1 y (x bf16 => y bf16).
+ * Gradients (dy, g, dx, dW), weights, coefficient tables and statistics partials are always fp32. */
 /* batch norm ------------------------------------------------------------------------------ */
 /* Train-mode nn.BatchNorm2d (every BN of the path; math: SURVEY A.2).  Combines the centred stat partials
  * (sum, M2 over rows_per_partial rows each; count = total rows) in f64, writes mean/invstd/scale/shift and
@@ -245,7 +257,7 @@ int sh_channel_stats(const float* y, int ldy, int64_t M, int C, float* partials,
  * so the downsample branch of torchvision's Bottleneck / BasicBlock never materialises its normalised output. */
 int sh_bn_act(const float* y, int ldy, const float* scale, const float* shift, const float* residual,
               int ldr, const float* res_scale, const float* res_shift, float* out, int ldo, int64_t M, int C, int relu,
-              void* stream);
+              int act_flags, void* stream);
 /* Backward of the above.  g = dout * mask.  relu = 0: no mask; 1: mask = out > 0 (needed when a residual was added);
  * 2: mask = y*scale+shift > 0, the forward's own arithmetic recomputed from y (no residual) -- `out` is not read, which
  * saves one activation-sized HBM read in each of the two passes.  reduce: partials [n][2][C] of (sum g, sum g*xhat);
@@ -255,14 +267,14 @@ int sh_bn_act(const float* y, int ldy, const float* scale, const float* shift, c
  * sh_conv_wgrad_x6_lin) then evaluate dy in their loaders and sh_bn_bwd_apply / the dy tensor are skipped. */
 int sh_bn_bwd_reduce(const float* dout, int lddo, const float* out, int ldo, const float* y, int ldy,
                      const float* mean, const float* invstd, const float* scale, const float* shift,
-                     float* partials, int64_t M, int C, int relu, float* g_out, int ldg, void* stream);
+                     float* partials, int64_t M, int C, int relu, float* g_out, int ldg, int act_flags, void* stream);
 int sh_bn_bwd_finalize(const float* partials, int n_partials, int C, const float* gamma,
                        const float* invstd, double count, float* dgamma, float* dbeta, float* c1,
                        float* c2, const float* mean, float* lin, void* stream);
 int sh_bn_bwd_apply(const float* dout, int lddo, const float* out, int ldo, const float* y, int ldy,
                     const float* mean, const float* invstd, const float* scale, const float* shift,
                     const float* gamma, const float* c1, const float* c2, float* dy, int lddy, float* dres,
-                    int lddres, int64_t M, int C, int relu, void* stream);
+                    int lddres, int64_t M, int C, int relu, int act_flags, void* stream);
 
 /* pooling / resampling -------------------------------------------------------------------- */
 /* nn.MaxPool2d(3, 2, 1) (models/backbone/resnet.py:68) and its backward (first-max tie rule).  argmax: one byte per
@@ -271,7 +283,7 @@ int sh_bn_bwd_apply(const float* dout, int lddo, const float* out, int ldo, cons
  * x is the stem conv's RAW output, read as relu(x * in_scale[c] + in_shift[c]) -- stem_bn + stem_relu (resnet.py:65-67) in the
  * pooling kernel's loader, so the 64-channel half-resolution activation is never materialised. */
 int sh_maxpool_fwd(const float* x, const float* in_scale, const float* in_shift, float* y, uint8_t* argmax, int N, int H,
-                   int W, int C, void* stream);
+                   int W, int C, int act_flags, void* stream);
 int sh_maxpool_bwd(const uint8_t* argmax, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
 /* nn.AdaptiveAvgPool2d(1) (sep_aspp_contrast_head.py:93,104): x [N,HW,C] -> y [N,C]; backward broadcasts. */
 int sh_avgpool_fwd(const float* x, int ldx, float* y, int N, int HW, int C, void* stream);

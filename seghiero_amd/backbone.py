@@ -141,18 +141,23 @@ class _BackboneFn(torch.autograd.Function):
             raise SegHieroHipError("stem_conv.weight must be contiguous")
         wpad = ops.new_act(w.shape[0], 4, 7, 7, w.device, zero=True)
         ops._call("sh_nchw_to_nhwc", w.data_ptr(), wpad.data_ptr(), w.shape[0], 3, 7, 7, 4, ops._st())
-        s_out, s_rec = L.cba_fwd(x4, wpad, L.conv_geom(mod.stem_conv), mod.stem_bn, True, training, lazy=True)
-        if isinstance(s_out, L.Lazy):          # stem_bn + stem_relu run in the pooling kernel's loader
-            pooled, pool_idx = ops.maxpool_fwd(s_out.y, want_argmax=training, aff=s_out.coefs)
-        else:
-            pooled, pool_idx = ops.maxpool_fwd(s_out, want_argmax=training)
-        h = pooled
-        saved, outs = [], []
-        for layer in (mod.layer1, mod.layer2, mod.layer3, mod.layer4):
-            for blk in layer:
-                h, sv = _block_fwd(blk, h, training)
-                saved.append(sv)
-            outs.append(h)
+        # act_dtype = torch.bfloat16 (training only): the trunk's raw conv outputs and block outputs are STORED as bf16 -- half the
+        # bytes of every activation read and write; arithmetic, BatchNorm statistics and gradients stay fp32 (BASELINE configs[4])
+        stored = mod.act_dtype if (training and L.FUSE_BN and ops.CONV_IMPL == "x6") else torch.float32
+        with ops.stored_as(stored):
+            s_out, s_rec = L.cba_fwd(x4, wpad, L.conv_geom(mod.stem_conv), mod.stem_bn, True, training, lazy=True)
+            if isinstance(s_out, L.Lazy):          # stem_bn + stem_relu run in the pooling kernel's loader
+                pooled, pool_idx = ops.maxpool_fwd(s_out.y, want_argmax=training, aff=s_out.coefs)
+            else:
+                pooled, pool_idx = ops.maxpool_fwd(s_out, want_argmax=training)
+            h = pooled
+            saved, outs = [], []
+            for layer in (mod.layer1, mod.layer2, mod.layer3, mod.layer4):
+                for blk in layer:
+                    h, sv = _block_fwd(blk, h, training)
+                    saved.append(sv)
+                outs.append(h)
+        outs = [o if o.dtype == torch.float32 else o.float() for o in outs]      # the head and the aux head take fp32 stage outputs
         if training:
             L.bump_bn_counters(_all_bns(mod))
         if training:
@@ -227,6 +232,9 @@ class ResNetBackbone(nn.Module):
         self.layer4, c = _stage(kind, c, 512, counts[3], 2)
         exp = 1 if kind == "basic" else 4
         self.out_channels = (64 * exp, 128 * exp, 256 * exp, 512 * exp)
+        # storage type of the trunk's activations in training (not a reference argument): torch.float32, or torch.bfloat16 =
+        # BASELINE configs[4]'s bf16 activation storage (see _BackboneFn.forward); set the attribute after construction
+        self.act_dtype = torch.float32
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")

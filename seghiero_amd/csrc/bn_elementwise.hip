@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partials_v4_kernel(const float* __
                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
                                                                  float* __restrict__ partials, long long M, int C, int relu,
-                                                                 float* __restrict__ g_out, long long ldg) {
+                                                                 float* __restrict__ g_out, long long ldg, int af) {
     __shared__ float red[2][16][64];
     const int t = threadIdx.x, cq = t & 15, rl = t >> 4;
     // 1-D grid, channel chunk fastest: blocks that run together read adjacent 256-byte pieces of the same rows
@@ -458,9 +458,9 @@ __global__ __launch_bounds__(256) void bn_bwd_partials_v4_kernel(const float* __
             const long long r = rbeg + rl + 16 * k;
             if (r < M) {
                 f32x4 g = ld4(dout + r * lddo + c);
-                const f32x4 yv = ld4(y + r * ldy + c);
+                const f32x4 yv = lda4(y, r * ldy + c, af & 1);            // af: bit 0 y, 1 out stored as bf16
                 if (relu == 1) {
-                    const f32x4 o = ld4(out + r * ldo + c);
+                    const f32x4 o = lda4(out, r * ldo + c, af & 2);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
                 } else if (relu == 2) {                 // no residual: the mask is the sign of the forward's y*scale+shift
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partials_v4_kernel(const float* __
 }
 extern "C" int sh_bn_bwd_reduce(const float* dout, int lddo, const float* out, int ldo, const float* y, int ldy,
                                 const float* mean, const float* invstd, const float* scale, const float* shift, float* partials,
-                                int64_t M, int C, int relu, float* g_out, int ldg, void* stream) {
+                                int64_t M, int C, int relu, float* g_out, int ldg, int act_flags, void* stream) {
     if (!dout || !y || !mean || !invstd || !partials || M <= 0 || C <= 0 || lddo < C || ldy < C) return SH_EINVAL;
     if (g_out && (ldg < C || (ldg & 3) || ((uintptr_t)g_out & 15))) return SH_EINVAL;
     if (relu < 0 || relu > 2 || (relu == 1 && (!out || ldo < C)) || (relu == 2 && (!scale || !shift))) return SH_EINVAL;
@@ -497,8 +497,8 @@ extern "C" int sh_bn_bwd_reduce(const float* dout, int lddo, const float* out, i
     const bool v4 = (C & 3) == 0 && ((lddo | ldy | (relu == 1 ? ldo : 0)) & 3) == 0 && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
                     (relu != 1 || ((uintptr_t)out & 15) == 0) && ((uintptr_t)mean & 15) == 0 && ((uintptr_t)invstd & 15) == 0 &&
                     (relu != 2 || ((((uintptr_t)scale | (uintptr_t)shift) & 15) == 0));
-    if (v4) bn_bwd_partials_v4_kernel<<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(y, ldy, dout, lddo, out, ldo, mean, invstd, scale, shift, partials, M, C, relu, g_out, ldg);
-    else if (g_out) return SH_EUNSUPPORTED;          // the masked gradient is written by the 16-byte kernel only
+    if (v4) bn_bwd_partials_v4_kernel<<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(y, ldy, dout, lddo, out, ldo, mean, invstd, scale, shift, partials, M, C, relu, g_out, ldg, act_flags);
+    else if (g_out || act_flags) return SH_EUNSUPPORTED;          // masked-gradient output and bf16 tensors: the 16-byte kernel only
     else channel_partials_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(y, ldy, dout, lddo, out, ldo, mean, invstd, scale, shift, partials, M, C, relu);
     return sh_launch_status();
 }
@@ -542,7 +542,7 @@ template <int V>
 __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y, long long ldy, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, const float* __restrict__ res, long long ldr,
                                                      float* __restrict__ out, long long ldo, long long M, int C, int relu,
-                                                     const float* __restrict__ rscale, const float* __restrict__ rshift) {
+                                                     const float* __restrict__ rscale, const float* __restrict__ rshift, int af) {
     const int cv = C / V;
     // chunks of EW_ROWS rows per block iteration; 32-bit (row, column) split inside a chunk
     for (long long m0 = (long long)blockIdx.x * EW_ROWS; m0 < M; m0 += (long long)gridDim.x * EW_ROWS)
@@ -551,14 +551,14 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y
         const long long m = m0 + r;
         const int c = (e - r * cv) * V;
         if (V == 4) {
-            f32x4 v = ld4(y + m * ldy + c) * ld4(scale + c) + ld4(shift + c);
+            f32x4 v = lda4(y, m * ldy + c, af & 1) * ld4(scale + c) + ld4(shift + c);        // af: bit 0 y, 1 residual, 2 out stored as bf16
             if (res) {
-                f32x4 r = ld4(res + m * ldr + c);
+                f32x4 r = lda4(res, m * ldr + c, af & 2);
                 if (rscale) r = r * ld4(rscale + c) + ld4(rshift + c);      // the downsample path's BatchNorm applied on the fly
                 v += r;
             }
             if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-            st4(out + m * ldo + c, v);
+            sta4(out, m * ldo + c, v, af & 4);
         } else {
             float v = y[m * ldy + c] * scale[c] + shift[c];
             if (res) v += rscale ? res[m * ldr + c] * rscale[c] + rshift[c] : res[m * ldr + c];
@@ -579,14 +579,17 @@ static inline bool vec4_ok(int C, long long a, long long b = 0, long long c = 0,
 static inline bool ptr16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 extern "C" int sh_bn_act(const float* y, int ldy, const float* scale, const float* shift, const float* residual, int ldr,
-                         const float* res_scale, const float* res_shift, float* out, int ldo, int64_t M, int C, int relu, void* stream) {
+                         const float* res_scale, const float* res_shift, float* out, int ldo, int64_t M, int C, int relu, int act_flags,
+                         void* stream) {
     if (!y || !scale || !shift || !out || M <= 0 || C <= 0 || ldy < C || ldo < C) return SH_EINVAL;
     if (residual && ldr < C) return SH_EINVAL;
     if ((res_scale == nullptr) != (res_shift == nullptr) || (res_scale && !residual)) return SH_EINVAL;
+    // (bf16 tensors: 8-byte accesses -- base pointers 8-byte aligned suffice, 16 is what the allocator gives anyway)
     const bool v4 = vec4_ok(C, ldy, ldo, residual ? ldr : 0) && ptr16(y) && ptr16(out) && ptr16(scale) && ptr16(shift) && (!residual || ptr16(residual)) &&
                     (!res_scale || (ptr16(res_scale) && ptr16(res_shift)));
-    if (v4) bn_act_kernel<4><<<rows_grid(M, C / 4), 256, 0, (hipStream_t)stream>>>(y, ldy, scale, shift, residual, ldr, out, ldo, M, C, relu, res_scale, res_shift);
-    else bn_act_kernel<1><<<rows_grid(M, C), 256, 0, (hipStream_t)stream>>>(y, ldy, scale, shift, residual, ldr, out, ldo, M, C, relu, res_scale, res_shift);
+    if (act_flags && !v4) return SH_EUNSUPPORTED;
+    if (v4) bn_act_kernel<4><<<rows_grid(M, C / 4), 256, 0, (hipStream_t)stream>>>(y, ldy, scale, shift, residual, ldr, out, ldo, M, C, relu, res_scale, res_shift, act_flags);
+    else bn_act_kernel<1><<<rows_grid(M, C), 256, 0, (hipStream_t)stream>>>(y, ldy, scale, shift, residual, ldr, out, ldo, M, C, relu, res_scale, res_shift, 0);
     return sh_launch_status();
 }
 
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ gamma, const float* __restrict__ c1,
                                                            const float* __restrict__ c2, float* __restrict__ dy, long long lddy,
-                                                           float* __restrict__ dres, long long lddres, long long M, int C, int relu) {
+                                                           float* __restrict__ dres, long long lddres, long long M, int C, int relu, int af) {
     const int cv = C / V;
     // chunks of EW_ROWS rows per block iteration; 32-bit (row, column) split inside a chunk
     for (long long m0 = (long long)blockIdx.x * EW_ROWS; m0 < M; m0 += (long long)gridDim.x * EW_ROWS)
@@ -607,9 +610,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const int c = (e - r * cv) * V;
         if (V == 4) {
             f32x4 g = ld4(dout + m * lddo + c);
-            const f32x4 yv = ld4(y + m * ldy + c);
+            const f32x4 yv = lda4(y, m * ldy + c, af & 1);                // af: bit 0 y, 1 out stored as bf16
             if (relu == 1) {
-                const f32x4 o = ld4(out + m * ldo + c);
+                const f32x4 o = lda4(out, m * ldo + c, af & 2);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) if (!(o[j] > 0.f)) g[j] = 0.f;
             } else if (relu == 2) {
@@ -639,15 +642,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 extern "C" int sh_bn_bwd_apply(const float* dout, int lddo, const float* out, int ldo, const float* y, int ldy,
                                const float* mean, const float* invstd, const float* scale, const float* shift, const float* gamma,
                                const float* c1, const float* c2, float* dy, int lddy, float* dres, int lddres, int64_t M, int C, int relu,
-                               void* stream) {
+                               int act_flags, void* stream) {
     if (!dout || !y || !mean || !invstd || !c1 || !c2 || !dy || M <= 0 || C <= 0 || lddo < C || ldy < C || lddy < C) return SH_EINVAL;
     if (relu < 0 || relu > 2 || (relu == 1 && (!out || ldo < C)) || (relu == 2 && (!scale || !shift))) return SH_EINVAL;
     if (dres && lddres < C) return SH_EINVAL;
     const bool v4 = vec4_ok(C, lddo, ldy, lddy, relu == 1 ? ldo : 0, dres ? lddres : 0) && ptr16(dout) && ptr16(y) && ptr16(dy) &&
                     ptr16(mean) && ptr16(invstd) && ptr16(c1) && ptr16(c2) && (!gamma || ptr16(gamma)) && (relu != 1 || ptr16(out)) &&
                     (relu != 2 || (ptr16(scale) && ptr16(shift))) && (!dres || ptr16(dres));
-    if (v4) bn_bwd_apply_kernel<4><<<rows_grid(M, C / 4), 256, 0, (hipStream_t)stream>>>(dout, lddo, out, ldo, y, ldy, mean, invstd, scale, shift, gamma, c1, c2, dy, lddy, dres, lddres, M, C, relu);
-    else bn_bwd_apply_kernel<1><<<rows_grid(M, C), 256, 0, (hipStream_t)stream>>>(dout, lddo, out, ldo, y, ldy, mean, invstd, scale, shift, gamma, c1, c2, dy, lddy, dres, lddres, M, C, relu);
+    if (act_flags && !v4) return SH_EUNSUPPORTED;
+    if (v4) bn_bwd_apply_kernel<4><<<rows_grid(M, C / 4), 256, 0, (hipStream_t)stream>>>(dout, lddo, out, ldo, y, ldy, mean, invstd, scale, shift, gamma, c1, c2, dy, lddy, dres, lddres, M, C, relu, act_flags);
+    else bn_bwd_apply_kernel<1><<<rows_grid(M, C), 256, 0, (hipStream_t)stream>>>(dout, lddo, out, ldo, y, ldy, mean, invstd, scale, shift, gamma, c1, c2, dy, lddy, dres, lddres, M, C, relu, 0);
     return sh_launch_status();
 }
 

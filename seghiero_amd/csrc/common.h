@@ -38,3 +38,26 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// ---- bf16 activation storage (BASELINE configs[4]): raw conv outputs and block outputs may be STORED as bf16 (half the HBM bytes);
+// every kernel computes in fp32.  `base` is the tensor's base pointer whatever its element type, `idx` the ELEMENT index
+// (row * ld + channel, a multiple of 4), `bf` != 0: bf16 elements (wave-uniform flag from the entry point's act_flags).
+typedef unsigned int sh_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 bf16x4_to_f32(sh_u32x2 v) {
+    return f32x4{__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u)};
+}
+__device__ __forceinline__ unsigned f32_to_bf16_rne(float f) {       // round to nearest even; NaN stays NaN
+    const unsigned u = __float_as_uint(f);
+    return (f != f) ? ((u >> 16) | 0x40u) : ((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ sh_u32x2 f32_to_bf16x4(f32x4 v) {
+    return sh_u32x2{f32_to_bf16_rne(v[0]) | (f32_to_bf16_rne(v[1]) << 16), f32_to_bf16_rne(v[2]) | (f32_to_bf16_rne(v[3]) << 16)};
+}
+__device__ __forceinline__ f32x4 lda4(const float* base, long long idx, int bf) {
+    if (bf) return bf16x4_to_f32(*reinterpret_cast<const sh_u32x2*>(reinterpret_cast<const unsigned short*>(base) + idx));
+    return ld4(base + idx);
+}
+__device__ __forceinline__ void sta4(float* base, long long idx, f32x4 v, int bf) {
+    if (bf) *reinterpret_cast<sh_u32x2*>(reinterpret_cast<unsigned short*>(base) + idx) = f32_to_bf16x4(v);
+    else st4(base + idx, v);
+}

@@ -796,7 +796,8 @@ extern "C" int sh_weight_transpose_multi(int n, const float* const* w, float* co
 // statistics of the conv epilogue (centred (sum, M2) per 64 rows); for dgrad optionally the front half of the producer layer's
 // BatchNorm backward (BNB: g = relumask * dx stored, (sum g, sum g*xhat) per 64 rows -> partials, see conv_x6p.hip).
 // Block = 64 rows x 64 columns, thread = 4 rows x 4 columns.
-struct BnbQ { const float* y; long long ldy; const float* mean; const float* invstd; const float* scale; const float* shift; int relu; const float* out; long long ldo; };
+struct BnbQ { const float* y; long long ldy; const float* mean; const float* invstd; const float* scale; const float* shift; int relu; const float* out; long long ldo;
+              int act; };      // act: ConvQ::act (bit 1 the fprop output, 2 y, 3 out stored as bf16)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, long long ldslab, int S, long long M, int Nn,
                                                             const float* __restrict__ bias, const float* __restrict__ addend, long long ldadd,
                                                             float* __restrict__ out, long long ldc, float* __restrict__ partials, const BnbQ bnb) {
@@ -821,17 +822,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             if (bias) o += ld4(bias + n);
             if (addend) o += ld4(addend + m * ldadd + n);
             if (bnb.y != nullptr) {
-                const f32x4 yv = ld4(bnb.y + m * bnb.ldy + n);
+                const f32x4 yv = lda4(bnb.y, m * bnb.ldy + n, bnb.act & 4);
                 if (bnb.relu) {
                     // the forward's own arithmetic (bn_act_kernel), or the stored block output where a residual was added
-                    const f32x4 a = bnb.out != nullptr ? ld4(bnb.out + m * bnb.ldo + n) : yv * b_sc + b_sh;
+                    const f32x4 a = bnb.out != nullptr ? lda4(bnb.out, m * bnb.ldo + n, bnb.act & 8) : yv * b_sc + b_sh;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) if (!(a[j] > 0.f)) o[j] = 0.f;
                 }
                 v[k] = o;                                                // statistics of g, not of the raw sum
                 gq += o * ((yv - b_mu) * b_is);
             }
-            st4(out + m * ldc + n, o);
+            sta4(out, m * ldc + n, o, bnb.y == nullptr ? (bnb.act & 2) : 0);       // (a bf16 output exists for fprop only; the statistics below use the fp32 sums)
         }
     }
     if (partials == nullptr) return;         // block-uniform
@@ -871,7 +872,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // reduce launch shared with conv_x6p.hip
 int sh_x6_splitk_reduce(const ConvQ& p, int mode, hipStream_t st) {
     dim3 rg((unsigned)sh_cdiv(p.M, 64), (unsigned)sh_cdiv(p.Nn, 64));
-    BnbQ bnb{p.bnb_y, p.bnb_ldy, p.bnb_mean, p.bnb_invstd, p.bnb_scale, p.bnb_shift, p.bnb_relu, p.bnb_out, p.bnb_ldo};
+    BnbQ bnb{p.bnb_y, p.bnb_ldy, p.bnb_mean, p.bnb_invstd, p.bnb_scale, p.bnb_shift, p.bnb_relu, p.bnb_out, p.bnb_ldo, mode == FPROP ? p.act : (p.act & ~2)};
     splitk_reduce_kernel<<<rg, 256, 0, st>>>(p.slab, p.ldslab, p.ksplit, p.M, p.Nn, mode == FPROP ? p.extra : nullptr,
                                              mode == DGRAD ? p.extra : nullptr, p.ldadd, p.c, p.ldc,
                                              (mode == FPROP || p.bnb_y != nullptr) ? p.partials : nullptr, bnb);
@@ -1015,12 +1016,13 @@ static bool operand_extents(ConvQ& p, int mode) {
     if (mode == FPROP) { a = ((long long)p.N * p.H * p.W - 1) * p.lda + p.Cin; b = (long long)p.Cout * p.K; }
     else { a = ((long long)p.N * p.Ho * p.Wo - 1) * p.lda + p.Kc; b = (long long)p.KH * p.KW * p.Cin * p.Kc; }
     if (a * 4 >= (1ll << 31) || b * 4 >= (1ll << 31)) return false;
-    p.a_bytes = (unsigned)(a * 4); p.b_bytes = (unsigned)(b * 4);
+    p.a_bytes = (unsigned)(a * ((mode == FPROP && (p.act & 1)) ? 2 : 4)); p.b_bytes = (unsigned)(b * 4);
     return true;
 }
 // pipelined kernel (conv_x6p.hip) where it has an instantiation for the shape, else conv_x6_kernel
 static int launch_fprop_any(ConvQ& p, hipStream_t st) {
     if (operand_extents(p, FPROP)) { const int rc = sh_x6p_launch(FPROP, p, st); if (rc != SH_X6P_NO) return rc; }
+    if (p.act) return SH_EUNSUPPORTED;          // bf16 tensors: the pipelined kernels only
     return launch_conv_x6<FPROP>(p, st);
 }
 static int launch_dgrad_any(ConvQ& p, hipStream_t st) {
@@ -1029,10 +1031,11 @@ static int launch_dgrad_any(ConvQ& p, hipStream_t st) {
 }
 extern "C" int sh_conv_fprop_x6(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, float* stat_partials,
                                 int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil,
-                                float* workspace, int64_t workspace_bytes, void* stream) {
+                                float* workspace, int64_t workspace_bytes, int act_flags, void* stream) {
     ConvQ p{};
     if (!x || !w || !y || !geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil)) return SH_EINVAL;
-    if (ldx < Cin || ldy < Cout || (ldx & 3)) return SH_EINVAL;
+    if (ldx < Cin || ldy < Cout || (ldx & 3) || (act_flags & ~3)) return SH_EINVAL;
+    p.act = act_flags;                                   // bit 0: x, bit 1: y stored as bf16
     p.a = x; p.b = w; p.c = y; p.extra = bias; p.partials = stat_partials; p.lda = ldx; p.ldc = ldy;
     p.M = N * p.Ho * p.Wo; p.Nn = Cout; p.K = KH * KW * Cin; p.Kc = Cin;
     p.n_partials = (int)sh_cdiv(p.M, 64);
@@ -1045,10 +1048,11 @@ extern "C" int sh_conv_fprop_x6(const float* x, int ldx, const float* w, const f
 // is never materialised.  SH_EUNSUPPORTED: this geometry has no fused instantiation (caller applies sh_bn_act first).
 extern "C" int sh_conv_fprop_x6_aff(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* w, const float* bias,
                                     float* y, int ldy, float* stat_partials, int N, int H, int W, int Cin, int Cout, int KH, int KW,
-                                    int stride, int pad, int dil, float* workspace, int64_t workspace_bytes, void* stream) {
+                                    int stride, int pad, int dil, float* workspace, int64_t workspace_bytes, int act_flags, void* stream) {
     ConvQ p{};
     if (!x || !w || !y || !in_scale || !in_shift || !geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil)) return SH_EINVAL;
-    if (ldx < Cin || ldy < Cout || (ldx & 3) || (((uintptr_t)in_scale | (uintptr_t)in_shift) & 15)) return SH_EINVAL;
+    if (ldx < Cin || ldy < Cout || (ldx & 3) || (((uintptr_t)in_scale | (uintptr_t)in_shift) & 15) || (act_flags & ~3)) return SH_EINVAL;
+    p.act = act_flags;                                   // bit 0: x, bit 1: y stored as bf16
     p.a = x; p.b = w; p.c = y; p.extra = bias; p.partials = stat_partials; p.lda = ldx; p.ldc = ldy;
     p.M = N * p.Ho * p.Wo; p.Nn = Cout; p.K = KH * KW * Cin; p.Kc = Cin;
     p.n_partials = (int)sh_cdiv(p.M, 64);
@@ -1132,8 +1136,11 @@ extern "C" int sh_conv_dgrad_x6(const float* dy, int lddy, const float* wt, cons
 extern "C" int sh_conv_dgrad_x6_bnb(const float* dy, int lddy, const float* wt, const float* addend, int ldadd, float* g, int ldg,
                                     const float* y_prev, int ldyp, const float* out_prev, int ldop, const float* mean, const float* invstd,
                                     const float* scale, const float* shift, int relu, float* stat_partials, int N, int H, int W, int Cin, int Cout,
-                                    int KH, int KW, int stride, int pad, int dil, float* workspace, int64_t workspace_bytes, void* stream) {
+                                    int KH, int KW, int stride, int pad, int dil, float* workspace, int64_t workspace_bytes, int act_flags,
+                                    void* stream) {
     ConvQ p{};
+    if (act_flags & ~3) return SH_EINVAL;
+    p.act = ((act_flags & 1) ? 4 : 0) | ((act_flags & 2) ? 8 : 0);          // bit 0: y_prev, bit 1: out_prev stored as bf16
     if (!dy || !wt || !g || !y_prev || !mean || !invstd || !scale || !shift || !stat_partials ||
         !geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil)) return SH_EINVAL;
     const int CoutP = (Cout + 3) & ~3;
@@ -1162,9 +1169,10 @@ extern "C" int sh_conv_dgrad_x6_bnb(const float* dy, int lddy, const float* wt, 
 extern "C" int sh_conv_dgrad_x6_lin(const float* g, int ldg, const float* y, int ldy, const float* lin, const float* wt, const float* addend,
                                     int ldadd, float* dx, int lddx, const float* y_prev, int ldyp, const float* mean, const float* invstd,
                                     const float* scale, const float* shift, int relu, float* stat_partials, int N, int H, int W, int Cin,
-                                    int Cout, float* workspace, int64_t workspace_bytes, void* stream) {
+                                    int Cout, float* workspace, int64_t workspace_bytes, int act_flags, void* stream) {
     ConvQ p{};
-    if (!g || !y || !lin || !wt || !dx || !geom(p, N, H, W, Cin, Cout, 1, 1, 1, 0, 1)) return SH_EINVAL;
+    if (!g || !y || !lin || !wt || !dx || !geom(p, N, H, W, Cin, Cout, 1, 1, 1, 0, 1) || (act_flags & ~3)) return SH_EINVAL;
+    p.act = ((act_flags & 1) ? 16 : 0) | ((act_flags & 2) ? 4 : 0);         // bit 0: y (the lin stream), bit 1: y_prev stored as bf16
     if (ldg < Cout || ldy < Cout || ((ldg | ldy) & 3) || lddx < Cin || (addend && ldadd < Cin)) return SH_EINVAL;
     if (y_prev && (!mean || !invstd || !scale || !shift || !stat_partials || ldyp < Cin)) return SH_EINVAL;
     if ((Cout & 3) || (((uintptr_t)g | (uintptr_t)y | (uintptr_t)lin) & 15)) return SH_EUNSUPPORTED;
@@ -1181,7 +1189,7 @@ extern "C" int sh_conv_dgrad_x6_lin(const float* g, int ldg, const float* y, int
     if (!operand_extents(p, DGRAD)) return SH_EUNSUPPORTED;
     const long long a2 = ((long long)p.M - 1) * ldy + Cout;
     if (a2 * 4 >= (1ll << 31)) return SH_EUNSUPPORTED;
-    p.a2_bytes = (unsigned)(a2 * 4);
+    p.a2_bytes = (unsigned)(a2 * ((p.act & 16) ? 2 : 4));
     const int rc = sh_x6p_launch(DGRAD, p, (hipStream_t)stream);
     return rc == SH_X6P_NO ? SH_EUNSUPPORTED : rc;
 }
@@ -1252,15 +1260,17 @@ static int launch_wgrad_x6(ConvQ& p, int splits, hipStream_t st) {
 }
 static int wgrad_x6_any(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* dy, int lddy, float* dw,
                         float* workspace, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, void* stream,
-                        const float* y_lin = nullptr, int ldyl = 0, const float* lin = nullptr) {
+                        const float* y_lin = nullptr, int ldyl = 0, const float* lin = nullptr, int act_flags = 0) {
     ConvQ p{};
+    if (act_flags & ~3) return SH_EINVAL;
+    p.act = ((act_flags & 1) ? 32 : 0) | ((act_flags & 2) ? 16 : 0);        // bit 0: x, bit 1: the lin y stream stored as bf16
     if (!x || !dy || !dw || !workspace || !geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil)) return SH_EINVAL;
     if (lddy < ((Cout + 3) & ~3) || (lddy & 3) || ldx < Cin || (ldx & 3)) return SH_EINVAL;
     p.a = dy; p.b = x; p.c = workspace; p.lda = lddy; p.ldb = ldx;
     if (lin) {
         const long long a2 = (((long long)N * p.Ho * p.Wo) - 1) * ldyl + Cout;
         if ((Cout & 3) || a2 * 4 >= (1ll << 31)) return SH_EUNSUPPORTED;
-        p.a2 = y_lin; p.lda2 = ldyl; p.a2_bytes = (unsigned)(a2 * 4); p.lin = lin;
+        p.a2 = y_lin; p.lda2 = ldyl; p.a2_bytes = (unsigned)(a2 * ((p.act & 16) ? 2 : 4)); p.lin = lin;
     }
     p.M = Cout; p.Nn = KH * KW * Cin; p.K = N * p.Ho * p.Wo;
     p.aff_scale = in_scale; p.aff_shift = in_shift;
@@ -1271,11 +1281,11 @@ static int wgrad_x6_any(const float* x, int ldx, const float* in_scale, const fl
     int rc = SH_X6P_NO;
     const long long ab = (((long long)p.K - 1) * lddy + ((Cout + 3) & ~3)) * 4, bb = (((long long)N * H * W - 1) * ldx + Cin) * 4;
     if (ab < (1ll << 31) && bb < (1ll << 31)) {
-        p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
+        p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)((p.act & 32) ? bb / 2 : bb);
         rc = sh_x6p_wgrad_launch(p, g.wgm, g.wgn, g.splits, st);
     }
     if (rc == SH_X6P_NO) {
-        if (in_scale || lin) return SH_EUNSUPPORTED;
+        if (in_scale || lin || p.act) return SH_EUNSUPPORTED;
         if (g.wgm == 4 && g.wgn == 1) rc = launch_wgrad_x6<4, 1>(p, g.splits, st);
         else if (g.wgm == 2 && g.wgn == 1) rc = launch_wgrad_x6<2, 1>(p, g.splits, st);
         else if (g.wgm == 2 && g.wgn == 4) rc = launch_wgrad_x6<2, 4>(p, g.splits, st);
@@ -1289,23 +1299,25 @@ static int wgrad_x6_any(const float* x, int ldx, const float* in_scale, const fl
     return sh_launch_status();
 }
 extern "C" int sh_conv_wgrad_x6(const float* x, int ldx, const float* dy, int lddy, float* dw, float* workspace, int N, int H, int W,
-                                int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, void* stream) {
-    return wgrad_x6_any(x, ldx, nullptr, nullptr, dy, lddy, dw, workspace, N, H, W, Cin, Cout, KH, KW, stride, pad, dil, stream);
+                                int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, int act_flags, void* stream) {
+    return wgrad_x6_any(x, ldx, nullptr, nullptr, dy, lddy, dw, workspace, N, H, W, Cin, Cout, KH, KW, stride, pad, dil, stream, nullptr, 0, nullptr,
+                        act_flags & 1);
 }
 // Weight gradient of a conv whose input is read THROUGH the producer's BatchNorm + ReLU (see sh_conv_fprop_x6_aff): x holds the raw
 // output of the previous convolution, the loader applies relu(x * in_scale[c] + in_shift[c]).  SH_EUNSUPPORTED: output width < 16.
 extern "C" int sh_conv_wgrad_x6_aff(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* dy, int lddy,
                                     float* dw, float* workspace, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
-                                    int pad, int dil, void* stream) {
+                                    int pad, int dil, int act_flags, void* stream) {
     if (!in_scale || !in_shift || (((uintptr_t)in_scale | (uintptr_t)in_shift) & 15)) return SH_EINVAL;
-    return wgrad_x6_any(x, ldx, in_scale, in_shift, dy, lddy, dw, workspace, N, H, W, Cin, Cout, KH, KW, stride, pad, dil, stream);
+    return wgrad_x6_any(x, ldx, in_scale, in_shift, dy, lddy, dw, workspace, N, H, W, Cin, Cout, KH, KW, stride, pad, dil, stream, nullptr, 0, nullptr,
+                        act_flags & 1);
 }
 // Weight gradient whose dY operand is lin(g, y) (see sh_conv_dgrad_x6_lin), optionally with x read through the producer's BatchNorm +
 // ReLU (in_scale / in_shift, as sh_conv_wgrad_x6_aff).  SH_EUNSUPPORTED: output width < 16, Cout % 4, extents >= 2 GiB.
 extern "C" int sh_conv_wgrad_x6_lin(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* g, int ldg,
                                     const float* y, int ldy, const float* lin, float* dw, float* workspace, int N, int H, int W, int Cin,
-                                    int Cout, int KH, int KW, int stride, int pad, int dil, void* stream) {
+                                    int Cout, int KH, int KW, int stride, int pad, int dil, int act_flags, void* stream) {
     if (!y || !lin || ldy < Cout || (ldy & 3) || (((uintptr_t)y | (uintptr_t)lin) & 15)) return SH_EINVAL;
     if ((in_scale == nullptr) != (in_shift == nullptr) || (((uintptr_t)in_scale | (uintptr_t)in_shift) & 15)) return SH_EINVAL;
-    return wgrad_x6_any(x, ldx, in_scale, in_shift, g, ldg, dw, workspace, N, H, W, Cin, Cout, KH, KW, stride, pad, dil, stream, y, ldy, lin);
+    return wgrad_x6_any(x, ldx, in_scale, in_shift, g, ldg, dw, workspace, N, H, W, Cin, Cout, KH, KW, stride, pad, dil, stream, y, ldy, lin, act_flags);
 }

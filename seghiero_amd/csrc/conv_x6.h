@@ -51,6 +51,10 @@ struct ConvQ {
     // lin(g, y) = lin[0][c]*g + lin[1][c]*(y - lin[2][c]) + lin[3][c] of the masked gradient g (p.a) and the raw conv output y (a2)
     const float* a2; long long lda2; unsigned a2_bytes;
     const float* lin;       // [4][Kc (dgrad) / M (wgrad)]
+    // ---- bf16 activation storage (common.h): bit 0 the fprop input x, 1 the fprop output y, 2 bnb_y, 3 bnb_out, 4 the lin y stream (a2),
+    // 5 the wgrad X operand are stored as bf16 (pixel strides count elements).  Loads inside a scheduled conv phase are selected by a
+    // template parameter (ABF / XBF), epilogue accesses by this mask at run time.
+    int act;
     int vec_epi;            // output / addend / bnb_y rows are 16-byte addressable: row-major float4 epilogue through LDS
     unsigned a_bytes, b_bytes;  // extents of the A / B operands for the buffer descriptors (bytes, < 2^31)
 };

@@ -49,7 +49,9 @@ __device__ __forceinline__ int swz_row(int row) { return ((row >> 2) & 3) ^ (row
 #endif
 // TAP: 0 = 1x1 (one tap), 1 = KxK with Kc % 16 == 0 (a half-tile never straddles taps: scalar tap math, switched by a block-uniform
 // branch at the start of a phase), 2 = general (per-lane tap; stem 7x7 with 4 channels)
-template <int MODE, int TM, int TN, int WGM, int WGN, int WPS, int AFF, int EPI, int SK, int TAP, int GRP = 0>
+// ABF: the activation stream of the loader is stored as bf16 (fprop: the A operand x; AFF == 2 dgrad: the y stream of lin(g, y)) --
+// 8-byte loads of 4 elements, widened to fp32 when the half-tile goes to LDS; everything downstream is unchanged
+template <int MODE, int TM, int TN, int WGM, int WGN, int WPS, int AFF, int EPI, int SK, int TAP, int GRP = 0, int ABF = 0>
 __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const ConvQ p) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
@@ -62,6 +64,22 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
     unsigned char* const Bs = smem + 3 * A_PLANE;
     float* const coef = reinterpret_cast<float*>(smem + 3 * (A_PLANE + B_PLANE));     // AFF 1: scale[Kc], shift[Kc]; AFF 2: lin[4][Kc]
     static_assert(AFF != 2 || (MODE == DGRAD && TAP == 0 && !GRP), "the deferred BatchNorm-backward loader exists for 1x1 dgrads");
+    static_assert(!ABF || (MODE == FPROP && !GRP) || AFF == 2, "bf16 loader streams: the fprop input, or the y stream of the lin loader");
+    constexpr bool A_BF = ABF && MODE == FPROP, A2_BF = ABF && AFF == 2;
+    auto load_a4 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned elem_off, unsigned ok, bool bf) -> f32x4 {
+        // 4 consecutive elements: fp32 -> one 16-byte load; bf16 -> one 8-byte load parked in the first two lanes of the f32x4 (widened
+        // by widen_a4 when the half-tile is stored); offsets beyond the buffer (masked rows / taps / K tail) read as zeros
+        if (bf) {
+            const unsigned voff = ((elem_off * 2u) & ok) | (0x80000000u & ~ok);
+            const u32x2 r = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0));
+            return f32x4{__uint_as_float(r[0]), __uint_as_float(r[1]), 0.f, 0.f};
+        }
+        const unsigned voff = ((elem_off * 4u) & ok) | (0x80000000u & ~ok);
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
+    };
+    auto widen_a4 = [&](f32x4 v, bool bf) -> f32x4 {
+        return bf ? bf16x4_to_f32(sh_u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])}) : v;
+    };
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WGN, wn = wave % WGN, l31 = lane & 31, h = lane >> 5;
@@ -183,12 +201,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const unsigned ok = kok & a_ok[i];
-            const unsigned voff = (((unsigned)(a_off[i] + cc) * 4u) & ok) | (OOB & ~ok);
-            R.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff, 0, 0));
-            if constexpr (AFF == 2) {
-                const unsigned voff2 = (((unsigned)(a_off2[i] + cc) * 4u) & ok) | (OOB & ~ok);
-                R.a2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a2, voff2, 0, 0));
-            }
+            R.a[i] = load_a4(rsrc_a, (unsigned)(a_off[i] + cc), ok, A_BF);
+            if constexpr (AFF == 2) R.a2[i] = load_a4(rsrc_a2, (unsigned)(a_off2[i] + cc), ok, A2_BF);
             if (AFF) R.okm |= ok & (1u << i);
         }
 #pragma unroll
@@ -210,12 +224,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
         if constexpr (AFF == 2) { lmu = *reinterpret_cast<const f32x4*>(coef + 2 * p.Kc + R.cc); ld_ = *reinterpret_cast<const f32x4*>(coef + 3 * p.Kc + R.cc); }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            f32x4 v = R.a[i];
+            f32x4 v = widen_a4(R.a[i], A_BF);
             if constexpr (AFF == 2) {
                 // dy = A*g + B*(y - mean) + D (sc = A, sh = B): rows beyond M / the K tail must stay exact zeros (D != 0)
                 const bool ok = (R.okm >> i) & 1u;
+                const f32x4 y2 = widen_a4(R.a2[i], A2_BF);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float w = fmaf(R.a2[i][e] - lmu[e], sh[e], fmaf(v[e], sc[e], ld_[e])); v[e] = ok ? w : 0.f; }
+                for (int e = 0; e < 4; ++e) { const float w = fmaf(y2[e] - lmu[e], sh[e], fmaf(v[e], sc[e], ld_[e])); v[e] = ok ? w : 0.f; }
             } else if constexpr (AFF) {
                 // bn_act_kernel's own operation order (y * scale + shift, then max with 0): the loader sees exactly the values the
                 // separate BatchNorm + ReLU pass would have written; padded taps / rows beyond M stay exact zeros
@@ -393,8 +408,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
                     if (mrow[kk] < Mc && nokv) {
                         if (p.extra != nullptr) ad[kk] = ld4(p.extra + mrow[kk] * p.ldadd + ncv);
                         if constexpr (EPI == 2) {
-                            yv[kk] = ld4(p.bnb_y + mrow[kk] * p.bnb_ldy + ncv);
-                            if (p.bnb_out != nullptr) ov[kk] = ld4(p.bnb_out + mrow[kk] * p.bnb_ldo + ncv);
+                            yv[kk] = lda4(p.bnb_y, mrow[kk] * p.bnb_ldy + ncv, p.act & 4);
+                            if (p.bnb_out != nullptr) ov[kk] = lda4(p.bnb_out, mrow[kk] * p.bnb_ldo + ncv, p.act & 8);
                         }
                     }
                 }
@@ -416,7 +431,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
                             gs += o; gq += o * ((yv[kk] - v_mu) * v_is);
                         }
                     }
-                    st4(p.c + mrow[kk] * p.ldc + ncv, o);
+                    sta4(p.c, mrow[kk] * p.ldc + ncv, o, MODE == FPROP ? (p.act & 2) : 0);
                 }
             }
             }
@@ -549,21 +564,21 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
 }
 
 // ---------------------------------------------------------------------------------------- host side
-template <int MODE, int TM, int TN, int WGM, int WGN, int WPS, int AFF, int EPI, int SK, int TAP, int GRP = 0>
+template <int MODE, int TM, int TN, int WGM, int WGN, int WPS, int AFF, int EPI, int SK, int TAP, int GRP = 0, int ABF = 0>
 static int launch_x6p(ConvQ& p, hipStream_t st) {
     constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
     const size_t lds = 3 * (size_t)(BM + BN) * ROWB + (AFF == 2 ? 16 : AFF ? 8 : 0) * (size_t)p.Kc;
     if (lds > 160 * 1024) return SH_X6P_NO;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6p_kernel<MODE, TM, TN, WGM, WGN, WPS, AFF, EPI, SK, TAP, GRP>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6p_kernel<MODE, TM, TN, WGM, WGN, WPS, AFF, EPI, SK, TAP, GRP, ABF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         attr_lds = 160 * 1024;
     }
     p.tiles_m = (int)sh_cdiv(p.M, BM);
     p.tiles_n = (int)sh_cdiv(p.Nn, BN);
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), p.parity ? 4u : (SK ? (unsigned)p.ksplit : 1u));
-    conv_x6p_kernel<MODE, TM, TN, WGM, WGN, WPS, AFF, EPI, SK, TAP, GRP><<<grid, 64 * WGM * WGN, lds, st>>>(p);
+    conv_x6p_kernel<MODE, TM, TN, WGM, WGN, WPS, AFF, EPI, SK, TAP, GRP, ABF><<<grid, 64 * WGM * WGN, lds, st>>>(p);
     return sh_launch_status();
 }
 
@@ -571,7 +586,7 @@ static int launch_x6p(ConvQ& p, hipStream_t st) {
 // tiles on 4 waves (164 VGPRs, 48 KB LDS => 3 blocks per CU, which also overlaps one block's epilogue stores with its neighbours'
 // MFMAs) match or beat 256 x 256 on 8 waves and 256 x 128 everywhere (sep1.pw 740 vs 743 vs 770 us; l2.conv3 65 vs 77 vs 80 us),
 // so only two shapes are instantiated: 128 x 128, and 128 x 64 for N <= 64.
-template <int MODE, int AFF, int EPI, int TAP>
+template <int MODE, int AFF, int EPI, int TAP, int ABF = 0>
 static int pick_tile_x6p(ConvQ& p, hipStream_t st, int force) {
     (void)force;
     // AFF == 2 carries a second A-operand stream (16 more prefetch registers): at 3 blocks per CU (168 VGPRs) it spills 15 registers into
@@ -579,30 +594,30 @@ static int pick_tile_x6p(ConvQ& p, hipStream_t st, int force) {
     // The BatchNorm-backward epilogue (EPI == 2) spilled 85 registers until its row groups were processed in chunks; 128 x 64 tiles with
     // it still need 3 instead of 4 blocks per CU (18 spills at 128 VGPRs).
     constexpr int W1 = SH_W1(AFF, EPI), W2 = SH_W2(AFF, EPI);
-    if (p.Nn > 64) return launch_x6p<MODE, 2, 2, 2, 2, W1, AFF, EPI, 0, TAP>(p, st);     // 128 x 128, 4 waves of 64 x 64, 3 blocks per CU
-    return launch_x6p<MODE, 2, 1, 2, 2, W2, AFF, EPI, 0, TAP>(p, st);                    // 128 x 64, 4 blocks per CU
+    if (p.Nn > 64) return launch_x6p<MODE, 2, 2, 2, 2, W1, AFF, EPI, 0, TAP, 0, ABF>(p, st);     // 128 x 128, 4 waves of 64 x 64, 3 blocks per CU
+    return launch_x6p<MODE, 2, 1, 2, 2, W2, AFF, EPI, 0, TAP, 0, ABF>(p, st);                    // 128 x 64, 4 blocks per CU
 }
 
-template <int MODE, int AFF, int EPI>
+template <int MODE, int AFF, int EPI, int ABF = 0>
 static int pick_x6p(ConvQ& p, hipStream_t st, int force) {
     if constexpr (AFF == 2) {    // deferred BatchNorm-backward loader: 1x1 only
         if (p.KH * p.KW != 1) return SH_X6P_NO;
         if (p.ksplit > 1) {
-            const int rc = launch_x6p<MODE, 2, 2, 2, 2, 2, 2, 0, 1, 0>(p, st);
+            const int rc = launch_x6p<MODE, 2, 2, 2, 2, 2, 2, 0, 1, 0, 0, ABF>(p, st);
             return rc == SH_OK ? sh_x6_splitk_reduce(p, MODE, st) : rc;
         }
-        return pick_tile_x6p<MODE, 2, EPI, 0>(p, st, force);
+        return pick_tile_x6p<MODE, 2, EPI, 0, ABF>(p, st, force);
     } else {
     if (p.ksplit > 1) {          // K slices (mid-network shapes with an under-filled grid): 128 x 128 tiles into slabs, then the reduce
         int rc;
-        if (p.KH * p.KW == 1) rc = launch_x6p<MODE, 2, 2, 2, 2, 3, AFF, 0, 1, 0>(p, st);
-        else if ((p.Kc & 15) == 0) rc = launch_x6p<MODE, 2, 2, 2, 2, 3, AFF, 0, 1, 1>(p, st);
+        if (p.KH * p.KW == 1) rc = launch_x6p<MODE, 2, 2, 2, 2, 3, AFF, 0, 1, 0, 0, ABF>(p, st);
+        else if ((p.Kc & 15) == 0) rc = launch_x6p<MODE, 2, 2, 2, 2, 3, AFF, 0, 1, 1, 0, ABF>(p, st);
         else return SH_X6P_NO;
         return rc == SH_OK ? sh_x6_splitk_reduce(p, MODE, st) : rc;
     }
-    if (p.KH * p.KW == 1) return pick_tile_x6p<MODE, AFF, EPI, 0>(p, st, force);
-    if ((p.Kc & 15) == 0) return pick_tile_x6p<MODE, AFF, EPI, 1>(p, st, force);
-    if (AFF || EPI == 2) return SH_X6P_NO;
+    if (p.KH * p.KW == 1) return pick_tile_x6p<MODE, AFF, EPI, 0, ABF>(p, st, force);
+    if ((p.Kc & 15) == 0) return pick_tile_x6p<MODE, AFF, EPI, 1, ABF>(p, st, force);
+    if (AFF || EPI == 2 || ABF) return SH_X6P_NO;
     return pick_tile_x6p<MODE, 0, EPI, 2>(p, st, force);
     }
 }
@@ -632,12 +647,15 @@ int sh_x6p_launch(int mode, ConvQ& p, hipStream_t st) {
                           al16(p.bnb_shift) && al16(p.partials)));
     if (bnb && !p.vec_epi) return SH_X6P_NO;
     { static int v = -2; if (v == -2) { const char* e = getenv("SEGHIERO_X6P_VEC"); v = e ? atoi(e) : 1; } if (!v && !bnb) p.vec_epi = 0; }
+    if ((p.act & 2) && !p.vec_epi) return SH_X6P_NO;          // a bf16 output is written by the row-major epilogue only
     if (mode == FPROP) {
         if (bnb) return SH_EINVAL;
+        if (p.act & 1) return aff ? pick_x6p<FPROP, 1, 1, 1>(p, st, force) : pick_x6p<FPROP, 0, 1, 1>(p, st, force);      // bf16 input
         if (aff) return pick_x6p<FPROP, 1, 1>(p, st, force);
         return pick_x6p<FPROP, 0, 1>(p, st, force);
     }
     if (aff) return SH_EINVAL;
+    if (p.lin != nullptr && (p.act & 16)) return bnb ? pick_x6p<DGRAD, 2, 2, 1>(p, st, force) : pick_x6p<DGRAD, 2, 0, 1>(p, st, force);
     if (p.lin != nullptr) return bnb ? pick_x6p<DGRAD, 2, 2>(p, st, force) : pick_x6p<DGRAD, 2, 0>(p, st, force);
     if (bnb) return pick_x6p<DGRAD, 0, 2>(p, st, force);
     return pick_x6p<DGRAD, 0, 0>(p, st, force);
@@ -653,7 +671,8 @@ int sh_x6p_launch(int mode, ConvQ& p, hipStream_t st) {
 // LIN: the dY operand is lin(g, y) = A[co]*g + B[co]*(y - mean[co]) + D[co] of the masked gradient g (p.a) and the raw conv output y
 // (p.a2) -- the deferred second half of this conv's own BatchNorm backward (see AFF == 2 above); a thread owns one 4-channel chunk
 // of co for the whole kernel, so the four coefficient vectors sit in registers.
-template <int WGM, int WGN, int AFF, int LIN = 0>
+// XBF: the stored activations this kernel reads -- the X operand and, with LIN, the y stream -- are bf16 (see conv_x6p_kernel's ABF)
+template <int WGM, int WGN, int AFF, int LIN = 0, int XBF = 0>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_x6p_kernel(const ConvQ p) {
     constexpr int NT = 64 * WGM * WGN, BM = 64 * WGM, BN = 64 * WGN;
     constexpr int AROWB = 2 * BM + 64, BROWB = 2 * BN + 64;
@@ -702,6 +721,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_x6p_kernel(const
         const int pix = kbeg + bk0 + BKPP * i;
         px_ow[i] = pix % p.Wo; const int q2 = pix / p.Wo; px_oh[i] = q2 % p.Ho; px_n[i] = q2 / p.Ho;
     }
+    auto wg_load4 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned elem_off, unsigned ok, bool bf) -> f32x4 {
+        if (bf) {
+            const unsigned voff = ((elem_off * 2u) & ok) | (OOB & ~ok);
+            const u32x2 r = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0));
+            return f32x4{__uint_as_float(r[0]), __uint_as_float(r[1]), 0.f, 0.f};
+        }
+        const unsigned voff = ((elem_off * 4u) & ok) | (OOB & ~ok);
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
+    };
+    auto wg_widen = [&](f32x4 v, bool bf) -> f32x4 { return bf ? bf16x4_to_f32(sh_u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])}) : v; };
     struct Regs { f32x4 a[NA]; f32x4 a2[LIN ? NA : 1]; f32x4 b[NB]; unsigned okm, okl; };
     auto load_half = [&](int q, Regs& R) {
         const int kbase = kbeg + 16 * q;
@@ -713,8 +742,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_x6p_kernel(const
             const unsigned voff = (((unsigned)(pix * (int)p.lda + co) * 4u) & ok) | (OOB & ~ok);
             R.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff, 0, 0));
             if constexpr (LIN) {
-                const unsigned voff2 = (((unsigned)(pix * (int)p.lda2 + co) * 4u) & ok) | (OOB & ~ok);
-                R.a2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a2, voff2, 0, 0));
+                R.a2[i] = wg_load4(rsrc_a2, (unsigned)(pix * (int)p.lda2 + co), ok, XBF);
                 R.okl |= ok & (1u << i);
             }
         }
@@ -724,8 +752,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_x6p_kernel(const
             const int ih = px_oh[i] * p.stride + wg_dh, iw = px_ow[i] * p.stride + wg_dw;
             const unsigned inimg = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? ~0u : 0u;
             const unsigned ok = (unsigned)((pix - kend) >> 31) & b_col_ok & inimg;
-            const unsigned voff = (((unsigned)(((px_n[i] * p.H + ih) * p.W + iw) * (int)p.ldb + wg_ci) * 4u) & ok) | (OOB & ~ok);
-            R.b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, voff, 0, 0));
+            R.b[i] = wg_load4(rsrc_b, (unsigned)(((px_n[i] * p.H + ih) * p.W + iw) * (int)p.ldb + wg_ci), ok, XBF);
             if (AFF) R.okm |= ok & (1u << i);
             int ow = px_ow[i] + 16, oh = px_oh[i], n = px_n[i];
             const bool c1 = ow >= p.Wo; ow -= c1 ? p.Wo : 0; oh += c1 ? 1 : 0;
@@ -741,8 +768,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_x6p_kernel(const
             f32x4 va = R.a[i];
             if constexpr (LIN) {      // pixels beyond the K slice stay exact zeros (D != 0)
                 const bool ok = (R.okl >> i) & 1u;
+                const f32x4 y2 = wg_widen(R.a2[i], XBF);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float w = fmaf(R.a2[i][e] - lM[e], lB[e], fmaf(va[e], lA[e], lD[e])); va[e] = ok ? w : 0.f; }
+                for (int e = 0; e < 4; ++e) { const float w = fmaf(y2[e] - lM[e], lB[e], fmaf(va[e], lA[e], lD[e])); va[e] = ok ? w : 0.f; }
             }
             split4(va, q1, q2, q3);
             *reinterpret_cast<u32x2*>(As + off) = q1;
@@ -751,7 +779,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_x6p_kernel(const
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            f32x4 v = R.b[i];
+            f32x4 v = wg_widen(R.b[i], XBF);
             if constexpr (AFF) {
                 const bool ok = (R.okm >> i) & 1u;
 #pragma unroll
@@ -841,34 +869,40 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_x6p_kernel(const
             }
         }
 }
-template <int WGM, int WGN, int AFF, int LIN = 0>
+template <int WGM, int WGN, int AFF, int LIN = 0, int XBF = 0>
 static int launch_wgrad_x6p(ConvQ& p, int splits, hipStream_t st) {
     constexpr size_t lds = 3 * 32 * (size_t)((2 * 64 * WGM + 64) + (2 * 64 * WGN + 64));
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x6p_kernel<WGM, WGN, AFF, LIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x6p_kernel<WGM, WGN, AFF, LIN, XBF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     p.tiles_m = (int)sh_cdiv(p.M, 64 * WGM); p.tiles_n = (int)sh_cdiv(p.Nn, 64 * WGN);
     p.ksplit = splits;
     const unsigned grid = (unsigned)(p.tiles_m * p.tiles_n) * (unsigned)(p.scatter ? sh_cdiv(splits, 8) * 8 : splits);
-    conv_wgrad_x6p_kernel<WGM, WGN, AFF, LIN><<<grid, 64 * WGM * WGN, lds, st>>>(p);
+    conv_wgrad_x6p_kernel<WGM, WGN, AFF, LIN, XBF><<<grid, 64 * WGM * WGN, lds, st>>>(p);
     return sh_launch_status();
 }
-template <int AFF, int LIN = 0>
+template <int AFF, int LIN = 0, int XBF = 0>
 static int pick_wgrad_x6p(ConvQ& p, int wgm, int wgn, int splits, hipStream_t st) {
-    if (wgm == 4 && wgn == 1) return launch_wgrad_x6p<4, 1, AFF, LIN>(p, splits, st);
-    if (wgm == 2 && wgn == 1) return launch_wgrad_x6p<2, 1, AFF, LIN>(p, splits, st);
-    if (wgm == 2 && wgn == 4) return launch_wgrad_x6p<2, 4, AFF, LIN>(p, splits, st);
-    if (wgm == 1 && wgn == 4) return launch_wgrad_x6p<1, 4, AFF, LIN>(p, splits, st);
-    if (wgm == 1 && wgn == 2) return launch_wgrad_x6p<1, 2, AFF, LIN>(p, splits, st);
-    return launch_wgrad_x6p<2, 2, AFF, LIN>(p, splits, st);
+    if (wgm == 4 && wgn == 1) return launch_wgrad_x6p<4, 1, AFF, LIN, XBF>(p, splits, st);
+    if (wgm == 2 && wgn == 1) return launch_wgrad_x6p<2, 1, AFF, LIN, XBF>(p, splits, st);
+    if (wgm == 2 && wgn == 4) return launch_wgrad_x6p<2, 4, AFF, LIN, XBF>(p, splits, st);
+    if (wgm == 1 && wgn == 4) return launch_wgrad_x6p<1, 4, AFF, LIN, XBF>(p, splits, st);
+    if (wgm == 1 && wgn == 2) return launch_wgrad_x6p<1, 2, AFF, LIN, XBF>(p, splits, st);
+    return launch_wgrad_x6p<2, 2, AFF, LIN, XBF>(p, splits, st);
 }
 // Entry used by sh_conv_wgrad_x6 (same tile / K-slice plan as conv_wgrad_x6_kernel; the slab reduce stays with the caller)
 int sh_x6p_wgrad_launch(ConvQ& p, int wgm, int wgn, int splits, hipStream_t st) {
     const bool aff = p.aff_scale != nullptr;
     if (!x6p_mode() && !aff && !p.lin) return SH_X6P_NO;
     if (p.Wo < 16 || (p.Cin & 3)) return SH_X6P_NO;
+    if (p.act & 32) {          // bf16 X operand; a lin y stream must then be bf16 too (the trunk: both are stored conv outputs)
+        if (p.lin != nullptr && !(p.act & 16)) return SH_X6P_NO;
+        if (p.lin != nullptr) return aff ? pick_wgrad_x6p<1, 1, 1>(p, wgm, wgn, splits, st) : pick_wgrad_x6p<0, 1, 1>(p, wgm, wgn, splits, st);
+        return aff ? pick_wgrad_x6p<1, 0, 1>(p, wgm, wgn, splits, st) : pick_wgrad_x6p<0, 0, 1>(p, wgm, wgn, splits, st);
+    }
+    if (p.lin != nullptr && (p.act & 16)) return SH_X6P_NO;
     if (p.lin != nullptr) return aff ? pick_wgrad_x6p<1, 1>(p, wgm, wgn, splits, st) : pick_wgrad_x6p<0, 1>(p, wgm, wgn, splits, st);
     return aff ? pick_wgrad_x6p<1>(p, wgm, wgn, splits, st) : pick_wgrad_x6p<0>(p, wgm, wgn, splits, st);
 }

@@ -15,7 +15,7 @@ static inline unsigned grid_for(long long work_items, int block = 256, int cap =
 // reference: nn.MaxPool2d(kernel_size=3, stride=2, padding=1) behind models/backbone/resnet.py:68
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned* __restrict__ argmax,
                                                           int H, int W, int Ho, int Wo, int C4, long long total,
-                                                          const float* __restrict__ isc, const float* __restrict__ ish) {
+                                                          const float* __restrict__ isc, const float* __restrict__ ish, int af) {
     GRID_STRIDE(i, total) {
         const int c = (int)(i % C4);
         long long q = i / C4;
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
             for (int kw = 0; kw < 3; ++kw) {
                 const int iw = ow * 2 - 1 + kw;
                 if ((unsigned)iw >= (unsigned)W) continue;
-                f32x4 v = ld4(x + (((n * H + ih) * W + iw) * C4 + c) * 4);
+                f32x4 v = lda4(x, (((n * H + ih) * W + iw) * C4 + c) * 4, af & 1);      // af: bit 0 x, 1 y stored as bf16
                 if (isc != nullptr) {          // input read through the stem's train-mode BatchNorm + ReLU (sh_bn_act's operation order)
                     v = v * ld4(isc + 4 * c) + ld4(ish + 4 * c);
                     v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
                     if (v[j] > m[j] || v[j] != v[j]) { m[j] = v[j]; idx = (idx & ~(0xffu << (8 * j))) | ((unsigned)(kh * 3 + kw) << (8 * j)); }
             }
         }
-        st4(y + i * 4, m);
+        sta4(y, i * 4, m, af & 2);
         if (argmax != nullptr) argmax[i] = idx;
     }
 }
@@ -78,13 +78,13 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned* __rest
     }
 }
 extern "C" int sh_maxpool_fwd(const float* x, const float* in_scale, const float* in_shift, float* y, uint8_t* argmax, int N, int H, int W,
-                              int C, void* stream) {
+                              int C, int act_flags, void* stream) {
     if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || ((uintptr_t)argmax & 3)) return SH_EINVAL;
     if ((in_scale == nullptr) != (in_shift == nullptr) || (((uintptr_t)in_scale | (uintptr_t)in_shift) & 15)) return SH_EINVAL;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const long long total = (long long)N * Ho * Wo * (C / 4);
     maxpool_fwd_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>(x, y, reinterpret_cast<unsigned*>(argmax), H, W, Ho, Wo, C / 4, total,
-                                                                         in_scale, in_shift);
+                                                                         in_scale, in_shift, act_flags);
     return sh_launch_status();
 }
 extern "C" int sh_maxpool_bwd(const uint8_t* argmax, const float* dy, float* dx, int N, int H, int W, int C, void* stream) {

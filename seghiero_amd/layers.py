@@ -185,7 +185,7 @@ def cba_fwd(x, weight, geom, bn, relu, training, residual=None, out=None, lazy=F
         ops.conv_fprop_act(dense(x), weight, coefs, out, relu, residual, s, p, d)
         y = None
     else:
-        y = ops.new_act(n, o, ho, wo, x.device, ld=ld, zero=ld != o)
+        y = ops.new_act(n, o, ho, wo, x.device, ld=ld, zero=ld != o, dtype=ops.stored_dtype())      # (bf16 inside ops.stored_as)
         partials = ops.conv_partials(m, o, x.device) if training else None
         _fprop(x, weight, None, y, partials, s, p, d)
         coefs = _bn_coefs(bn, partials, m, training, o, x.device)
@@ -195,7 +195,7 @@ def cba_fwd(x, weight, geom, bn, relu, training, residual=None, out=None, lazy=F
             out = LazyAffine(y, coefs)
         else:
             if out is None:
-                out = ops.new_act(n, o, ho, wo, x.device, ld=ld, zero=ld != o)
+                out = ops.new_act(n, o, ho, wo, x.device, ld=ld, zero=ld != o, dtype=ops.stored_dtype())
             if isinstance(residual, LazyAffine):
                 ops.bn_act(y, coefs, out, relu, residual.y, res_coefs=residual.coefs)
             else:

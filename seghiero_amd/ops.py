@@ -75,12 +75,36 @@ def _require_gpu(t):
 
 
 # ----------------------------------------------------------------------------- tensor helpers
-def new_act(n, c, h, w, device, ld=None, zero=False):
-    """Logical [n,c,h,w] fp32 tensor over NHWC memory with pixel stride ld (>= c, default c)."""
+def new_act(n, c, h, w, device, ld=None, zero=False, dtype=torch.float32):
+    """Logical [n,c,h,w] tensor over NHWC memory with pixel stride ld (>= c, default c); fp32, or bf16 for STORED activations
+    (stored_dtype())."""
     ld = c if ld is None else ld
-    buf = (torch.zeros if zero else torch.empty)((n, h, w, ld), device=device, dtype=torch.float32)
+    buf = (torch.zeros if zero else torch.empty)((n, h, w, ld), device=device, dtype=dtype)
     t = buf.permute(0, 3, 1, 2)
     return t if ld == c else t[:, :c]
+
+
+# bf16 activation storage (BASELINE configs[4]; include/seghiero_hip.h "bf16 ACTIVATION STORAGE"): inside `with stored_as(torch.bfloat16)`
+# -- the training forward of the ResNet trunk when its act_dtype says so -- the raw conv outputs and block outputs that layers.py
+# allocates are bf16; every kernel computes in fp32, BatchNorm statistics come from the fp32 accumulators, gradients stay fp32.
+_STORED = torch.float32
+
+
+def stored_dtype():
+    return _STORED
+
+
+class stored_as:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _STORED
+        self.prev, _STORED = _STORED, self.dtype
+
+    def __exit__(self, *exc):
+        global _STORED
+        _STORED = self.prev
 
 
 def pad4(c):
@@ -91,8 +115,17 @@ def pm(t):
     """(data_ptr, ld) of a logical-NCHW tensor with NHWC memory; raises if the strides are anything else.
 
     Element (n,c,h,w) must live at ((n*H + h)*W + w)*ld + c; strides of size-1 dims are ignored."""
+    return _pm(t, False)[:2]
+
+
+def pmx(t):
+    """(data_ptr, ld, 1 if bf16 else 0): as pm, for the entry points that take bf16-stored activations (act_flags)."""
+    return _pm(t, True)
+
+
+def _pm(t, allow_bf16):
     _require_gpu(t)
-    if t.dim() != 4 or t.dtype != torch.float32:
+    if t.dim() != 4 or not (t.dtype == torch.float32 or (allow_bf16 and t.dtype == torch.bfloat16)):
         raise SegHieroHipError(f"expected a 4-D fp32 tensor, got {tuple(t.shape)} {t.dtype}")
     n, c, h, w = t.shape
     s = t.stride()
@@ -108,7 +141,7 @@ def pm(t):
         (n == 1 or s[0] == h * w * ld) and ld >= c
     if not ok:
         raise SegHieroHipError(f"tensor is not NHWC-strided: shape {tuple(t.shape)} strides {s}")
-    return t.data_ptr(), ld
+    return t.data_ptr(), ld, int(t.dtype == torch.bfloat16)
 
 
 def is_nhwc(t):
@@ -185,32 +218,35 @@ def conv_fprop_aff(x, in_coefs, weight, bias, y, partials, stride, pad, dil):
         return False
     n, cin, h, w = x.shape
     o, _, kh, kw = weight.shape
-    xp, ldx = pm(x)
-    yp, ldy = pm(y)
+    xp, ldx, xb = pmx(x)
+    yp, ldy, yb = pmx(y)
     ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
     m = n * ho * wo
     cost = (2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin + m * o + o * cin * kh * kw))
     ws, nb = _splitk_ws(0, n, h, w, cin, o, kh, kw, stride, pad, dil, 0, x.device)
     return _call_fused("sh_conv_fprop_x6_aff", xp, ldx, in_coefs[2].data_ptr(), in_coefs[3].data_ptr(), w_ohwi(weight).data_ptr(),
                        None if bias is None else bias.data_ptr(), yp, ldy, None if partials is None else partials.data_ptr(),
-                       n, h, w, cin, o, kh, kw, stride, pad, dil, ws, nb, _st(), cost=cost, key=_ckey(n, h, w, cin, o, kh, stride, dil))
+                       n, h, w, cin, o, kh, kw, stride, pad, dil, ws, nb, xb | (yb << 1), _st(), cost=cost,
+                       key=_ckey(n, h, w, cin, o, kh, stride, dil))
 
 
 def conv_fprop(x, weight, bias, y, partials, stride, pad, dil):
     n, cin, h, w = x.shape
     o, _, kh, kw = weight.shape
-    xp, ldx = pm(x)
-    yp, ldy = pm(y)
+    xp, ldx, xb = pmx(x)
+    yp, ldy, yb = pmx(y)
     ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
     m = n * ho * wo
     x6 = CONV_IMPL == "x6"
+    if (xb or yb) and not x6:
+        raise SegHieroHipError("bf16-stored activations need the x6 convolution path")
     wptr = w_ohwi(weight).data_ptr()
     cost = (2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin + m * o + o * cin * kh * kw))
     args = (xp, ldx, wptr, None if bias is None else bias.data_ptr(), yp, ldy,
             None if partials is None else partials.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil)
     if x6:
         ws, nb = _splitk_ws(0, n, h, w, cin, o, kh, kw, stride, pad, dil, 0, x.device)
-        _call("sh_conv_fprop_x6", *args, ws, nb, _st(), cost=cost, key=_ckey(n, h, w, cin, o, kh, stride, dil))
+        _call("sh_conv_fprop_x6", *args, ws, nb, xb | (yb << 1), _st(), cost=cost, key=_ckey(n, h, w, cin, o, kh, stride, dil))
     else:
         _call("sh_conv_fprop", *args, _st(), cost=cost, key=_ckey(n, h, w, cin, o, kh, stride, dil))
 
@@ -320,18 +356,18 @@ def conv_dgrad_bnb(dy, weight, g, y_prev, coefs, relu, partials, stride, pad, di
     o, _, kh, kw = weight.shape
     dyp, lddy = pm(dy)
     gp, ldg = pm(g)
-    ypp, ldyp = pm(y_prev)
+    ypp, ldyp, ypb = pmx(y_prev)
     if lddy < pad4(o):
         return False
     ap, lda = (None, 0) if addend is None else pm(addend)
-    opp, ldop = (None, 0) if out_prev is None else pm(out_prev)
+    opp, ldop, opb = (None, 0, 0) if out_prev is None else pmx(out_prev)
     ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
     m = n * ho * wo
     cost = (2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin * (3 if addend is not None else 2) + m * o + o * cin * kh * kw))
     ws, nb = _splitk_ws(1, n, h, w, cin, o, kh, kw, stride, pad, dil, 0, g.device)
     return _call_fused("sh_conv_dgrad_x6_bnb", dyp, lddy, weight_transpose(weight).data_ptr(), ap, lda, gp, ldg, ypp, ldyp, opp, ldop,
                        coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(), coefs[3].data_ptr(), int(bool(relu)),
-                       partials.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, ws, nb, _st(), cost=cost,
+                       partials.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, ws, nb, ypb | (opb << 1), _st(), cost=cost,
                        key=_ckey(n, h, w, cin, o, kh, stride, dil))
 
 
@@ -344,20 +380,21 @@ def conv_dgrad_lin(dd, weight, dx, addend=None, bnb=None):
     n, cin, h, w = dx.shape
     o = weight.shape[0]
     gp, ldg = pm(dd.g)
-    yp, ldy = pm(dd.y)
+    yp, ldy, yb = pmx(dd.y)
     dxp, lddx = pm(dx)
     ap, lda = (None, 0) if addend is None else pm(addend)
+    ypb = 0
     if bnb is None:
         bargs = (None, 0, None, None, None, None, 0, None)
     else:
         y_prev, cf, partials = bnb
-        ypp, ldyp = pm(y_prev)
+        ypp, ldyp, ypb = pmx(y_prev)
         bargs = (ypp, ldyp, cf[0].data_ptr(), cf[1].data_ptr(), cf[2].data_ptr(), cf[3].data_ptr(), 1, partials.data_ptr())
     m = n * h * w
     cost = (2.0 * m * o * cin, 4.0 * (m * cin * (1 + (addend is not None) + (bnb is not None)) + 2 * m * o + o * cin))
     ws, nb = _splitk_ws(1, n, h, w, cin, o, 1, 1, 1, 0, 1, 0, dx.device)
     return _call_fused("sh_conv_dgrad_x6_lin", gp, ldg, yp, ldy, dd.lin.data_ptr(), weight_transpose(weight).data_ptr(), ap, lda, dxp, lddx,
-                       *bargs, n, h, w, cin, o, ws, nb, _st(), cost=cost, key=_ckey(n, h, w, cin, o, 1, 1, 1))
+                       *bargs, n, h, w, cin, o, ws, nb, yb | (ypb << 1), _st(), cost=cost, key=_ckey(n, h, w, cin, o, 1, 1, 1))
 
 
 _WS = {}
@@ -429,16 +466,23 @@ def conv_wgrad(x, dy, dweight, stride, pad, dil, side=False, aff=None):
     n, cin, h, w = x.shape
     o, _, kh, kw = dweight.shape
     dd = dy if isinstance(dy, DeferredDy) else None          # dy evaluated in the loader (check lin_ok before deferring)
+    if x.dtype == torch.bfloat16 and not (CONV_IMPL == "x6" and cin % 4 == 0 and conv_out_hw(h, w, kh, kw, stride, pad, dil)[1] >= 16):
+        # bf16-stored x where the pipelined wgrad has no instantiation (output width < 16: tiny test inputs): widen once
+        x = x.float()
+        if dd is not None:
+            dy, dd = dd.materialize(), None
+    if dd is not None and (dd.y.dtype == torch.bfloat16) != (x.dtype == torch.bfloat16):
+        dy, dd = dd.materialize(), None                      # the kernel takes both stored streams in one element type
     if dd is not None:
         dy = dd.g
     # tiny output-channel counts (cls_seg, aux head) stay on the f32-MFMA kernel
     x6 = CONV_IMPL == "x6" and o >= 32 and (cin * kh * kw >= 128 or (cin * kh * kw == 64 and o >= 128))
-    if aff is not None or dd is not None:
+    if aff is not None or dd is not None or x.dtype == torch.bfloat16:
         x6 = True
     need = LIB.raw("sh_conv_wgrad_x6_workspace" if x6 else "sh_conv_wgrad_workspace")(n, h, w, cin, o, kh, kw, stride, pad, dil)
     if need < 0:
         raise SegHieroHipError("sh_conv_wgrad_workspace rejected the geometry")
-    xp, ldx = pm(x)
+    xp, ldx, xb = pmx(x)
     dyp, lddy = pm(dy)
     ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
     m = n * ho * wo
@@ -448,20 +492,20 @@ def conv_wgrad(x, dy, dweight, stride, pad, dil, side=False, aff=None):
     def launch(tag="wgrad"):
         ws = workspace(need, x.device, tag)              # one workspace per stream: its kernels stay in that stream's order
         if dd is not None:
-            y2p, ldy2 = pm(dd.y)
+            y2p, ldy2, y2b = pmx(dd.y)
             if not _call_fused("sh_conv_wgrad_x6_lin", xp, ldx, None if aff is None else aff[2].data_ptr(), None if aff is None else aff[3].data_ptr(),
                                dyp, lddy, y2p, ldy2, dd.lin.data_ptr(), dweight.data_ptr(), ws.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil,
-                               _st(), cost=cost, key=_ckey(n, h, w, cin, o, kh, stride, dil)):
+                               xb | (y2b << 1), _st(), cost=cost, key=_ckey(n, h, w, cin, o, kh, stride, dil)):
                 raise SegHieroHipError("sh_conv_wgrad_x6_lin: unsupported geometry (check lin_ok before deferring the BatchNorm-backward apply)")
             return
         if aff is not None:
             if not _call_fused("sh_conv_wgrad_x6_aff", xp, ldx, aff[2].data_ptr(), aff[3].data_ptr(), dyp, lddy, dweight.data_ptr(),
-                               ws.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, _st(), cost=cost,
+                               ws.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, xb, _st(), cost=cost,
                                key=_ckey(n, h, w, cin, o, kh, stride, dil)):
                 raise SegHieroHipError("sh_conv_wgrad_x6_aff: unsupported geometry (check wgrad_aff_ok before deferring the activation)")
             return
-        _call(name, xp, ldx, dyp, lddy, dweight.data_ptr(), ws.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, _st(), cost=cost,
-              key=_ckey(n, h, w, cin, o, kh, stride, dil))
+        _call(name, xp, ldx, dyp, lddy, dweight.data_ptr(), ws.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, *((xb,) if x6 else ()), _st(),
+              cost=cost, key=_ckey(n, h, w, cin, o, kh, stride, dil))
 
     if not (side and WGRAD_ASYNC and x.is_cuda):
         launch()
@@ -678,12 +722,12 @@ def channel_stats(y):
 def bn_act(y, coefs, out, relu, residual=None, res_coefs=None):
     """res_coefs: `residual` is a raw conv output whose BatchNorm (no ReLU) is applied on the fly (the downsample branch)."""
     n, c, h, w = y.shape
-    yp, ldy = pm(y)
-    op, ldo = pm(out)
-    rp, ldr = (None, 0) if residual is None else pm(residual)
+    yp, ldy, yb = pmx(y)
+    op, ldo, ob = pmx(out)
+    rp, ldr, rb = (None, 0, 0) if residual is None else pmx(residual)
     _call("sh_bn_act", yp, ldy, coefs[2].data_ptr(), coefs[3].data_ptr(), rp, ldr,
           None if res_coefs is None else res_coefs[2].data_ptr(), None if res_coefs is None else res_coefs[3].data_ptr(),
-          op, ldo, n * h * w, c, int(relu), _st())
+          op, ldo, n * h * w, c, int(relu), yb | (rb << 1) | (ob << 2), _st())
 
 
 class DeferredDy:
@@ -705,12 +749,12 @@ class DeferredDy:
             ld = pad4(c)
             dy = new_act(n, c, h, w, self.y.device, ld=ld, zero=ld != c)
             gp, ldg = pm(self.g)
-            yp, ldy = pm(self.y)
+            yp, ldy, yb = pmx(self.y)
             dyp, lddy = pm(dy)
             cf = self.coefs
             _call("sh_bn_bwd_apply", gp, ldg, None, 0, yp, ldy, cf[0].data_ptr(), cf[1].data_ptr(), cf[2].data_ptr(), cf[3].data_ptr(),
                   None if self.gamma is None else self.gamma.data_ptr(), self.red[2].data_ptr(), self.red[3].data_ptr(), dyp, lddy,
-                  None, 0, n * h * w, c, 0, _st())
+                  None, 0, n * h * w, c, 0, yb, _st())
             self._dy = dy
         return self._dy
 
@@ -745,8 +789,9 @@ def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None, d
     n, c, h, w = y.shape
     m = n * h * w
     dev = y.device
-    yp, ldy = pm(y)
-    op, ldo = (None, 0) if out is None else pm(out)
+    yp, ldy, yb = pmx(y)
+    op, ldo, ob = (None, 0, 0) if out is None else pmx(out)
+    af = yb | (ob << 1)
     packed = hasattr(dout, "partials")
     if packed:
         partials, dout, relu, op, ldo = dout.partials, dout.g, 0, None, 0
@@ -760,11 +805,11 @@ def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None, d
         if defer and relu:
             gmask = new_act(n, c, h, w, dev)
             if not _call_fused("sh_bn_bwd_reduce", dop, lddo, op, ldo, yp, ldy, coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(),
-                               coefs[3].data_ptr(), partials.data_ptr(), m, c, relu, gmask.data_ptr(), c, _st()):
+                               coefs[3].data_ptr(), partials.data_ptr(), m, c, relu, gmask.data_ptr(), c, af, _st()):
                 gmask, defer = None, False
         if gmask is None:
             _call("sh_bn_bwd_reduce", dop, lddo, op, ldo, yp, ldy, coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(),
-                  coefs[3].data_ptr(), partials.data_ptr(), m, c, relu, None, 0, _st())
+                  coefs[3].data_ptr(), partials.data_ptr(), m, c, relu, None, 0, af, _st())
         else:
             dout, relu, op, ldo = gmask, 0, None, 0          # from here on as a packed gradient: mask applied
             dop, lddo = pm(dout)
@@ -797,7 +842,7 @@ def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None, d
     drp, lddr = (None, 0) if (dres is None or packed) else pm(dres)
     _call("sh_bn_bwd_apply", dop, lddo, op, ldo, yp, ldy, coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(),
           coefs[3].data_ptr(), None if gamma is None else gamma.data_ptr(), red[2].data_ptr(), red[3].data_ptr(), dyp, lddy,
-          drp, lddr, m, c, relu, _st())
+          drp, lddr, m, c, relu, af, _st())
     return dy, red[0], red[1], dres
 
 
@@ -806,14 +851,14 @@ def maxpool_fwd(x, want_argmax=True, aff=None):
     """-> (y, argmax): argmax uint8 [N,Ho,Wo,C] (window position of the first maximum) or None.
     aff = (4, C) BatchNorm coefficients: x is the stem conv's raw output, read as relu(x * scale + shift)."""
     n, c, h, w = x.shape
-    xp, ldx = pm(x)
+    xp, ldx, xb = pmx(x)
     if ldx != c:
         raise SegHieroHipError("maxpool needs a dense NHWC tensor")
     ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
-    y = new_act(n, c, ho, wo, x.device)
+    y = new_act(n, c, ho, wo, x.device, dtype=x.dtype)                # stored like its input
     am = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.uint8) if want_argmax else None
     _call("sh_maxpool_fwd", xp, None if aff is None else aff[2].data_ptr(), None if aff is None else aff[3].data_ptr(), y.data_ptr(),
-          None if am is None else am.data_ptr(), n, h, w, c, _st())
+          None if am is None else am.data_ptr(), n, h, w, c, xb | (xb << 1), _st())
     return y, am
 
 
@@ -906,7 +951,7 @@ def dense_copy(t, ld=None):
     ones[1].zero_()
     tp, ldt = pm(t)
     op, ldo = pm(out)
-    _call("sh_bn_act", tp, ldt, ones[0].data_ptr(), ones[1].data_ptr(), None, 0, None, None, op, ldo, n * h * w, c, 0, _st())
+    _call("sh_bn_act", tp, ldt, ones[0].data_ptr(), ones[1].data_ptr(), None, 0, None, None, op, ldo, n * h * w, c, 0, 0, _st())
     return out
 
 

@@ -101,15 +101,17 @@ class SegHieroTrainer:
 
     def __init__(self, depth=50, n_fine=9, coarse_to_fine_map=((0, 3), (4, 6), (7,), (8,)), lr=0.01, fine_weight=1.0,
                  device="cuda:0", head_kw=None, grad_sync=None, super_coarse_to_coarse_map=None, rmi_radius=3,
-                 rmi_pool_way=0, rmi_pool_size=3, rmi_pool_stride=3):
+                 rmi_pool_way=0, rmi_pool_size=3, rmi_pool_stride=3, act_dtype=torch.float32):
         """``super_coarse_to_coarse_map`` given -> 3-level model + RMIHieraTripletLoss (train.py:202-233), else the
-        2-level HieraTripletLoss (train.py:176-200)."""
+        2-level HieraTripletLoss (train.py:176-200).  ``act_dtype=torch.bfloat16``: the trunk stores its activations as bf16
+        (BASELINE configs[4]; ResNetBackbone.act_dtype)."""
         cfg_map = [list(x) for x in coarse_to_fine_map]
         sup_map = None if super_coarse_to_coarse_map is None else [list(x) for x in super_coarse_to_coarse_map]
         self.n_fine, self.n_coarse = n_fine, len(cfg_map)
         self.n_super = 0 if sup_map is None else len(sup_map)
         self.device = torch.device(device)
         self.backbone = ResNetBackbone(depth=depth, pretrained=False)
+        self.backbone.act_dtype = act_dtype
         ch = self.backbone.out_channels
         kw = dict(in_channels=ch[3], c1_in_channels=ch[0], c1_channels=48, aspp_channels=512,
                   dilations=(1, 12, 24, 36), num_classes=n_fine + self.n_coarse + self.n_super, proj_dim=256,

@@ -556,3 +556,64 @@ def test_eval_step_fused_bn_epilogue_is_bit_identical(sa):
     assert float(l0) == float(l1) and torch.equal(c0, c1)
     assert abs(float(l2) - float(l1)) <= 1e-5 * abs(float(l1))
     assert int(c1[1]) > 0
+
+
+@pytest.mark.parametrize("depth,size", [(50, 128), (18, 128)])
+def test_bf16_activation_storage_of_the_trunk(sa, depth, size):
+    """BASELINE configs[4]: the trunk's raw conv outputs and block outputs STORED as bf16 (ResNetBackbone.act_dtype), arithmetic /
+    BatchNorm statistics / gradients in fp32.  Against the fp32-storage HIP path on the same weights and inputs:
+    stage outputs within 0.5 relative L2 (each stored tensor carries 2^-9 relative rounding and a random deep trunk amplifies it), the
+    tensors really are bf16, and -- per block, from the SAME bf16-rounded block input, so that storage rounding does not compound --
+    outputs within 1e-2, gradients: median within 8e-2, worst (BatchNorm biases) within 0.15 of the fp32-storage block
+    (ReLU flips of the rounded pre-activations, see below)."""
+    import copy
+    from seghiero_amd import layers as L, ops
+    from seghiero_amd.backbone import ResNetBackbone, _block_bwd, _block_fwd
+    torch.manual_seed(depth)
+    a = ResNetBackbone(depth, pretrained=False).to(DEV).train()
+    b = copy.deepcopy(a)
+    b.act_dtype = torch.bfloat16
+    x = torch.randn(4, 3, size, size, generator=torch.Generator().manual_seed(1)).to(DEV)
+    outs_a, outs_b = a(x), b(x)
+    for oa, ob in zip(outs_a, outs_b):
+        # a randomly initialised deep trunk amplifies ANY perturbation (1e-6 of the input -> 6e-4 of the logits, tests/diag/sens50.py):
+        # end to end this only shows that nothing is grossly off; the per-block comparison below is the parity check
+        assert ob.dtype == torch.float32 and relerr(ob, oa) < 0.5, relerr(ob, oa)
+    # whole-trunk backward runs (every bf16-aware kernel of the hand-scheduled backward is exercised) and stays finite
+    gs = [torch.randn(o.shape, generator=torch.Generator().manual_seed(2)).to(DEV) for o in outs_b]
+    torch.autograd.backward([outs_b[0], outs_b[2], outs_b[3]], [gs[0], gs[2], gs[3]])
+    torch.autograd.backward([outs_a[0], outs_a[2], outs_a[3]], [gs[0], gs[2], gs[3]])
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.isfinite(pb.grad).all(), k
+    # block by block from the same (bf16-representable) input
+    g = torch.Generator().manual_seed(3)
+    worst = []
+    for li, hw in ((1, size // 4), (2, size // 4), (3, size // 8), (4, size // 16)):
+        layer = getattr(a, f"layer{li}")
+        for bi in (0, len(layer) - 1):
+            blk = layer[bi]
+            cin = blk.conv1.weight.shape[1]
+            h = hw if bi == 0 else (hw if li == 1 else hw // 2)
+            xin = torch.randn(4, cin, h, h, generator=g).bfloat16().float().to(DEV).relu()
+            res = {}
+            for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+                with ops.stored_as(dt):
+                    xs = ops.new_act(4, cin, h, h, DEV, dtype=dt)
+                    xs.copy_(xin)
+                    y, saved = _block_fwd(blk, xs, True)
+                assert y.dtype == dt and saved[0][0].y.dtype == dt
+                dout = torch.randn(y.shape, generator=torch.Generator().manual_seed(5)).to(DEV)
+                gm = L.GradMap()
+                dx = _block_bwd(blk, saved, L.grad_as_nhwc_padded(dout, y.shape[1]), gm)
+                ops.join_wgrad()
+                res[name] = (y.float(), dx, {k: gm.g[id(p)].reshape(p.shape).clone() for k, p in blk.named_parameters()})
+            worst.append((relerr(res["bf16"][0], res["f32"][0]), f"layer{li}.{bi}.out"))
+            assert worst[-1][0] < 1e-2, worst[-1]
+            worst.append((relerr(res["bf16"][1], res["f32"][1]), f"layer{li}.{bi}.dx"))
+            for k in res["f32"][2]:
+                worst.append((relerr(res["bf16"][2][k], res["f32"][2][k]), f"layer{li}.{bi}.{k}"))
+    worst.sort(reverse=True)
+    # rounding a stored pre-activation to bf16 (2^-9 relative) moves it across 0 for a fraction f ~ 1e-3 of the elements, and a ReLU
+    # that flips changes its gradient element by 100 %: sqrt(f) ~ 3-5 % relative L2 on every gradient tensor of ANY implementation of
+    # bf16 activation storage -- the stated tolerance: median 8 %, worst (BatchNorm biases: sums with cancellation) 15 %
+    assert worst[0][0] < 0.15 and worst[len(worst) // 2][0] < 0.08, (worst[:5], worst[len(worst) // 2])

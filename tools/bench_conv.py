@@ -48,7 +48,7 @@ def phase_profile(x, wt, y, part, n, h, w, cin, cout, k, s, p):
     xp, ldx = ops.pm(x)
     yp, ldy = ops.pm(y)
     ops._call("sh_conv_fprop_x6", xp, ldx, ops.w_ohwi(wt).data_ptr(), None, yp, ldy, part.data_ptr(), n, h, w, cin, cout, k, k, s, p, 1,
-              dbg.data_ptr(), dbg.numel(), ops._st())
+              dbg.data_ptr(), dbg.numel(), 0, ops._st())
     torch.cuda.synchronize()
     raw = dbg.cpu().numpy().view(np.uint64)
     total = raw[65536:65536 + 64 * 16].astype(np.float64)

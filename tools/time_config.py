@@ -22,6 +22,8 @@ def main():
     size, batch = cfg.pop("size"), cfg.pop("batch")
     if len(sys.argv) > 2:
         batch = int(sys.argv[2])
+    if len(sys.argv) > 3 and sys.argv[3] == "bf16":          # trunk activations stored as bf16 (BASELINE configs[4])
+        cfg["act_dtype"] = torch.bfloat16
     torch.manual_seed(0)
     tr = SegHieroTrainer(lr=0.01, device="cuda:0", **cfg)
     tr.train()
