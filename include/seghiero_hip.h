@@ -174,22 +174,22 @@ int sh_dw_tile_rows(void);                      /* rows per stat-partial of sh_d
  * read as relu(x * in_scale[c] + in_shift[c]) -- the producer's train-mode BatchNorm + ReLU in the loader (zero padding stays
  * zero), see sh_conv_fprop_x6_aff. */
 int sh_dwconv_fprop(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* w, float* y, int ldy,
-                    float* stat_partials, int N, int H, int W, int C, int dil, void* stream);
+                    float* stat_partials, int N, int H, int W, int C, int dil, int act_flags, void* stream);
 /* y_lin / lin (optional, both or neither; dgrad, dgrad_bnb, wgrad): deferred BatchNorm-backward apply of the depthwise conv's own
  * BatchNorm -- `dy` holds the masked gradient g and the loader evaluates dy = lin[0][c]*g + lin[1][c]*(y_lin - lin[2][c]) + lin[3][c]
  * (sh_bn_bwd_finalize's lin; y_lin = the conv's raw output), so sh_bn_bwd_apply and the dy tensor are skipped
  * (sep_aspp_contrast_head.py:43-61).  dil == 1 with H, W multiples of 8 only; SH_EUNSUPPORTED otherwise. */
 int sh_dwconv_dgrad(const float* dy, int lddy, const float* y_lin, int ldyl, const float* lin, const float* w, float* dx, int lddx,
-                    int N, int H, int W, int C, int dil, int accumulate, void* stream);
+                    int N, int H, int W, int C, int dil, int accumulate, int act_flags, void* stream);
 /* ... with the front half of the producer layer's BatchNorm backward in the epilogue (see sh_conv_dgrad_x6_bnb):
  * g <- relumask(y_prev*scale + shift) * dx, stat_partials[sh_dw_partials(N,H,W)][2][C] <- (sum g, sum g*xhat) per 64 pixels. */
 int sh_dwconv_dgrad_bnb(const float* dy, int lddy, const float* y_lin, int ldyl, const float* lin, const float* w, float* g, int ldg,
                         const float* y_prev, int ldyp, const float* mean, const float* invstd, const float* scale, const float* shift,
-                        float* stat_partials, int N, int H, int W, int C, int dil, void* stream);
+                        float* stat_partials, int N, int H, int W, int C, int dil, int act_flags, void* stream);
 /* dw_partials: [sh_dw_partials(N,H,W)][9][C] floats; dw: [C][9] */
 int sh_dwconv_wgrad(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* dy, int lddy,
                     const float* y_lin, int ldyl, const float* lin, float* dw_partials, float* dw, int N, int H, int W, int C, int dil,
-                    void* stream);
+                    int act_flags, void* stream);
 
 /* bf16 ACTIVATION STORAGE (BASELINE configs[4]).  Raw conv outputs and block outputs may be stored as bf16 -- half the HBM bytes of the
  * streaming kernels and of the HBM-bound layer-1 convolutions; all arithmetic, the BatchNorm statistics (taken from the fp32
@@ -200,6 +200,8 @@ int sh_dwconv_wgrad(const float* x, int ldx, const float* in_scale, const float*
  *   sh_bn_act: bit 0 y, 1 residual, 2 out.   sh_bn_bwd_reduce / sh_bn_bwd_apply: bit 0 y, 1 out.   sh_maxpool_fwd: bit 0 x, 1 y.
  *   sh_conv_fprop_x6 / _aff: bit 0 x, 1 y (statistics from the fp32 accumulators).   sh_conv_dgrad_x6_bnb: bit 0 y_prev, 1 out_prev.
  *   sh_conv_dgrad_x6_lin: bit 0 y, 1 y_prev.   sh_conv_wgrad_x6 / _aff: bit 0 x.   sh_conv_wgrad_x6_lin: bit 0 x, 1 y (x bf16 => y bf16).
+ *   sh_dwconv_fprop: bit 0 x, 1 y.   sh_dwconv_dgrad: bit 0 y_lin.   sh_dwconv_dgrad_bnb: bit 0 y_lin, 1 y_prev.   sh_dwconv_wgrad: bit 0 x,
+ *   1 y_lin (strip-walk geometries only: dilation 1, H and W multiples of 8).   sh_bilinear_fwd: bit 0 y.
  * Gradients (dy, g, dx, dW), weights, coefficient tables and statistics partials are always fp32. */
 /* batch norm ------------------------------------------------------------------------------ */
 /* Train-mode nn.BatchNorm2d (every BN of the path; math: SURVEY A.2).  Combines the centred stat partials
@@ -293,7 +295,7 @@ int sh_avgpool_bwd(const float* dy, float* dx, int lddx, int N, int HW, int C, f
 int sh_broadcast_hw(const float* x, float* y, int ldy, int N, int HW, int C, void* stream);
 int sh_sum_hw(const float* dy, int lddy, float* dx, int N, int HW, int C, void* stream);
 /* F.interpolate(mode='bilinear', align_corners=False) NHWC (sep_aspp_contrast_head.py:235-238) and its backward. */
-int sh_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int h, int w, int H, int W, int C, void* stream);
+int sh_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int h, int w, int H, int W, int C, int act_flags, void* stream);
 /* workspace (optional, sh_bilinear_bwd_workspace bytes, 16-byte aligned; used when H >= 2h and W >= 2w): backward that reads dy once
  * (row bands + two partial planes) instead of the gather form's ~4 reads per element. */
 int64_t sh_bilinear_bwd_workspace(int N, int h, int w, int C);

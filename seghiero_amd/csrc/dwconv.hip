@@ -25,9 +25,10 @@ __device__ __forceinline__ f32x4 dw_in(const float* p, const float* isc, const f
 
 // dgrad epilogue = front half of the BatchNorm backward of the layer that produced the conv's input (see sh_conv_dgrad_x6_bnb):
 // g = relumask(y * scale + shift) * dx is stored and (sum g, sum g * xhat) per 64-pixel block go to `partials`
-struct DwBnb { const float* y; long long ldy; const float* mean; const float* invstd; const float* scale; const float* shift; float* partials; };
+struct DwBnb { const float* y; long long ldy; const float* mean; const float* invstd; const float* scale; const float* shift; float* partials;
+               int y_bf; };          // y_bf: y stored as bf16 (common.h lda4)
 __device__ __forceinline__ f32x4 dw_bnb_apply(const DwBnb& b, long long m, int c, f32x4 dx, f32x4& sg, f32x4& sq) {
-    const f32x4 yv = ld4(b.y + m * b.ldy + c);
+    const f32x4 yv = lda4(b.y, m * b.ldy + c, b.y_bf);
     const f32x4 a = yv * ld4(b.scale + c) + ld4(b.shift + c);                // the forward's own arithmetic (bn_act_kernel)
 #pragma unroll
     for (int j = 0; j < 4; ++j) if (!(a[j] > 0.f)) dx[j] = 0.f;
@@ -311,14 +312,14 @@ __device__ __forceinline__ bool dw_walk_inside(const DwWalk& q, int H, int W, in
 }
 // raw element (zero outside the image); the producer's BatchNorm + ReLU is applied by dw_walk_act when the value goes to LDS,
 // i.e. AFTER the arithmetic of the current tile, so the prefetch stays in flight
-__device__ __forceinline__ f32x4 dw_walk_fetch(const float* __restrict__ x, long long ldx, const DwWalk& q, int H, int W, int hy, int ix) {
+__device__ __forceinline__ f32x4 dw_walk_fetch(const float* __restrict__ x, long long ldx, const DwWalk& q, int H, int W, int hy, int ix, int bf = 0) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (dw_walk_inside(q, H, W, hy, ix)) v = ld4(x + (((long long)q.n * H + q.ty * DT + hy - 1) * W + ix) * ldx + q.c);
+    if (dw_walk_inside(q, H, W, hy, ix)) v = lda4(x, (((long long)q.n * H + q.ty * DT + hy - 1) * W + ix) * ldx + q.c, bf);
     return v;
 }
 // deferred BatchNorm-backward apply (dgrad / wgrad of a depthwise conv -> BN layer): the gradient operand is lin(g, y) =
 // A*g + B*(y - mean) + D per channel (sh_bn_bwd_finalize's lin[4][C]) of the masked gradient g and the raw conv output y
-struct DwLin { const float* y; long long ldy; const float* lin; };
+struct DwLin { const float* y; long long ldy; const float* lin; int y_bf; };
 struct DwLinC { f32x4 a, b, mu, d; };
 __device__ __forceinline__ DwLinC dw_lin_coefs(const DwLin& L, int C, int c, bool cok) {
     DwLinC k; k.a = k.b = k.mu = k.d = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -341,11 +342,11 @@ __device__ __forceinline__ f32x4 dw_walk_act(f32x4 v, bool aff, bool inside, con
 // columns 8tx-1 .. 8tx+8 of the strip -> ring slots rb .. rb+9 (start of a run / of a strip); 100 items over 16 pixel lanes
 __device__ __forceinline__ void dw_walk_prologue(float (*xs)[DWR][DW_CH], const float* __restrict__ x, long long ldx, bool aff,
                                                  const f32x4& sc, const f32x4& sh, const DwWalk& q, int H, int W, int tx, int rb, int pl, int cq,
-                                                 const DwLin* L = nullptr, const DwLinC* lc = nullptr) {
+                                                 const DwLin* L = nullptr, const DwLinC* lc = nullptr, int x_bf = 0) {
     for (int i = pl; i < (DT + 2) * (DT + 2); i += 16) {
         const int hy = i / (DT + 2), hx = i - hy * (DT + 2), ix = tx * DT + hx - 1;
-        f32x4 v = dw_walk_fetch(x, ldx, q, H, W, hy, ix);
-        if (L != nullptr && L->lin != nullptr) v = dw_lin_eval(v, dw_walk_fetch(L->y, L->ldy, q, H, W, hy, ix), dw_walk_inside(q, H, W, hy, ix), *lc);
+        f32x4 v = dw_walk_fetch(x, ldx, q, H, W, hy, ix, x_bf);
+        if (L != nullptr && L->lin != nullptr) v = dw_lin_eval(v, dw_walk_fetch(L->y, L->ldy, q, H, W, hy, ix, L->y_bf), dw_walk_inside(q, H, W, hy, ix), *lc);
         st4(&xs[hy][dw_slot(rb, hx)][cq * 4], dw_walk_act(v, aff, dw_walk_inside(q, H, W, hy, ix), sc, sh));
     }
 }
@@ -354,10 +355,11 @@ __global__ __launch_bounds__(256) void dwconv_walk_kernel(const float* __restric
                                                           float* __restrict__ y, long long ldy, float* __restrict__ partials,
                                                           int N, int H, int W, int C, int accumulate,
                                                           const float* __restrict__ isc, const float* __restrict__ ish, const DwBnb bnb,
-                                                          const DwLin lin) {
+                                                          const DwLin lin, int af) {      // af (fprop): bit 0 x, bit 1 y stored as bf16
     __shared__ __attribute__((aligned(16))) float xs[DT + 2][DWR][DW_CH];
     __shared__ float red[16][DW_CH];
     __shared__ float colmean[DW_CH];
+    const int x_bf = MODE == 0 ? (af & 1) : 0, y_bf = MODE == 0 ? (af & 2) : 0;
     const int t = threadIdx.x, cq = t & 15, pl = t >> 4;
     DwWalk q;
     dw_walk_init(q, H, W, C, N, cq);
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(256) void dwconv_walk_kernel(const float* __restric
     for (long long tile = q.t0; tile < q.t1; ++tile) {
         if (tile == q.t0 || tx == 0) {            // the run or a strip begins: the whole 10x10 halo (the loop ends on a barrier)
             dw_walk_strip(q, tile / q.tiles_x);
-            dw_walk_prologue(xs, x, ldx, aff, sc, sh, q, H, W, tx, rb, pl, cq, &lin, &lc);
+            dw_walk_prologue(xs, x, ldx, aff, sc, sh, q, H, W, tx, rb, pl, cq, &lin, &lc, x_bf);
             __syncthreads();
         }
         // columns 8tx+9 .. 8tx+16 (tile tx+1's new ones): 80 items, 5 per thread, in flight during this tile's arithmetic
@@ -386,8 +388,8 @@ __global__ __launch_bounds__(256) void dwconv_walk_kernel(const float* __restric
 #pragma unroll
             for (int it = 0; it < 5; ++it) {
                 const int i = it * 16 + pl;
-                nx[it] = dw_walk_fetch(x, ldx, q, H, W, i >> 3, tx * DT + 9 + (i & 7));
-                if (MODE == 1 && has_lin) ny[it] = dw_walk_fetch(lin.y, lin.ldy, q, H, W, i >> 3, tx * DT + 9 + (i & 7));
+                nx[it] = dw_walk_fetch(x, ldx, q, H, W, i >> 3, tx * DT + 9 + (i & 7), x_bf);
+                if (MODE == 1 && has_lin) ny[it] = dw_walk_fetch(lin.y, lin.ldy, q, H, W, i >> 3, tx * DT + 9 + (i & 7), lin.y_bf);
             }
         }
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -408,7 +410,8 @@ __global__ __launch_bounds__(256) void dwconv_walk_kernel(const float* __restric
                 float* dst = y + m * ldy + q.c;
                 if (MODE == 1 && accumulate) acc += ld4(dst);
                 if (MODE == 1 && bnb.y != nullptr) acc = dw_bnb_apply(bnb, m, q.c, acc, bsg, bsq);
-                st4(dst, acc);
+                if (MODE == 0) sta4(y, m * ldy + q.c, acc, y_bf);          // (the statistics below use the fp32 values in `kept`)
+                else st4(dst, acc);
             }
             s += kept[it];
         }
@@ -458,7 +461,8 @@ __global__ __launch_bounds__(256) void dwconv_walk_kernel(const float* __restric
 // one partial [9][C] per block
 __global__ __launch_bounds__(256) void dwconv_wgrad_walk_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ dy,
                                                                long long lddy, float* __restrict__ partials, int N, int H, int W, int C,
-                                                               const float* __restrict__ isc, const float* __restrict__ ish, const DwLin lin) {
+                                                               const float* __restrict__ isc, const float* __restrict__ ish, const DwLin lin,
+                                                               int x_bf) {
     __shared__ __attribute__((aligned(16))) float xs[DT + 2][DWR][DW_CH];
     __shared__ float red[16][DW_CH];
     const int t = threadIdx.x, cq = t & 15, pl = t >> 4;
@@ -482,7 +486,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_walk_kernel(const float* __r
             const int pidx = it * 16 + pl, py = pidx / DT, px = pidx - py * DT;
             const long long m = (fn * H + fty * DT + py) * W + ftx * DT + px;
             g[it] = q.cok ? ld4(dy + m * lddy + q.c) : f32x4{0.f, 0.f, 0.f, 0.f};
-            gy[it] = (has_lin && q.cok) ? ld4(lin.y + m * lin.ldy + q.c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            gy[it] = (has_lin && q.cok) ? lda4(lin.y, m * lin.ldy + q.c, lin.y_bf) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     if (q.t0 < q.t1) fetch_dy(q.t0);
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_walk_kernel(const float* __r
     for (long long tile = q.t0; tile < q.t1; ++tile) {
         if (tile == q.t0 || tx == 0) {
             dw_walk_strip(q, tile / q.tiles_x);
-            dw_walk_prologue(xs, x, ldx, aff, sc, sh, q, H, W, tx, rb, pl, cq);
+            dw_walk_prologue(xs, x, ldx, aff, sc, sh, q, H, W, tx, rb, pl, cq, nullptr, nullptr, x_bf);
             __syncthreads();
         }
         f32x4 nx[5];
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_walk_kernel(const float* __r
 #pragma unroll
             for (int it = 0; it < 5; ++it) {
                 const int i = it * 16 + pl;
-                nx[it] = dw_walk_fetch(x, ldx, q, H, W, i >> 3, tx * DT + 9 + (i & 7));
+                nx[it] = dw_walk_fetch(x, ldx, q, H, W, i >> 3, tx * DT + 9 + (i & 7), x_bf);
             }
         }
 #pragma unroll
@@ -618,14 +622,16 @@ static unsigned dw_walk_blocks(int N, int H, int W, int C) { (void)W; (void)C; r
 static bool dw_args_ok(const void* a, const void* b, const void* c, int N, int H, int W, int C, int dil, int ld1, int ld2) {
     return a && b && c && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && dil > 0 && ld1 >= C && ld2 >= C && !(ld1 & 3) && !(ld2 & 3);
 }
+// act_flags (include/seghiero_hip.h "bf16 ACTIVATION STORAGE"): the strip-walk kernels only -- SH_EUNSUPPORTED for other geometries
 extern "C" int sh_dwconv_fprop(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* w, float* y, int ldy,
-                               float* stat_partials, int N, int H, int W, int C, int dil, void* stream) {
-    if (!dw_args_ok(x, w, y, N, H, W, C, dil, ldx, ldy)) return SH_EINVAL;
+                               float* stat_partials, int N, int H, int W, int C, int dil, int act_flags, void* stream) {
+    if (!dw_args_ok(x, w, y, N, H, W, C, dil, ldx, ldy) || (act_flags & ~3)) return SH_EINVAL;
+    if (act_flags && !(dil == 1 && H % DT == 0 && W % DT == 0 && dw_walk_on())) return SH_EUNSUPPORTED;
     if ((in_scale == nullptr) != (in_shift == nullptr) || (((uintptr_t)in_scale | (uintptr_t)in_shift) & 15)) return SH_EINVAL;
     const long long M = (long long)N * H * W;
     dim3 grid((unsigned)sh_cdiv(M, DW_PIX), (unsigned)sh_cdiv(C, DW_CH));
     if (dil == 1 && H % DT == 0 && W % DT == 0 && dw_walk_on())       // same partial count: (H/8)*(W/8) tiles of 64 pixels per image
-        dwconv_walk_kernel<0><<<dw_walk_blocks(N, H, W, C) * grid.y, 256, 0, (hipStream_t)stream>>>(x, ldx, w, y, ldy, stat_partials, N, H, W, C, 0, in_scale, in_shift, DwBnb{}, DwLin{});
+        dwconv_walk_kernel<0><<<dw_walk_blocks(N, H, W, C) * grid.y, 256, 0, (hipStream_t)stream>>>(x, ldx, w, y, ldy, stat_partials, N, H, W, C, 0, in_scale, in_shift, DwBnb{}, DwLin{}, act_flags);
     else if (dil == 1 && H % DT == 0 && W % DT == 0)
         dwconv_tile_kernel<0><<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(x, ldx, w, y, ldy, stat_partials, H, W, C, 0, in_scale, in_shift, DwBnb{});
     else
@@ -640,8 +646,8 @@ static int dw_dgrad_any(const float* dy, int lddy, const float* w, float* dx, in
     const long long M = (long long)N * H * W;
     dim3 grid((unsigned)sh_cdiv(M, DW_PIX), (unsigned)sh_cdiv(C, DW_CH));
     if (dil == 1 && H % DT == 0 && W % DT == 0 && dw_walk_on())
-        dwconv_walk_kernel<1><<<dw_walk_blocks(N, H, W, C) * grid.y, 256, 0, (hipStream_t)stream>>>(dy, lddy, w, dx, lddx, nullptr, N, H, W, C, accumulate, nullptr, nullptr, bnb, lin);
-    else if (lin.lin != nullptr) return SH_EUNSUPPORTED;          // the deferred-apply loader exists in the strip-walk kernels only
+        dwconv_walk_kernel<1><<<dw_walk_blocks(N, H, W, C) * grid.y, 256, 0, (hipStream_t)stream>>>(dy, lddy, w, dx, lddx, nullptr, N, H, W, C, accumulate, nullptr, nullptr, bnb, lin, 0);
+    else if (lin.lin != nullptr || bnb.y_bf) return SH_EUNSUPPORTED;          // the deferred-apply loader and bf16 streams exist in the strip-walk kernels only
     else if (dil == 1 && H % DT == 0 && W % DT == 0)
         dwconv_tile_kernel<1><<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(dy, lddy, w, dx, lddx, nullptr, H, W, C, accumulate, nullptr, nullptr, bnb);
     else
@@ -651,25 +657,26 @@ static int dw_dgrad_any(const float* dy, int lddy, const float* w, float* dx, in
 // y_lin / lin (optional, both or neither): deferred BatchNorm-backward apply -- `dy` holds the masked gradient g and the loader evaluates
 // dy = lin[0]*g + lin[1]*(y_lin - lin[2]) + lin[3] (sh_bn_bwd_finalize's lin[4][C]); dil == 1 and H, W multiples of 8, else SH_EUNSUPPORTED
 extern "C" int sh_dwconv_dgrad(const float* dy, int lddy, const float* y_lin, int ldyl, const float* lin, const float* w, float* dx, int lddx,
-                               int N, int H, int W, int C, int dil, int accumulate, void* stream) {
-    if (!dw_args_ok(dy, w, dx, N, H, W, C, dil, lddy, lddx) || !dw_lin_args_ok(y_lin, ldyl, lin, C)) return SH_EINVAL;
-    return dw_dgrad_any(dy, lddy, w, dx, lddx, N, H, W, C, dil, accumulate, DwBnb{}, stream, DwLin{y_lin, ldyl, lin});
+                               int N, int H, int W, int C, int dil, int accumulate, int act_flags, void* stream) {
+    if (!dw_args_ok(dy, w, dx, N, H, W, C, dil, lddy, lddx) || !dw_lin_args_ok(y_lin, ldyl, lin, C) || (act_flags & ~1)) return SH_EINVAL;
+    return dw_dgrad_any(dy, lddy, w, dx, lddx, N, H, W, C, dil, accumulate, DwBnb{}, stream, DwLin{y_lin, ldyl, lin, act_flags & 1});
 }
 // ... with the front half of the producer layer's BatchNorm backward in the epilogue (see sh_conv_dgrad_x6_bnb): g <- relumask * dx,
 // stat_partials[sh_dw_partials(N,H,W)][2][C] <- (sum g, sum g * xhat) per 64-pixel block.  y_prev: raw output of the producer conv.
 extern "C" int sh_dwconv_dgrad_bnb(const float* dy, int lddy, const float* y_lin, int ldyl, const float* lin, const float* w, float* g, int ldg,
                                    const float* y_prev, int ldyp, const float* mean, const float* invstd, const float* scale, const float* shift,
-                                   float* stat_partials, int N, int H, int W, int C, int dil, void* stream) {
+                                   float* stat_partials, int N, int H, int W, int C, int dil, int act_flags, void* stream) {
     if (!dw_args_ok(dy, w, g, N, H, W, C, dil, lddy, ldg) || !y_prev || !mean || !invstd || !scale || !shift || !stat_partials ||
-        !dw_lin_args_ok(y_lin, ldyl, lin, C)) return SH_EINVAL;
+        !dw_lin_args_ok(y_lin, ldyl, lin, C) || (act_flags & ~3)) return SH_EINVAL;
     if (ldyp < C || (ldyp & 3) || (((uintptr_t)y_prev | (uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)scale | (uintptr_t)shift) & 15)) return SH_EINVAL;
-    return dw_dgrad_any(dy, lddy, w, g, ldg, N, H, W, C, dil, 0, DwBnb{y_prev, ldyp, mean, invstd, scale, shift, stat_partials}, stream,
-                        DwLin{y_lin, ldyl, lin});
+    return dw_dgrad_any(dy, lddy, w, g, ldg, N, H, W, C, dil, 0, DwBnb{y_prev, ldyp, mean, invstd, scale, shift, stat_partials, (act_flags >> 1) & 1}, stream,
+                        DwLin{y_lin, ldyl, lin, act_flags & 1});          // act_flags: bit 0 y_lin, bit 1 y_prev stored as bf16
 }
 extern "C" int sh_dwconv_wgrad(const float* x, int ldx, const float* in_scale, const float* in_shift, const float* dy, int lddy,
                                const float* y_lin, int ldyl, const float* lin, float* dw_partials, float* dw, int N, int H, int W, int C, int dil,
-                               void* stream) {
-    if (!dw_args_ok(x, dy, dw, N, H, W, C, dil, ldx, lddy) || !dw_partials || !dw_lin_args_ok(y_lin, ldyl, lin, C)) return SH_EINVAL;
+                               int act_flags, void* stream) {
+    if (!dw_args_ok(x, dy, dw, N, H, W, C, dil, ldx, lddy) || !dw_partials || !dw_lin_args_ok(y_lin, ldyl, lin, C) || (act_flags & ~3)) return SH_EINVAL;
+    if (act_flags && !(dil == 1 && H % DT == 0 && W % DT == 0 && dw_walk_on())) return SH_EUNSUPPORTED;      // bit 0 x, bit 1 y_lin stored as bf16
     if ((in_scale == nullptr) != (in_shift == nullptr) || (((uintptr_t)in_scale | (uintptr_t)in_shift) & 15)) return SH_EINVAL;
     const long long M = (long long)N * H * W;
     int P = (int)sh_cdiv(M, DW_PIX);
@@ -679,7 +686,7 @@ extern "C" int sh_dwconv_wgrad(const float* x, int ldx, const float* in_scale, c
     if (dil == 1 && H % DT == 0 && W % DT == 0 && dw_walk_on()) {
         P = (int)dw_walk_blocks(N, H, W, C);                        // one partial per block (<= M/64 rows of the workspace)
         dwconv_wgrad_walk_kernel<<<(unsigned)P * grid.y, 256, 0, (hipStream_t)stream>>>(x, ldx, dy, lddy, dw_partials, N, H, W, C, in_scale, in_shift,
-                                                                                        DwLin{y_lin, ldyl, lin});
+                                                                                        DwLin{y_lin, ldyl, lin, (act_flags >> 1) & 1}, act_flags & 1);
     } else if (lin != nullptr) return SH_EUNSUPPORTED;
     else if (dil == 1 && H % DT == 0 && W % DT == 0)
         dwconv_wgrad_tile_kernel<<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(x, ldx, dy, lddy, dw_partials, H, W, C, M / (DT * DT), in_scale, in_shift);

@@ -165,7 +165,7 @@ __device__ __forceinline__ Lerp lerp_src(int dst, float scale, int in) {
 }
 __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ x, long long ldx, float* __restrict__ y,
                                                            long long ldy, int h, int w, int H, int W, int C4, float sy, float sx,
-                                                           long long total) {
+                                                           long long total, int y_bf) {
     GRID_STRIDE(i, total) {
         const int c = (int)(i % C4) * 4;
         long long q = i / C4;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restri
         const f32x4 v00 = ld4(b + ((long long)ly.i0 * w + lx.i0) * ldx), v01 = ld4(b + ((long long)ly.i0 * w + lx.i1) * ldx);
         const f32x4 v10 = ld4(b + ((long long)ly.i1 * w + lx.i0) * ldx), v11 = ld4(b + ((long long)ly.i1 * w + lx.i1) * ldx);
         const f32x4 r = ly.w0 * (lx.w0 * v00 + lx.w1 * v01) + ly.w1 * (lx.w0 * v10 + lx.w1 * v11);
-        st4(y + ((n * H + oy) * W + ox) * ldy + c, r);
+        sta4(y, ((n * H + oy) * W + ox) * ldy + c, r, y_bf);
     }
 }
 // gather-form backward: each input pixel scans the output window that can reference it and re-derives the forward weights.
@@ -217,10 +217,10 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
         st4(dx + ((n * h + iy) * w + ix) * lddx + c, acc);
     }
 }
-extern "C" int sh_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int h, int w, int H, int W, int C, void* stream) {
+extern "C" int sh_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int h, int w, int H, int W, int C, int act_flags, void* stream) {
     if (!x || !y || N <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || ldx < C || ldy < C || (ldx & 3) || (ldy & 3)) return SH_EINVAL;
     const long long total = (long long)N * H * W * (C / 4);
-    bilinear_fwd_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>(x, ldx, y, ldy, h, w, H, W, C / 4, (float)h / (float)H, (float)w / (float)W, total);
+    bilinear_fwd_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>(x, ldx, y, ldy, h, w, H, W, C / 4, (float)h / (float)H, (float)w / (float)W, total, act_flags & 1);      // bit 0: y stored as bf16
     return sh_launch_status();
 }
 // Upsampling backward that reads dy ONCE.  The output rows whose upper source row (i0) is iy form one contiguous band; a block

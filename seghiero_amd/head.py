@@ -171,19 +171,23 @@ class _HeadFn(torch.autograd.Function):
                 _, R[f"pw{i}"] = L.cba_fwd(t, ds.pointwise.weight, G1, ds.bn_pw, True, training, out=cat[:, (i + 1) * A:(i + 2) * A])
         b, R["bt"] = L.cba_fwd(cat, mod.bottleneck[0].weight, G1, mod.bottleneck[1], True, training)
         # ---- decoder: x8 bilinear + C1 skip into one buffer (:231-242)
-        if mod.c1_bottleneck is not None:
-            c1 = ops.to_nhwc(c1)
-            H1, W1 = c1.shape[2:]
-            c1ch = mod.c1_bottleneck[0].out_channels
-            cat2 = ops.new_act(n, A + c1ch, H1, W1, dev)
-            _, R["c1"] = L.cba_fwd(c1, mod.c1_bottleneck[0].weight, G1, mod.c1_bottleneck[1], True, training, out=cat2[:, A:])
-            ops.bilinear_fwd(b, cat2[:, :A])
-            xin = cat2
-        else:
-            xin = b
-        for j, ds in enumerate(mod.sep_bottleneck):
-            t, R[f"sdw{j}"] = L.dw_fwd(xin, ds.depthwise.weight, 1, ds.bn_dw, training, lazy=True)
-            xin, R[f"spw{j}"] = L.cba_fwd(t, ds.pointwise.weight, G1, ds.bn_pw, True, training, lazy=True)
+        # act_dtype = torch.bfloat16 (training, strip-walk geometry): the decoder's 128 x 128 tensors -- concat buffer, raw depthwise and
+        # pointwise outputs -- are STORED as bf16 like the trunk's (ResNetBackbone.act_dtype; arithmetic / statistics / gradients fp32)
+        H1, W1 = (c1.shape[2:] if mod.c1_bottleneck is not None else (h, w))
+        stored = mod.act_dtype if (training and L.FUSE_BN and ops.CONV_IMPL == "x6" and ops.dw_lin_ok((n, A, H1, W1), 1)) else torch.float32
+        with ops.stored_as(stored):
+            if mod.c1_bottleneck is not None:
+                c1 = ops.to_nhwc(c1)
+                c1ch = mod.c1_bottleneck[0].out_channels
+                cat2 = ops.new_act(n, A + c1ch, H1, W1, dev, dtype=stored)
+                _, R["c1"] = L.cba_fwd(c1, mod.c1_bottleneck[0].weight, G1, mod.c1_bottleneck[1], True, training, out=cat2[:, A:])
+                ops.bilinear_fwd(b, cat2[:, :A])
+                xin = cat2
+            else:
+                xin = b
+            for j, ds in enumerate(mod.sep_bottleneck):
+                t, R[f"sdw{j}"] = L.dw_fwd(xin, ds.depthwise.weight, 1, ds.bn_dw, training, lazy=True)
+                xin, R[f"spw{j}"] = L.cba_fwd(t, ds.pointwise.weight, G1, ds.bn_pw, True, training, lazy=True)
         logits = L.conv_fwd(xin, mod.cls_seg.weight, mod.cls_seg.bias, G1)
         R["cls_in"] = xin
         if training:
@@ -295,6 +299,7 @@ class DepthwiseSeparableASPPContrastHead(nn.Module):
             DepthwiseSeparableConv(aspp_channels + c1_channels, aspp_channels, kernel_size=3, padding=1, bias=False),
             DepthwiseSeparableConv(aspp_channels, aspp_channels, kernel_size=3, padding=1, bias=False))
         self.cls_seg = nn.Conv2d(aspp_channels, num_classes, kernel_size=1)
+        self.act_dtype = torch.float32          # torch.bfloat16: the decoder stores its activations as bf16 (see _HeadFn.forward)
         self.align_corners = False
         for name, v in (("in_channels", in_channels), ("aspp_channels", aspp_channels), ("c1_channels", c1_channels),
                         ("proj_dim", proj_dim), ("c1_in_channels", max(c1_in_channels, 0))):

@@ -250,7 +250,7 @@ class DWRec:
 def dw_fwd(x, weight, dil, bn, training, lazy=False):
     """depthwise 3x3 -> BN -> ReLU; lazy=True defers the BatchNorm + ReLU to the pointwise conv's loader (-> Lazy)."""
     n, c, h, w = x.shape
-    y = ops.new_act(n, c, h, w, x.device)
+    y = ops.new_act(n, c, h, w, x.device, dtype=ops.stored_dtype())
     partials = torch.empty((ops.dw_partials_rows(n, h, w), 2, c), device=x.device) if training else None
     if isinstance(x, Lazy) and x._out is None:
         ops.dwconv_fprop(x.y, weight, y, partials, dil, aff=x.coefs)      # the producer's BN + ReLU in the depthwise loader

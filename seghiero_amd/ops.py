@@ -530,10 +530,10 @@ def dw_partials_rows(n, h, w):
 def dwconv_fprop(x, weight, y, partials, dil, aff=None):
     """aff = (4, C) BatchNorm coefficients: x is the producer conv's raw output, read as relu(x * scale + shift)."""
     n, c, h, w = x.shape
-    xp, ldx = pm(x)
-    yp, ldy = pm(y)
+    xp, ldx, xb = pmx(x)
+    yp, ldy, yb = pmx(y)
     _call("sh_dwconv_fprop", xp, ldx, None if aff is None else aff[2].data_ptr(), None if aff is None else aff[3].data_ptr(),
-          weight.data_ptr(), yp, ldy, None if partials is None else partials.data_ptr(), n, h, w, c, dil, _st())
+          weight.data_ptr(), yp, ldy, None if partials is None else partials.data_ptr(), n, h, w, c, dil, xb | (yb << 1), _st())
 
 
 def dw_lin_ok(shape, dil):
@@ -543,26 +543,29 @@ def dw_lin_ok(shape, dil):
 
 
 def _lin_args(dy):
-    """(g pointer, ldg, y pointer, ldy, lin pointer) of a DeferredDy, or (dy pointer, lddy, None, 0, None) of a tensor."""
+    """((g pointer, ldg, y pointer, ldy, lin pointer), y-is-bf16) of a DeferredDy, or ((dy pointer, lddy, None, 0, None), 0) of a tensor."""
     if isinstance(dy, DeferredDy):
-        return pm(dy.g) + pm(dy.y) + (dy.lin.data_ptr(),)
-    return pm(dy) + (None, 0, None)
+        yp, ldy, yb = pmx(dy.y)
+        return pm(dy.g) + (yp, ldy, dy.lin.data_ptr()), yb
+    return pm(dy) + (None, 0, None), 0
 
 
 def dwconv_dgrad(dy, weight, dx, dil, accumulate=False):
     """dy: tensor or DeferredDy (check dw_lin_ok first)."""
     n, c, h, w = dx.shape
     dxp, lddx = pm(dx)
-    _call("sh_dwconv_dgrad", *_lin_args(dy), weight.data_ptr(), dxp, lddx, n, h, w, c, dil, int(accumulate), _st())
+    largs, yb = _lin_args(dy)
+    _call("sh_dwconv_dgrad", *largs, weight.data_ptr(), dxp, lddx, n, h, w, c, dil, int(accumulate), yb, _st())
 
 
 def dwconv_dgrad_bnb(dy, weight, g, y_prev, coefs, partials, dil):
     """depthwise input gradient + front half of the producer's BatchNorm backward: g <- relumask * dx, partials <- (sum g, sum g*xhat)."""
     n, c, h, w = g.shape
     gp, ldg = pm(g)
-    ypp, ldyp = pm(y_prev)
-    _call("sh_dwconv_dgrad_bnb", *_lin_args(dy), weight.data_ptr(), gp, ldg, ypp, ldyp, coefs[0].data_ptr(), coefs[1].data_ptr(),
-          coefs[2].data_ptr(), coefs[3].data_ptr(), partials.data_ptr(), n, h, w, c, dil, _st())
+    ypp, ldyp, ypb = pmx(y_prev)
+    largs, yb = _lin_args(dy)
+    _call("sh_dwconv_dgrad_bnb", *largs, weight.data_ptr(), gp, ldg, ypp, ldyp, coefs[0].data_ptr(), coefs[1].data_ptr(),
+          coefs[2].data_ptr(), coefs[3].data_ptr(), partials.data_ptr(), n, h, w, c, dil, yb | (ypb << 1), _st())
 
 
 def dwconv_wgrad(x, dy, dweight, dil, side=False, aff=None):
@@ -570,8 +573,8 @@ def dwconv_wgrad(x, dy, dweight, dil, side=False, aff=None):
     aff: as dwconv_fprop."""
     n, c, h, w = x.shape
     p = dw_partials_rows(n, h, w)
-    xp, ldx = pm(x)
-    largs = _lin_args(dy)
+    xp, ldx, xb = pmx(x)
+    largs, yb = _lin_args(dy)
     dd = dy if isinstance(dy, DeferredDy) else None
     if dd is not None:
         dy = dd.g
@@ -579,7 +582,7 @@ def dwconv_wgrad(x, dy, dweight, dil, side=False, aff=None):
     def launch(tag="dwwgrad"):
         ws = workspace(p * 9 * c * 4, x.device, tag)
         _call("sh_dwconv_wgrad", xp, ldx, None if aff is None else aff[2].data_ptr(), None if aff is None else aff[3].data_ptr(),
-              *largs, ws.data_ptr(), dweight.data_ptr(), n, h, w, c, dil, _st())
+              *largs, ws.data_ptr(), dweight.data_ptr(), n, h, w, c, dil, xb | (yb << 1), _st())
 
     if not (side and WGRAD_ASYNC and x.is_cuda):
         launch()
@@ -905,8 +908,8 @@ def bilinear_fwd(x, out):
     n, c, h, w = x.shape
     _, _, H, W = out.shape
     xp, ldx = pm(x)
-    op, ldo = pm(out)
-    _call("sh_bilinear_fwd", xp, ldx, op, ldo, n, h, w, H, W, c, _st())
+    op, ldo, ob = pmx(out)
+    _call("sh_bilinear_fwd", xp, ldx, op, ldo, n, h, w, H, W, c, ob, _st())
 
 
 def bilinear_bwd(dy, h, w):

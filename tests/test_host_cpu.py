@@ -42,7 +42,7 @@ def test_abi_rejects_bad_arguments_without_launching(built):
     assert LIB.raw("sh_conv_dgrad_x6_lin")(None, 64, None, 64, None, None, None, 0, None, 64, None, 0, None, None, None, None, 0, None,
                                            1, 8, 8, 64, 64, None, 0, 0, None) == -1
     assert LIB.raw("sh_conv_wgrad_x6_lin")(None, 64, None, None, None, 64, None, 64, None, None, None, 1, 8, 8, 64, 64, 1, 1, 1, 0, 1, 0, None) == -1
-    assert LIB.raw("sh_dwconv_dgrad")(None, 64, None, 0, None, None, None, 64, 1, 8, 8, 64, 1, 0, None) == -1
+    assert LIB.raw("sh_dwconv_dgrad")(None, 64, None, 0, None, None, None, 64, 1, 8, 8, 64, 1, 0, 0, None) == -1
     assert LIB.raw("sh_bn_bwd_reduce")(None, 64, None, 0, None, 64, None, None, None, None, None, 64, 64, 0, None, 0, 0, None) == -1
     assert LIB.raw("sh_bilinear_bwd")(None, 64, None, 64, 1, 4, 4, 8, 8, 64, None, 0, None) == -1
     assert LIB.raw("sh_hiera2_loss_fwd")(None, 16, None, None, 9, 4, None, None, None, None, 1, 8, 8, 32, 32, None, 0, 0, None) == -1
