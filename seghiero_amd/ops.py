@@ -48,6 +48,7 @@ class profile:
         global _PROF, WGRAD_ASYNC
         WGRAD_ASYNC = self._async
         rec, _PROF = _PROF, None
+        self.rec = rec
         torch.cuda.synchronize()
         self.rows, self.shapes = {}, {}
         for name, cost, e0, e1, key in rec:
