@@ -70,6 +70,8 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 }
 
 // exact 3-way split of 4 floats -> three packed bf16x4 (8 bytes each)
+// (16 and/sub + 6 perm.  Tried: the residual subtractions on element pairs, v_pk_add_f32 -- 18 VALU instead of 22, same box 33.4-33.5
+// vs 32.7-32.9 ms per step: the packed op is no cheaper to issue and its 64-bit-aligned operand pairs cost the scheduler freedom.)
 __device__ __forceinline__ void split4(const f32x4 v, u32x2& p1, u32x2& p2, u32x2& p3) {
     unsigned h1[4], h2[4], h3[4];
 #pragma unroll
