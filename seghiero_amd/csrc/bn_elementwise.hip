@@ -91,6 +91,8 @@ extern "C" int sh_axpy(float* y, const float* x, float a, int64_t n, void* strea
 // CENTRED != 0: partial = (sum, M2 about its own mean) over n_p = min(R, M - p*R) rows -> returns (sum, sum of squares about 0)
 // NT threads per block (256, or 1024 for long partial lists: the kernel is a latency-bound strided gather -- 16 bytes per row --
 // and the layers with 4096+ partials and 64 channels run only 16 blocks, so more threads per block is the parallelism there is)
+// Tried (round 2): blocks of 16 / 32 adjacent channels (64 / 128 contiguous bytes per row, NT/4 or NT/8 rows per pass) -- slower, 17 -> 20 /
+// 25 us at P = 4096, C = 64: the time follows the passes per thread, not the bytes pulled through L2.
 template <int NT = 256, typename F>
 __device__ __forceinline__ void reduce_partials_4ch(const float* __restrict__ partials, int P, int C, int c0, int R, long long M, F&& fin, long long ldp = 0) {
     if (ldp == 0) ldp = C;                 // row length of the partials (> C: this tensor is a column slice of a wider set)

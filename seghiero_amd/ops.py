@@ -534,7 +534,8 @@ def dwconv_fprop(x, weight, y, partials, dil, aff=None):
     xp, ldx, xb = pmx(x)
     yp, ldy, yb = pmx(y)
     _call("sh_dwconv_fprop", xp, ldx, None if aff is None else aff[2].data_ptr(), None if aff is None else aff[3].data_ptr(),
-          weight.data_ptr(), yp, ldy, None if partials is None else partials.data_ptr(), n, h, w, c, dil, xb | (yb << 1), _st())
+          weight.data_ptr(), yp, ldy, None if partials is None else partials.data_ptr(), n, h, w, c, dil, xb | (yb << 1), _st(),
+          key=f"{n}x{h}x{w} C{c} d{dil}")
 
 
 def dw_lin_ok(shape, dil):
@@ -556,7 +557,7 @@ def dwconv_dgrad(dy, weight, dx, dil, accumulate=False):
     n, c, h, w = dx.shape
     dxp, lddx = pm(dx)
     largs, yb = _lin_args(dy)
-    _call("sh_dwconv_dgrad", *largs, weight.data_ptr(), dxp, lddx, n, h, w, c, dil, int(accumulate), yb, _st())
+    _call("sh_dwconv_dgrad", *largs, weight.data_ptr(), dxp, lddx, n, h, w, c, dil, int(accumulate), yb, _st(), key=f"{n}x{h}x{w} C{c} d{dil}")
 
 
 def dwconv_dgrad_bnb(dy, weight, g, y_prev, coefs, partials, dil):
@@ -566,7 +567,7 @@ def dwconv_dgrad_bnb(dy, weight, g, y_prev, coefs, partials, dil):
     ypp, ldyp, ypb = pmx(y_prev)
     largs, yb = _lin_args(dy)
     _call("sh_dwconv_dgrad_bnb", *largs, weight.data_ptr(), gp, ldg, ypp, ldyp, coefs[0].data_ptr(), coefs[1].data_ptr(),
-          coefs[2].data_ptr(), coefs[3].data_ptr(), partials.data_ptr(), n, h, w, c, dil, yb | (ypb << 1), _st())
+          coefs[2].data_ptr(), coefs[3].data_ptr(), partials.data_ptr(), n, h, w, c, dil, yb | (ypb << 1), _st(), key=f"{n}x{h}x{w} C{c} d{dil}")
 
 
 def dwconv_wgrad(x, dy, dweight, dil, side=False, aff=None):
@@ -583,7 +584,7 @@ def dwconv_wgrad(x, dy, dweight, dil, side=False, aff=None):
     def launch(tag="dwwgrad"):
         ws = workspace(p * 9 * c * 4, x.device, tag)
         _call("sh_dwconv_wgrad", xp, ldx, None if aff is None else aff[2].data_ptr(), None if aff is None else aff[3].data_ptr(),
-              *largs, ws.data_ptr(), dweight.data_ptr(), n, h, w, c, dil, xb | (yb << 1), _st())
+              *largs, ws.data_ptr(), dweight.data_ptr(), n, h, w, c, dil, xb | (yb << 1), _st(), key=f"{n}x{h}x{w} C{c} d{dil}")
 
     if not (side and WGRAD_ASYNC and x.is_cuda):
         launch()
@@ -639,7 +640,8 @@ def bn_finalize(partials, count, gamma, beta, eps, momentum, running_mean, runni
           None if gamma is None else gamma.data_ptr(), None if beta is None else beta.data_ptr(), eps, momentum,
           None if running_mean is None else running_mean.data_ptr(),
           None if running_var is None else running_var.data_ptr(),
-          coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(), coefs[3].data_ptr(), rows, int(partials_ld), _st())
+          coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(), coefs[3].data_ptr(), rows, int(partials_ld), _st(),
+          key=f"P{partials.shape[0]} C{c}")
     return coefs
 
 
@@ -731,7 +733,7 @@ def bn_act(y, coefs, out, relu, residual=None, res_coefs=None):
     rp, ldr, rb = (None, 0, 0) if residual is None else pmx(residual)
     _call("sh_bn_act", yp, ldy, coefs[2].data_ptr(), coefs[3].data_ptr(), rp, ldr,
           None if res_coefs is None else res_coefs[2].data_ptr(), None if res_coefs is None else res_coefs[3].data_ptr(),
-          op, ldo, n * h * w, c, int(relu), yb | (rb << 1) | (ob << 2), _st())
+          op, ldo, n * h * w, c, int(relu), yb | (rb << 1) | (ob << 2), _st(), key=f"{n}x{h}x{w} C{c}" + (" +res" if residual is not None else ""))
 
 
 class DeferredDy:
@@ -758,7 +760,7 @@ class DeferredDy:
             cf = self.coefs
             _call("sh_bn_bwd_apply", gp, ldg, None, 0, yp, ldy, cf[0].data_ptr(), cf[1].data_ptr(), cf[2].data_ptr(), cf[3].data_ptr(),
                   None if self.gamma is None else self.gamma.data_ptr(), self.red[2].data_ptr(), self.red[3].data_ptr(), dyp, lddy,
-                  None, 0, n * h * w, c, 0, yb, _st())
+                  None, 0, n * h * w, c, 0, yb, _st(), key=f"{n}x{h}x{w} C{c} (deferred)")
             self._dy = dy
         return self._dy
 
@@ -809,11 +811,11 @@ def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None, d
         if defer and relu:
             gmask = new_act(n, c, h, w, dev)
             if not _call_fused("sh_bn_bwd_reduce", dop, lddo, op, ldo, yp, ldy, coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(),
-                               coefs[3].data_ptr(), partials.data_ptr(), m, c, relu, gmask.data_ptr(), c, af, _st()):
+                               coefs[3].data_ptr(), partials.data_ptr(), m, c, relu, gmask.data_ptr(), c, af, _st(), key=f"{n}x{h}x{w} C{c} +g"):
                 gmask, defer = None, False
         if gmask is None:
             _call("sh_bn_bwd_reduce", dop, lddo, op, ldo, yp, ldy, coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(),
-                  coefs[3].data_ptr(), partials.data_ptr(), m, c, relu, None, 0, af, _st())
+                  coefs[3].data_ptr(), partials.data_ptr(), m, c, relu, None, 0, af, _st(), key=f"{n}x{h}x{w} C{c}")
         else:
             dout, relu, op, ldo = gmask, 0, None, 0          # from here on as a packed gradient: mask applied
             dop, lddo = pm(dout)
@@ -833,7 +835,7 @@ def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None, d
     else:
         _call("sh_bn_bwd_finalize", partials.data_ptr(), p, c, None if gamma is None else gamma.data_ptr(),
               coefs[1].data_ptr(), float(m), red[0].data_ptr(), red[1].data_ptr(), red[2].data_ptr(), red[3].data_ptr(),
-              coefs[0].data_ptr(), linp, _st())
+              coefs[0].data_ptr(), linp, _st(), key=f"P{p} C{c}")
     if defer:
         # relu == 0 here: dout is the masked gradient (packed, or stored by the statistics pass), or no mask applies
         return DeferredDy(dout, y, lin, coefs, gamma, red), red[0], red[1], (dout if want_dres else None)
@@ -846,7 +848,7 @@ def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None, d
     drp, lddr = (None, 0) if (dres is None or packed) else pm(dres)
     _call("sh_bn_bwd_apply", dop, lddo, op, ldo, yp, ldy, coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(),
           coefs[3].data_ptr(), None if gamma is None else gamma.data_ptr(), red[2].data_ptr(), red[3].data_ptr(), dyp, lddy,
-          drp, lddr, m, c, relu, af, _st())
+          drp, lddr, m, c, relu, af, _st(), key=f"{n}x{h}x{w} C{c}" + (" +dres" if drp else ""))
     return dy, red[0], red[1], dres
 
 
