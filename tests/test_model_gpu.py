@@ -438,6 +438,46 @@ def test_config2_full_size_step0_matches_oracle(sa):
         assert relerr(sm[k], sr[k]) < 1e-3, (k, relerr(sm[k], sr[k]))
 
 
+@pytest.mark.parametrize("cfg", ["C4", "C5"])
+def test_config4_config5_full_size_step0_match_oracle(sa, cfg):
+    """BASELINE configs[3] (ResNet-101, 3-level RMIHieraTripletLoss, 512x512) and configs[4] (ResNet-101 + aux head, 20 fine / 5 coarse,
+    1024x1024) at their real sizes on batch 2: same weights, same inputs, training-mode forward; main and aux loss within 1e-4
+    (relative to max(1, |loss|)) of the CPU oracle.  configs[4] is then repeated with the trunk's activations STORED as bf16
+    (act_dtype): the stated tolerance of that mode is 5e-3 relative on both losses (rounding of every stored tensor to 2^-9,
+    amplified by the random trunk: tests/diag/sens50.py; measured 7e-4 main, 4.5e-4 aux)."""
+    from oracle.step import OracleTrainer
+    from seghiero_amd.synthetic import make_batch
+    from seghiero_amd.train_step import SegHieroTrainer
+    torch.manual_seed(0)
+    if cfg == "C4":
+        kw, size, nf = dict(depth=101, n_fine=7, coarse_to_fine_map=[[0], [1, 4], [5, 6]], super_coarse_to_coarse_map=[[0], [1, 6]],
+                            fine_weight=0.5, lr=0.01), 512, 7
+    else:
+        kw, size, nf = dict(depth=101, n_fine=20, coarse_to_fine_map=[[0, 3], [4, 7], [8, 11], [12, 15], [16, 19]], lr=0.01), 1024, 20
+    ref = OracleTrainer(**kw)
+    mine = SegHieroTrainer(device=DEV, **kw)
+    mine.load_state_dicts(ref.state_dicts())
+    ref.train(); mine.train()
+    img, lab = make_batch(2, size, nf, seed=3)
+    with torch.no_grad():
+        _, m_r, a_r, _ = ref.forward_loss(img, lab, 0)
+        _, m_m, a_m, _ = mine.forward_loss(img.to(DEV), lab.to(DEV), 0)
+    m_r, a_r = float(m_r), float(a_r)
+    assert abs(float(m_m) - m_r) < 1e-4 * max(1.0, abs(m_r)), (float(m_m), m_r)
+    assert abs(float(a_m) - a_r) < 1e-4 * max(1.0, abs(a_r)), (float(a_m), a_r)
+    if cfg == "C5":
+        del mine
+        torch.cuda.empty_cache()
+        bf = SegHieroTrainer(device=DEV, act_dtype=torch.bfloat16, **kw)
+        bf.load_state_dicts(ref.state_dicts())        # (the oracle's running statistics moved; training-mode BatchNorm does not read them)
+        bf.train()
+        with torch.no_grad():
+            _, m_b, a_b, _ = bf.forward_loss(img.to(DEV), lab.to(DEV), 0)
+        assert abs(float(m_b) - m_r) < 5e-3 * max(1.0, abs(m_r)), (float(m_b), m_r)
+        assert abs(float(a_b) - a_r) < 5e-3 * max(1.0, abs(a_r)), (float(a_b), a_r)
+        print("C5 bf16-trunk loss distance:", abs(float(m_b) - m_r) / max(1.0, abs(m_r)), abs(float(a_b) - a_r) / max(1.0, abs(a_r)))
+
+
 def test_three_level_rmi_train_step_config4_family(sa):
     """BASELINE config 4 family (7 fine / 3 mid / 2 high, RMIHieraTripletLoss) on ResNet-18 at 96x96, B=4: step-0 loss
     within 1e-4 of the oracle; two SGD steps stay within 4x the fp32 oracle's own distance from its fp64 trajectory."""
