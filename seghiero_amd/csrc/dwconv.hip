@@ -27,6 +27,20 @@ __device__ __forceinline__ f32x4 dw_in(const float* p, const float* isc, const f
 // g = relumask(y * scale + shift) * dx is stored and (sum g, sum g * xhat) per 64-pixel block go to `partials`
 struct DwBnb { const float* y; long long ldy; const float* mean; const float* invstd; const float* scale; const float* shift; float* partials;
                int y_bf; };          // y_bf: y stored as bf16 (common.h lda4)
+struct DwBnbC { f32x4 scale, shift, mean, invstd; };       // the four per-channel coefficients of this thread's channel quad, in registers
+__device__ __forceinline__ DwBnbC dw_bnb_coefs(const DwBnb& b, int c, bool cok) {
+    DwBnbC k; k.scale = k.shift = k.mean = k.invstd = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (b.y != nullptr && cok) { k.scale = ld4(b.scale + c); k.shift = ld4(b.shift + c); k.mean = ld4(b.mean + c); k.invstd = ld4(b.invstd + c); }
+    return k;
+}
+__device__ __forceinline__ f32x4 dw_bnb_apply(const DwBnbC& k, f32x4 yv, f32x4 dx, f32x4& sg, f32x4& sq) {
+    const f32x4 a = yv * k.scale + k.shift;                                  // the forward's own arithmetic (bn_act_kernel)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (!(a[j] > 0.f)) dx[j] = 0.f;
+    sg += dx;
+    sq += dx * ((yv - k.mean) * k.invstd);
+    return dx;
+}
 __device__ __forceinline__ f32x4 dw_bnb_apply(const DwBnb& b, long long m, int c, f32x4 dx, f32x4& sg, f32x4& sq) {
     const f32x4 yv = lda4(b.y, m * b.ldy + c, b.y_bf);
     const f32x4 a = yv * ld4(b.scale + c) + ld4(b.shift + c);                // the forward's own arithmetic (bn_act_kernel)
@@ -340,18 +354,23 @@ __device__ __forceinline__ f32x4 dw_walk_act(f32x4 v, bool aff, bool inside, con
     return v;
 }
 // columns 8tx-1 .. 8tx+8 of the strip -> ring slots rb .. rb+9 (start of a run / of a strip); 100 items over 16 pixel lanes
+template <int LIN, int XBF, int YBF>       // compile-time: deferred-apply loader, element types of x and of the lin stream y
 __device__ __forceinline__ void dw_walk_prologue(float (*xs)[DWR][DW_CH], const float* __restrict__ x, long long ldx, bool aff,
                                                  const f32x4& sc, const f32x4& sh, const DwWalk& q, int H, int W, int tx, int rb, int pl, int cq,
-                                                 const DwLin* L = nullptr, const DwLinC* lc = nullptr, int x_bf = 0) {
+                                                 const DwLin* L = nullptr, const DwLinC* lc = nullptr) {
     for (int i = pl; i < (DT + 2) * (DT + 2); i += 16) {
         const int hy = i / (DT + 2), hx = i - hy * (DT + 2), ix = tx * DT + hx - 1;
-        f32x4 v = dw_walk_fetch(x, ldx, q, H, W, hy, ix, x_bf);
-        if (L != nullptr && L->lin != nullptr) v = dw_lin_eval(v, dw_walk_fetch(L->y, L->ldy, q, H, W, hy, ix, L->y_bf), dw_walk_inside(q, H, W, hy, ix), *lc);
+        f32x4 v = dw_walk_fetch(x, ldx, q, H, W, hy, ix, XBF);
+        if constexpr (LIN) v = dw_lin_eval(v, dw_walk_fetch(L->y, L->ldy, q, H, W, hy, ix, YBF), dw_walk_inside(q, H, W, hy, ix), *lc);
         st4(&xs[hy][dw_slot(rb, hx)][cq * 4], dw_walk_act(v, aff, dw_walk_inside(q, H, W, hy, ix), sc, sh));
     }
 }
-template <int MODE>   // 0 fprop (+stats), 1 dgrad (flipped taps, optional accumulate / BatchNorm-backward epilogue)
-__global__ __launch_bounds__(256) void dwconv_walk_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ w,
+// MODE 0 fprop (+stats), 1 dgrad (flipped taps, optional accumulate / BatchNorm-backward epilogue).  Compile-time so that a tile's
+// arithmetic is ONE basic block (runtime flags put a branch at every load and the scheduler then sank the arithmetic below the
+// barrier with all 36 LDS operands live): LIN = deferred-apply loader (dgrad), BNB = BatchNorm-backward epilogue (dgrad),
+// BF bits = element types -- fprop: bit 0 x, bit 1 y;  dgrad: bit 0 the lin stream y, bit 1 the epilogue's y_prev.
+template <int MODE, int LIN, int BNB, int BF>
+__global__ __launch_bounds__(256, (LIN && BNB) ? 2 : 3) void dwconv_walk_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ w,
                                                           float* __restrict__ y, long long ldy, float* __restrict__ partials,
                                                           int N, int H, int W, int C, int accumulate,
                                                           const float* __restrict__ isc, const float* __restrict__ ish, const DwBnb bnb,
@@ -359,25 +378,28 @@ __global__ __launch_bounds__(256) void dwconv_walk_kernel(const float* __restric
     __shared__ __attribute__((aligned(16))) float xs[DT + 2][DWR][DW_CH];
     __shared__ float red[16][DW_CH];
     __shared__ float colmean[DW_CH];
-    const int x_bf = MODE == 0 ? (af & 1) : 0, y_bf = MODE == 0 ? (af & 2) : 0;
+    static_assert(MODE == 1 || (LIN == 0 && BNB == 0), "the loader / epilogue hooks belong to the dgrad");
+    constexpr int x_bf = MODE == 0 ? (BF & 1) : 0, y_bf = MODE == 0 ? (BF & 2) : 0, ly_bf = MODE == 1 ? (BF & 1) : 0, by_bf = MODE == 1 ? (BF & 2) : 0;
+    constexpr bool has_lin = LIN != 0;
+    (void)af;
     const int t = threadIdx.x, cq = t & 15, pl = t >> 4;
     DwWalk q;
     dw_walk_init(q, H, W, C, N, cq);
-    const bool has_lin = MODE == 1 && lin.lin != nullptr;
     const DwLinC lc = dw_lin_coefs(lin, C, q.c, q.cok);
+    const DwBnbC bc = dw_bnb_coefs(bnb, q.c, q.cok);
     f32x4 wr[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k)
 #pragma unroll
         for (int j = 0; j < 4; ++j) wr[k][j] = q.cok ? w[(long long)(q.c + j) * 9 + (MODE == 0 ? k : 8 - k)] : 0.f;
-    const bool aff = isc != nullptr;
+    const bool aff = MODE == 0 && isc != nullptr;      // (the dgrad's operand is a gradient: no producer activation)
     f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
     if (aff && q.cok) { sc = ld4(isc + q.c); sh = ld4(ish + q.c); }
     int tx = (int)(q.t0 % q.tiles_x), rb = (tx * DT) % DWR;
     for (long long tile = q.t0; tile < q.t1; ++tile) {
         if (tile == q.t0 || tx == 0) {            // the run or a strip begins: the whole 10x10 halo (the loop ends on a barrier)
             dw_walk_strip(q, tile / q.tiles_x);
-            dw_walk_prologue(xs, x, ldx, aff, sc, sh, q, H, W, tx, rb, pl, cq, &lin, &lc, x_bf);
+            dw_walk_prologue<LIN, x_bf, ly_bf>(xs, x, ldx, aff, sc, sh, q, H, W, tx, rb, pl, cq, &lin, &lc);
             __syncthreads();
         }
         // columns 8tx+9 .. 8tx+16 (tile tx+1's new ones): 80 items, 5 per thread, in flight during this tile's arithmetic
@@ -389,7 +411,7 @@ __global__ __launch_bounds__(256) void dwconv_walk_kernel(const float* __restric
             for (int it = 0; it < 5; ++it) {
                 const int i = it * 16 + pl;
                 nx[it] = dw_walk_fetch(x, ldx, q, H, W, i >> 3, tx * DT + 9 + (i & 7), x_bf);
-                if (MODE == 1 && has_lin) ny[it] = dw_walk_fetch(lin.y, lin.ldy, q, H, W, i >> 3, tx * DT + 9 + (i & 7), lin.y_bf);
+                if constexpr (has_lin) ny[it] = dw_walk_fetch(lin.y, lin.ldy, q, H, W, i >> 3, tx * DT + 9 + (i & 7), ly_bf);
             }
         }
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -409,13 +431,13 @@ __global__ __launch_bounds__(256) void dwconv_walk_kernel(const float* __restric
                 const long long m = (((long long)q.n * H + q.ty * DT + py) * W + tx * DT + px);
                 float* dst = y + m * ldy + q.c;
                 if (MODE == 1 && accumulate) acc += ld4(dst);
-                if (MODE == 1 && bnb.y != nullptr) acc = dw_bnb_apply(bnb, m, q.c, acc, bsg, bsq);
+                if constexpr (BNB) acc = dw_bnb_apply(bc, lda4(bnb.y, m * bnb.ldy + q.c, by_bf), acc, bsg, bsq);
                 if (MODE == 0) sta4(y, m * ldy + q.c, acc, y_bf);          // (the statistics below use the fp32 values in `kept`)
                 else st4(dst, acc);
             }
             s += kept[it];
         }
-        if (MODE == 1 && bnb.y != nullptr) dw_bnb_store(bnb, red, bsg, bsq, tile, C, q.c0, t, cq, pl);
+        if constexpr (BNB) dw_bnb_store(bnb, red, bsg, bsq, tile, C, q.c0, t, cq, pl);
         if (MODE == 0 && partials != nullptr) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) red[pl][cq * 4 + j] = s[j];
@@ -449,7 +471,7 @@ __global__ __launch_bounds__(256) void dwconv_walk_kernel(const float* __restric
                 const int i = it * 16 + pl;
                 const bool inside = dw_walk_inside(q, H, W, i >> 3, tx * DT + 9 + (i & 7));
                 f32x4 v = nx[it];
-                if (MODE == 1 && has_lin) v = dw_lin_eval(v, ny[it], inside, lc);
+                if constexpr (has_lin) v = dw_lin_eval(v, ny[it], inside, lc);
                 st4(&xs[i >> 3][dw_slot(rb, i & 7)][cq * 4], dw_walk_act(v, aff, inside, sc, sh));
             }
             __syncthreads();
@@ -459,16 +481,17 @@ __global__ __launch_bounds__(256) void dwconv_walk_kernel(const float* __restric
 }
 // wgrad, strip walk: x through the same ring, dy straight from global (prefetched one tile ahead), nine accumulators per thread;
 // one partial [9][C] per block
-__global__ __launch_bounds__(256) void dwconv_wgrad_walk_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ dy,
+template <int LIN, int BF>     // LIN: dy = lin(g, y) evaluated here;  BF bit 0: x, bit 1: the lin stream y stored as bf16
+__global__ __launch_bounds__(256, 3) void dwconv_wgrad_walk_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ dy,
                                                                long long lddy, float* __restrict__ partials, int N, int H, int W, int C,
-                                                               const float* __restrict__ isc, const float* __restrict__ ish, const DwLin lin,
-                                                               int x_bf) {
+                                                               const float* __restrict__ isc, const float* __restrict__ ish, const DwLin lin) {
+    constexpr int x_bf = BF & 1, ly_bf = BF & 2;
     __shared__ __attribute__((aligned(16))) float xs[DT + 2][DWR][DW_CH];
     __shared__ float red[16][DW_CH];
     const int t = threadIdx.x, cq = t & 15, pl = t >> 4;
     DwWalk q;
     dw_walk_init(q, H, W, C, N, cq);
-    const bool has_lin = lin.lin != nullptr;
+    constexpr bool has_lin = LIN != 0;
     const DwLinC lc = dw_lin_coefs(lin, C, q.c, q.cok);
     f32x4 acc[9];
 #pragma unroll
@@ -476,7 +499,8 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_walk_kernel(const float* __r
     const bool aff = isc != nullptr;
     f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
     if (aff && q.cok) { sc = ld4(isc + q.c); sh = ld4(ish + q.c); }
-    f32x4 g[4], gy[4];         // dy of the next tile (raw g and, deferred apply, y: the linear form is evaluated when the tile is used)
+    f32x4 g[4];
+    [[maybe_unused]] f32x4 gy[4];         // dy of the next tile (raw g and, deferred apply, y: the linear form is evaluated when the tile is used)
     auto fetch_dy = [&](long long tile) {
         const long long strip = tile / q.tiles_x;
         const int ftx = (int)(tile - strip * q.tiles_x), fty = (int)(strip % q.tiles_y);
@@ -486,7 +510,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_walk_kernel(const float* __r
             const int pidx = it * 16 + pl, py = pidx / DT, px = pidx - py * DT;
             const long long m = (fn * H + fty * DT + py) * W + ftx * DT + px;
             g[it] = q.cok ? ld4(dy + m * lddy + q.c) : f32x4{0.f, 0.f, 0.f, 0.f};
-            gy[it] = (has_lin && q.cok) ? lda4(lin.y, m * lin.ldy + q.c, lin.y_bf) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (has_lin) gy[it] = q.cok ? lda4(lin.y, m * lin.ldy + q.c, ly_bf) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     if (q.t0 < q.t1) fetch_dy(q.t0);
@@ -494,7 +518,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_walk_kernel(const float* __r
     for (long long tile = q.t0; tile < q.t1; ++tile) {
         if (tile == q.t0 || tx == 0) {
             dw_walk_strip(q, tile / q.tiles_x);
-            dw_walk_prologue(xs, x, ldx, aff, sc, sh, q, H, W, tx, rb, pl, cq, nullptr, nullptr, x_bf);
+            dw_walk_prologue<0, x_bf, 0>(xs, x, ldx, aff, sc, sh, q, H, W, tx, rb, pl, cq);
             __syncthreads();
         }
         f32x4 nx[5];
@@ -509,12 +533,17 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_walk_kernel(const float* __r
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int pidx = it * 16 + pl, py = pidx / DT, px = pidx - py * DT;
-            const f32x4 gv = has_lin ? dw_lin_eval(g[it], gy[it], q.cok, lc) : g[it];
+            f32x4 gv = g[it];
+            if constexpr (has_lin) gv = dw_lin_eval(g[it], gy[it], q.cok, lc);
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw)
                     acc[kh * 3 + kw] += gv * ld4(&xs[py + kh][dw_slot(rb, px + kw)][cq * 4]);
+            // pin the nine accumulators here: left alone, the compiler sinks all 4 x 9 multiply-adds below the two barriers that
+            // follow and keeps the 36 LDS operands (144 registers) alive until then -- 289-341 VGPRs, one block per CU
+#pragma unroll
+            for (int k = 0; k < 9; ++k) asm volatile("" : "+v"(acc[k]));
         }
         if (tile + 1 < q.t1) fetch_dy(tile + 1);
         __syncthreads();
@@ -610,6 +639,47 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_reduce_kernel(const float* _
     }
 }
 
+// runtime flags -> the compile-time instantiations of the strip-walk kernels
+template <typename... A>
+static void dw_launch_fprop_walk(int bf, unsigned blocks, hipStream_t st, A... a) {
+    switch (bf & 3) {
+    case 0: dwconv_walk_kernel<0, 0, 0, 0><<<blocks, 256, 0, st>>>(a...); break;
+    case 1: dwconv_walk_kernel<0, 0, 0, 1><<<blocks, 256, 0, st>>>(a...); break;
+    case 2: dwconv_walk_kernel<0, 0, 0, 2><<<blocks, 256, 0, st>>>(a...); break;
+    default: dwconv_walk_kernel<0, 0, 0, 3><<<blocks, 256, 0, st>>>(a...); break;
+    }
+}
+template <int LIN, int BNB, typename... A>
+static void dw_launch_dgrad_walk_bf(int bf, unsigned blocks, hipStream_t st, A... a) {
+    switch (bf & 3) {
+    case 0: dwconv_walk_kernel<1, LIN, BNB, 0><<<blocks, 256, 0, st>>>(a...); break;
+    case 1: dwconv_walk_kernel<1, LIN, BNB, 1><<<blocks, 256, 0, st>>>(a...); break;
+    case 2: dwconv_walk_kernel<1, LIN, BNB, 2><<<blocks, 256, 0, st>>>(a...); break;
+    default: dwconv_walk_kernel<1, LIN, BNB, 3><<<blocks, 256, 0, st>>>(a...); break;
+    }
+}
+template <typename... A>
+static void dw_launch_dgrad_walk(bool lin, bool bnb, int bf, unsigned blocks, hipStream_t st, A... a) {
+    if (!lin) bf &= ~1;
+    if (!bnb) bf &= ~2;
+    if (lin && bnb) dw_launch_dgrad_walk_bf<1, 1>(bf, blocks, st, a...);
+    else if (lin) dw_launch_dgrad_walk_bf<1, 0>(bf, blocks, st, a...);
+    else if (bnb) dw_launch_dgrad_walk_bf<0, 1>(bf, blocks, st, a...);
+    else dw_launch_dgrad_walk_bf<0, 0>(bf, blocks, st, a...);
+}
+template <typename... A>
+static void dw_launch_wgrad_walk(bool lin, int bf, unsigned blocks, hipStream_t st, A... a) {
+    if (!lin) bf &= ~2;
+    if (lin) {
+        switch (bf & 3) {
+        case 0: dwconv_wgrad_walk_kernel<1, 0><<<blocks, 256, 0, st>>>(a...); break;
+        case 1: dwconv_wgrad_walk_kernel<1, 1><<<blocks, 256, 0, st>>>(a...); break;
+        case 2: dwconv_wgrad_walk_kernel<1, 2><<<blocks, 256, 0, st>>>(a...); break;
+        default: dwconv_wgrad_walk_kernel<1, 3><<<blocks, 256, 0, st>>>(a...); break;
+        }
+    } else if (bf & 1) dwconv_wgrad_walk_kernel<0, 1><<<blocks, 256, 0, st>>>(a...);
+    else dwconv_wgrad_walk_kernel<0, 0><<<blocks, 256, 0, st>>>(a...);
+}
 // SEGHIERO_DW_WALK=0: the per-tile kernels (A/B timing)
 static bool dw_walk_on() {
     static const bool on = [] { const char* e = getenv("SEGHIERO_DW_WALK"); return !(e && e[0] == '0'); }();
@@ -631,7 +701,8 @@ extern "C" int sh_dwconv_fprop(const float* x, int ldx, const float* in_scale, c
     const long long M = (long long)N * H * W;
     dim3 grid((unsigned)sh_cdiv(M, DW_PIX), (unsigned)sh_cdiv(C, DW_CH));
     if (dil == 1 && H % DT == 0 && W % DT == 0 && dw_walk_on())       // same partial count: (H/8)*(W/8) tiles of 64 pixels per image
-        dwconv_walk_kernel<0><<<dw_walk_blocks(N, H, W, C) * grid.y, 256, 0, (hipStream_t)stream>>>(x, ldx, w, y, ldy, stat_partials, N, H, W, C, 0, in_scale, in_shift, DwBnb{}, DwLin{}, act_flags);
+        dw_launch_fprop_walk(act_flags, dw_walk_blocks(N, H, W, C) * grid.y, (hipStream_t)stream, x, (long long)ldx, w, y, (long long)ldy, stat_partials, N, H, W, C, 0, in_scale,
+                             in_shift, DwBnb{}, DwLin{}, act_flags);
     else if (dil == 1 && H % DT == 0 && W % DT == 0)
         dwconv_tile_kernel<0><<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(x, ldx, w, y, ldy, stat_partials, H, W, C, 0, in_scale, in_shift, DwBnb{});
     else
@@ -646,7 +717,8 @@ static int dw_dgrad_any(const float* dy, int lddy, const float* w, float* dx, in
     const long long M = (long long)N * H * W;
     dim3 grid((unsigned)sh_cdiv(M, DW_PIX), (unsigned)sh_cdiv(C, DW_CH));
     if (dil == 1 && H % DT == 0 && W % DT == 0 && dw_walk_on())
-        dwconv_walk_kernel<1><<<dw_walk_blocks(N, H, W, C) * grid.y, 256, 0, (hipStream_t)stream>>>(dy, lddy, w, dx, lddx, nullptr, N, H, W, C, accumulate, nullptr, nullptr, bnb, lin, 0);
+        dw_launch_dgrad_walk(lin.lin != nullptr, bnb.y != nullptr, (lin.y_bf ? 1 : 0) | (bnb.y_bf ? 2 : 0), dw_walk_blocks(N, H, W, C) * grid.y, (hipStream_t)stream,
+                             dy, (long long)lddy, w, dx, (long long)lddx, (float*)nullptr, N, H, W, C, accumulate, (const float*)nullptr, (const float*)nullptr, bnb, lin, 0);
     else if (lin.lin != nullptr || bnb.y_bf) return SH_EUNSUPPORTED;          // the deferred-apply loader and bf16 streams exist in the strip-walk kernels only
     else if (dil == 1 && H % DT == 0 && W % DT == 0)
         dwconv_tile_kernel<1><<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(dy, lddy, w, dx, lddx, nullptr, H, W, C, accumulate, nullptr, nullptr, bnb);
@@ -685,8 +757,8 @@ extern "C" int sh_dwconv_wgrad(const float* x, int ldx, const float* in_scale, c
     dim3 grid((unsigned)P, (unsigned)sh_cdiv(C, DW_CH));
     if (dil == 1 && H % DT == 0 && W % DT == 0 && dw_walk_on()) {
         P = (int)dw_walk_blocks(N, H, W, C);                        // one partial per block (<= M/64 rows of the workspace)
-        dwconv_wgrad_walk_kernel<<<(unsigned)P * grid.y, 256, 0, (hipStream_t)stream>>>(x, ldx, dy, lddy, dw_partials, N, H, W, C, in_scale, in_shift,
-                                                                                        DwLin{y_lin, ldyl, lin, (act_flags >> 1) & 1}, act_flags & 1);
+        dw_launch_wgrad_walk(lin != nullptr, act_flags & 3, (unsigned)P * grid.y, (hipStream_t)stream, x, (long long)ldx, dy, (long long)lddy, dw_partials, N, H, W, C, in_scale,
+                             in_shift, DwLin{y_lin, ldyl, lin, (act_flags >> 1) & 1});
     } else if (lin != nullptr) return SH_EUNSUPPORTED;
     else if (dil == 1 && H % DT == 0 && W % DT == 0)
         dwconv_wgrad_tile_kernel<<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(x, ldx, dy, lddy, dw_partials, H, W, C, M / (DT * DT), in_scale, in_shift);
