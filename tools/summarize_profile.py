@@ -31,12 +31,12 @@ out = collections.defaultdict(lambda: dict(launches=0, fetch_kib=0.0, write_kib=
 for which, col in (("fetch", "fetch_kib"), ("write", "write_kib")):
     f = glob.glob(f"{src}/{which}/runc/*_counter_collection.csv")[0]
     rows = list(csv.DictReader(open(f)))
-    # bench ran warmup 1 + steps 1 + instrumented 1 = 3 identical steps: average per step
+    # bench ran warmup 1 + steps 1 + instrumented 2 = 4 identical steps: average per step
     for r in rows:
         fam = family(r["Kernel_Name"])
-        out[fam][col] += float(r["Counter_Value"]) / 3.0
+        out[fam][col] += float(r["Counter_Value"]) / 4.0
         if which == "fetch":
-            out[fam]["launches"] += 1.0 / 3.0
+            out[fam]["launches"] += 1.0 / 4.0
 res = {}
 for fam, d in out.items():
     rd, wr = 2.0 * d["fetch_kib"] * 1024, d["write_kib"] * 1024
