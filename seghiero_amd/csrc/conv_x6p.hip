@@ -51,6 +51,21 @@ __device__ __forceinline__ int swz_row(int row) { return ((row >> 2) & 3) ^ (row
 // branch at the start of a phase), 2 = general (per-lane tap; stem 7x7 with 4 channels)
 // ABF: the activation stream of the loader is stored as bf16 (fprop: the A operand x; AFF == 2 dgrad: the y stream of lin(g, y)) --
 // 8-byte loads of 4 elements, widened to fp32 when the half-tile goes to LDS; everything downstream is unchanged
+// This file compiles as ONE translation unit (SH_X6P_PART undefined or 0) or as six (build.sh: -DSH_X6P_PART=1 fprop + grouped launch,
+// 2 dgrad, 3-6 the wgrad families by (lin loader, bf16 streams) -- the instantiations of one part each, so they compile side by side:
+// 4m45 of wall time for the one unit, about 1m10 for the slowest part).
+#ifndef SH_X6P_PART
+#define SH_X6P_PART 0
+#endif
+#define SH_PART(n) (SH_X6P_PART == 0 || SH_X6P_PART == (n))
+int sh_x6p_launch_dgrad(ConvQ& p, hipStream_t st, int force);
+int sh_x6p_wgrad_l0b0(ConvQ& p, bool aff, int wgm, int wgn, int splits, hipStream_t st);
+int sh_x6p_wgrad_l1b0(ConvQ& p, bool aff, int wgm, int wgn, int splits, hipStream_t st);
+int sh_x6p_wgrad_l0b1(ConvQ& p, bool aff, int wgm, int wgn, int splits, hipStream_t st);
+int sh_x6p_wgrad_l1b1(ConvQ& p, bool aff, int wgm, int wgn, int splits, hipStream_t st);
+static int x6p_mode() { static int v = -2; if (v == -2) { const char* e = getenv("SEGHIERO_X6P"); v = e ? atoi(e) : 1; } return v; }
+static int x6p_tile() { static int v = -2; if (v == -2) { const char* e = getenv("SEGHIERO_X6P_TILE"); v = e ? atoi(e) : 0; } return v; }
+#if SH_PART(1) || SH_PART(2)
 template <int MODE, int TM, int TN, int WGM, int WGN, int WPS, int AFF, int EPI, int SK, int TAP, int GRP = 0, int ABF = 0>
 __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const ConvQ p) {
     constexpr int NT = 64 * WGM * WGN;
@@ -622,8 +637,8 @@ static int pick_x6p(ConvQ& p, hipStream_t st, int force) {
     }
 }
 
-static int x6p_mode() { static int v = -2; if (v == -2) { const char* e = getenv("SEGHIERO_X6P"); v = e ? atoi(e) : 1; } return v; }
-static int x6p_tile() { static int v = -2; if (v == -2) { const char* e = getenv("SEGHIERO_X6P_TILE"); v = e ? atoi(e) : 0; } return v; }
+#endif
+#if SH_PART(1)
 
 // ngroups 1x1 convolutions of one geometry in ONE launch (p.ngroups, p.group_n, p.ga / gb / gsc / gsh set by the caller): the ASPP
 // branches of sep_aspp_contrast_head.py:100-131 -- grid = tiles_m x (ngroups * group_n / 128), so four under-filled 128-tile GEMMs
@@ -655,12 +670,20 @@ int sh_x6p_launch(int mode, ConvQ& p, hipStream_t st) {
         return pick_x6p<FPROP, 0, 1>(p, st, force);
     }
     if (aff) return SH_EINVAL;
+    return sh_x6p_launch_dgrad(p, st, force);
+}
+#endif
+#if SH_PART(2)
+int sh_x6p_launch_dgrad(ConvQ& p, hipStream_t st, int force) {
+    const bool bnb = p.bnb_y != nullptr;
     if (p.lin != nullptr && (p.act & 16)) return bnb ? pick_x6p<DGRAD, 2, 2, 1>(p, st, force) : pick_x6p<DGRAD, 2, 0, 1>(p, st, force);
     if (p.lin != nullptr) return bnb ? pick_x6p<DGRAD, 2, 2>(p, st, force) : pick_x6p<DGRAD, 2, 0>(p, st, force);
     if (bnb) return pick_x6p<DGRAD, 0, 2>(p, st, force);
     return pick_x6p<DGRAD, 0, 0>(p, st, force);
 }
+#endif
 
+#if SH_X6P_PART == 0 || SH_X6P_PART >= 3
 // ============================================================================================ WGRAD, pipelined
 // dW[co][n'] = sum_pix dY[pix][co] * im2col(X)[pix][n'] with the same two-half-tile pipeline as above: a K=32 tile of pixels is
 // two K=16 halves = k-rows 0..15 / 16..31 of the [k][row] LDS planes of conv_wgrad_x6_kernel (transposing ds_read_b64_tr_b16
@@ -892,6 +915,11 @@ static int pick_wgrad_x6p(ConvQ& p, int wgm, int wgn, int splits, hipStream_t st
     if (wgm == 1 && wgn == 2) return launch_wgrad_x6p<1, 2, AFF, LIN, XBF>(p, splits, st);
     return launch_wgrad_x6p<2, 2, AFF, LIN, XBF>(p, splits, st);
 }
+// the four (LIN, XBF) families of instantiations, one translation unit each (parts 3-6)
+#if SH_PART(3)
+int sh_x6p_wgrad_l0b0(ConvQ& p, bool aff, int wgm, int wgn, int splits, hipStream_t st) {
+    return aff ? pick_wgrad_x6p<1>(p, wgm, wgn, splits, st) : pick_wgrad_x6p<0>(p, wgm, wgn, splits, st);
+}
 // Entry used by sh_conv_wgrad_x6 (same tile / K-slice plan as conv_wgrad_x6_kernel; the slab reduce stays with the caller)
 int sh_x6p_wgrad_launch(ConvQ& p, int wgm, int wgn, int splits, hipStream_t st) {
     const bool aff = p.aff_scale != nullptr;
@@ -899,10 +927,25 @@ int sh_x6p_wgrad_launch(ConvQ& p, int wgm, int wgn, int splits, hipStream_t st) 
     if (p.Wo < 16 || (p.Cin & 3)) return SH_X6P_NO;
     if (p.act & 32) {          // bf16 X operand; a lin y stream must then be bf16 too (the trunk: both are stored conv outputs)
         if (p.lin != nullptr && !(p.act & 16)) return SH_X6P_NO;
-        if (p.lin != nullptr) return aff ? pick_wgrad_x6p<1, 1, 1>(p, wgm, wgn, splits, st) : pick_wgrad_x6p<0, 1, 1>(p, wgm, wgn, splits, st);
-        return aff ? pick_wgrad_x6p<1, 0, 1>(p, wgm, wgn, splits, st) : pick_wgrad_x6p<0, 0, 1>(p, wgm, wgn, splits, st);
+        return p.lin != nullptr ? sh_x6p_wgrad_l1b1(p, aff, wgm, wgn, splits, st) : sh_x6p_wgrad_l0b1(p, aff, wgm, wgn, splits, st);
     }
     if (p.lin != nullptr && (p.act & 16)) return SH_X6P_NO;
-    if (p.lin != nullptr) return aff ? pick_wgrad_x6p<1, 1>(p, wgm, wgn, splits, st) : pick_wgrad_x6p<0, 1>(p, wgm, wgn, splits, st);
-    return aff ? pick_wgrad_x6p<1>(p, wgm, wgn, splits, st) : pick_wgrad_x6p<0>(p, wgm, wgn, splits, st);
+    return p.lin != nullptr ? sh_x6p_wgrad_l1b0(p, aff, wgm, wgn, splits, st) : sh_x6p_wgrad_l0b0(p, aff, wgm, wgn, splits, st);
 }
+#endif
+#if SH_PART(4)
+int sh_x6p_wgrad_l1b0(ConvQ& p, bool aff, int wgm, int wgn, int splits, hipStream_t st) {
+    return aff ? pick_wgrad_x6p<1, 1>(p, wgm, wgn, splits, st) : pick_wgrad_x6p<0, 1>(p, wgm, wgn, splits, st);
+}
+#endif
+#if SH_PART(5)
+int sh_x6p_wgrad_l0b1(ConvQ& p, bool aff, int wgm, int wgn, int splits, hipStream_t st) {
+    return aff ? pick_wgrad_x6p<1, 0, 1>(p, wgm, wgn, splits, st) : pick_wgrad_x6p<0, 0, 1>(p, wgm, wgn, splits, st);
+}
+#endif
+#if SH_PART(6)
+int sh_x6p_wgrad_l1b1(ConvQ& p, bool aff, int wgm, int wgn, int splits, hipStream_t st) {
+    return aff ? pick_wgrad_x6p<1, 1, 1>(p, wgm, wgn, splits, st) : pick_wgrad_x6p<0, 1, 1>(p, wgm, wgn, splits, st);
+}
+#endif
+#endif
