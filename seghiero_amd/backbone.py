@@ -68,6 +68,9 @@ def _stage(kind, cin, width, n, stride):
 # (+1.6 ms of dgrad) than the statistics pass it replaces (-0.7 ms); with the epilogue processed in row-group chunks (no spills) it
 # wins: dgrad +0.6 ms, statistics pass -1.0 ms, step 33.94 -> 33.45 ms -- on by default.
 BNB_RESIDUAL = __import__("os").environ.get("SEGHIERO_BNB_RESIDUAL", "1") != "0"
+# The gradient a stage output receives from outside the trunk (c1 <- decoder, c3 <- aux head) is summed by the first dgrad epilogue of the
+# next stage's first block instead of an axpy pass over the 268 MB / 67 MB tensor: same-box A/B 33.00 -> 32.85 ms per step.
+STAGE_GRAD_IN_EPILOGUE = __import__("os").environ.get("SEGHIERO_STAGE_GRAD_EPI", "1") != "0"
 
 
 # ----------------------------------------------------------------------------- hand-scheduled fwd / bwd
@@ -88,11 +91,12 @@ def _block_fwd(blk, x, training):
     return h, (recs, ds_rec)
 
 
-def _block_bwd(blk, saved, dout, gm, prev_rec=None):
+def _block_bwd(blk, saved, dout, gm, prev_rec=None, extra=None):
     """dout: gradient w.r.t. the block output (tensor, or a GradPack made by the NEXT block's first conv).  prev_rec: last CBARec of
     the previous block when this block's input is that block's output and no downsample path adds into the input gradient -- the
     first conv's dgrad epilogue then runs the front half of that block's bn3 backward (mask from its `out`) and the identity
-    gradient needs no separate tensor."""
+    gradient needs no separate tensor.  extra (blocks with a downsample path only): a tensor of the input's shape summed into the
+    input gradient by the first conv's dgrad epilogue -- the previous stage's own output gradient (c1 / c3 feed the head)."""
     recs, ds_rec = saved
     chain = blk.chain()
     # last conv: g = dout * relu-mask feeds BN backward AND (as dres) the identity / downsample path
@@ -102,7 +106,7 @@ def _block_bwd(blk, saved, dout, gm, prev_rec=None):
     for i in range(len(chain) - 2, -1, -1):
         conv, bn = chain[i]
         first = i == 0
-        addend = dres if (first and ds_rec is None) else None      # identity path summed in the dgrad epilogue
+        addend = dres if (first and ds_rec is None) else (extra if first else None)      # identity path summed in the dgrad epilogue
         d, dw, dg, db, _ = L.cba_bwd(recs[i], bn, d, need_dx=True, addend=addend,
                                      pack_for=prev_rec if (first and ds_rec is None) else None)
         gm.put(conv.weight, dw); gm.put(bn.weight, dg); gm.put(bn.bias, db)
@@ -179,9 +183,10 @@ class _BackboneFn(torch.autograd.Function):
         for idx, (li, _) in enumerate(blocks):
             last_of_layer[li] = idx
         d = None
+        summed = set()                                                   # stages whose own output gradient is already inside d
         for idx in range(len(blocks) - 1, -1, -1):
             li, blk = blocks[idx]
-            if last_of_layer[li] == idx and douts[li] is not None:       # this block's output is c_{li+1}
+            if last_of_layer[li] == idx and douts[li] is not None and li not in summed:       # this block's output is c_{li+1}
                 g = L.grad_as_nhwc_padded(douts[li], douts[li].shape[1])
                 if d is None:
                     d = g
@@ -192,7 +197,14 @@ class _BackboneFn(torch.autograd.Function):
             prev_rec = None
             if BNB_RESIDUAL and idx > 0 and blocks[idx - 1][0] == li and blk.downsample is None:
                 prev_rec = saved[idx - 1][0][-1]                      # previous block of the same stage feeds this one directly
-            d = _block_bwd(blk, saved[idx], d, gm, prev_rec)
+            extra = None
+            if STAGE_GRAD_IN_EPILOGUE and idx > 0 and blocks[idx - 1][0] != li and blk.downsample is not None and douts[blocks[idx - 1][0]] is not None:
+                # first block of a stage: the previous stage's own output gradient (c1 from the decoder, c3 from the aux head) rides in
+                # this block's first dgrad epilogue instead of a separate read-modify-write pass over the stage output
+                lp = blocks[idx - 1][0]
+                extra = L.grad_as_nhwc_padded(douts[lp], douts[lp].shape[1])
+                summed.add(lp)
+            d = _block_bwd(blk, saved[idx], d, gm, prev_rec, extra)
             if idx == 0 or blocks[idx - 1][0] != li:                      # first block of a stage: the stage's gradients are final
                 gm.flush(L.params_of(layers[li]))
         if d is not None:
