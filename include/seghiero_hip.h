@@ -234,6 +234,14 @@ int sh_bn_finalize_multi(int k, const float* partials, int n_partials, int C, do
  * dL/dw_centre = gamma * dgamma * eps * invstd_y^2 / w, off-centre taps exactly 0. */
 int sh_dw_center_wgrad(const float* dgamma, const float* gamma, const float* isy, const float* w, float eps, float* dw,
                        int C, void* stream);
+/* Fold a long list of statistics partials before finalizing it: `chunk` consecutive partials -> one partial of the same format
+ * (centred (sum, M2) pairs of rows_per_partial rows each when rows_per_partial > 0 -- the last one short, count rows in all; plain
+ * sums when 0), out = [ceil(n_partials / chunk)][2][C].  sh_bn_finalize / sh_bn_bwd_finalize then take `out` with
+ * rows_per_partial * chunk.  Blocks own whole 128-byte lines of 32 channels over the whole chip; the one-stage finalize gathers 16
+ * bytes per row on C / 4 CUs (PyTorch's nn.BatchNorm2d statistics, models/backbone/resnet.py:65-73 via torchvision; new kernel).
+ * SH_EUNSUPPORTED unless C % 4 == 0 and both buffers are 16-byte aligned. */
+int sh_bn_fold_partials(const float* partials, int n_partials, int C, double count, int rows_per_partial, int chunk,
+                        float* out, void* stream);
 /* SyncBN building blocks (cross-GPU BatchNorm is new functionality): reduce the partials to f64 per-channel
  * sums on each rank -- sq is double[2*C + 1] = {sum x [C], sum x^2 [C], local pixel count} (forward, from the centred
  * partials) or {sum g [C], sum g*xhat [C], count} (backward, rows_per_partial = 0) -- all-reduce the vector over RCCL on

@@ -158,6 +158,69 @@ __device__ __forceinline__ void reduce_partials_4ch(const float* __restrict__ pa
     }
 }
 
+// Long partial lists (P >= 4096: the 128x128 layers and the stem) fold first: `chunk` consecutive partials -> one partial of chunk * R
+// rows, in the SAME format (centred (sum, M2) pairs when R > 0, plain sums when R == 0), so the finalize kernels above then run on
+// P / chunk rows.  The one-stage reduce owns 4 channels per block -- 16 of a row's bytes out of every 128-byte line it pulls, and at
+// C = 64 only 16 CUs take part (17-31 us at P = 4096, 51 us for the stem).  Here a block owns 32 adjacent channels (whole lines: 8
+// float4 lanes x 32 row lanes) of one chunk, so the grid is (C / 32) x (P / chunk) blocks over the whole chip.
+// Centred merge in f64: M2 = sum M2_p + sum (s_p^2 / n_p) - S^2 / n with S = sum s_p, n = sum n_p.
+__global__ __launch_bounds__(256) void bn_fold_partials_kernel(const float* __restrict__ partials, int P, int C, long long M, int R, int chunk,
+                                                               float* __restrict__ out) {
+    __shared__ double red[4][8][12];
+    const int t = threadIdx.x, l = t & 7, rr = t >> 3;
+    const int c = blockIdx.x * 32 + 4 * l, s = blockIdx.y;
+    const int p0 = s * chunk, p1 = p0 + chunk < P ? p0 + chunk : P;
+    double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};          // [0..3] sum s_p, [4..7] sum M2_p (or the second plain sum), [8..11] sum s_p^2 / n_p
+    if (c < C) {
+        for (int p = p0 + rr; p < p1; p += 32) {
+            const float* r0 = partials + ((long long)p * 2) * C + c;
+            const f32x4 a = ld4(r0), b = ld4(r0 + C);
+            double inv_n = 0.0;
+            if (R > 0) { const long long left = M - (long long)p * R; inv_n = 1.0 / (double)(left < R ? left : R); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[j] += (double)a[j]; acc[4 + j] += (double)b[j]; acc[8 + j] += (double)a[j] * (double)a[j] * inv_n; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+#pragma unroll
+        for (int o = 32; o >= 8; o >>= 1) acc[j] += __shfl_xor(acc[j], o, 64);
+    }
+    if ((t & 63) < 8) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) red[t >> 6][l][j] = acc[j];
+    }
+    __syncthreads();
+    if (t < 8 && c < C) {
+        double v[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) v[j] = (red[0][t][j] + red[1][t][j]) + (red[2][t][j] + red[3][t][j]);
+        f32x4 o0, o1;
+        double n = 0.0;
+        if (R > 0) { const long long left = M - (long long)p0 * R, full = (long long)chunk * R; n = (double)(left < full ? left : full); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o0[j] = (float)v[j];
+            double m2 = v[4 + j];
+            if (R > 0) { m2 += v[8 + j] - v[j] * v[j] / n; if (m2 < 0) m2 = 0; }
+            o1[j] = (float)m2;
+        }
+        st4(out + ((long long)s * 2) * C + c, o0);
+        st4(out + ((long long)s * 2 + 1) * C + c, o1);
+    }
+}
+// out: [ceil(n_partials / chunk)][2][C].  rows_per_partial > 0: centred partials of that many rows each (the last one short: count rows
+// in all); 0: plain sums.  C % 4 == 0 and 16-byte aligned buffers, else SH_EUNSUPPORTED (the caller finalizes the list as it is).
+extern "C" int sh_bn_fold_partials(const float* partials, int n_partials, int C, double count, int rows_per_partial, int chunk, float* out,
+                                   void* stream) {
+    if (!partials || !out || n_partials <= 0 || C <= 0 || chunk < 2 || rows_per_partial < 0 || (rows_per_partial > 0 && count <= 0)) return SH_EINVAL;
+    if (rows_per_partial > 0 && (long long)n_partials != sh_cdiv((long long)count, rows_per_partial)) return SH_EINVAL;
+    if ((C & 3) || (((uintptr_t)partials | (uintptr_t)out) & 15)) return SH_EUNSUPPORTED;
+    dim3 grid((unsigned)sh_cdiv(C, 32), (unsigned)sh_cdiv(n_partials, chunk));
+    bn_fold_partials_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(partials, n_partials, C, (long long)count, rows_per_partial, chunk, out);
+    return sh_launch_status();
+}
+
 // wmul != nullptr (per-channel multiplier wmul[c * wstride]): the statistics are those of x but the BatchNorm normalises y = w * x
 // (a depthwise conv whose off-centre taps never touch the image, SURVEY A.1: dilation >= H, W) -- mean_y = w mean_x, var_y = w^2 var_x.
 // The coefficients are then emitted in the x domain so that every consumer can work on x itself:

@@ -615,6 +615,21 @@ def _all_reduce_sq(sq):
     return sq
 
 
+FOLD_MIN = int(os.environ.get("SEGHIERO_FOLD_MIN", "4096"))      # partial lists at least this long are folded 64:1 before the finalize
+FOLD_CHUNK = 64
+
+
+def _fold_partials(partials, c, count, rows):
+    """(partials', rows') for the finalize kernels: a long list is folded FOLD_CHUNK:1 by sh_bn_fold_partials (same format), else as is."""
+    p = partials.shape[0]
+    if p < FOLD_MIN or partials.shape[-1] != c or not partials.is_contiguous():
+        return partials, rows
+    out = torch.empty((-(-p // FOLD_CHUNK), 2, c), device=partials.device, dtype=torch.float32)
+    if not _call_fused("sh_bn_fold_partials", partials.data_ptr(), p, c, float(count), rows, FOLD_CHUNK, out.data_ptr(), _st(), key=f"P{p} C{c}"):
+        return partials, rows
+    return out, rows * FOLD_CHUNK
+
+
 def bn_finalize(partials, count, gamma, beta, eps, momentum, running_mean, running_var, c, device, rows=64, coefs=None,
                 partials_ld=0, partials_col=0):
     """coefs (optional): (4, c) tensor / strided view to fill.  partials_ld / partials_col: this layer's columns are
@@ -636,6 +651,9 @@ def bn_finalize(partials, count, gamma, beta, eps, momentum, running_mean, runni
               None if running_var is None else running_var.data_ptr(),
               coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(), coefs[3].data_ptr(), _st())
         return coefs
+    if not partials_ld and not partials_col:
+        partials, rows = _fold_partials(partials, c, count, rows)
+        pptr = partials.data_ptr()
     _call("sh_bn_finalize", pptr, partials.shape[0], c, float(count),
           None if gamma is None else gamma.data_ptr(), None if beta is None else beta.data_ptr(), eps, momentum,
           None if running_mean is None else running_mean.data_ptr(),
@@ -833,6 +851,8 @@ def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None, d
               red[0].data_ptr(), red[1].data_ptr(), red[2].data_ptr(), red[3].data_ptr(),
               None if gamma is None else gamma.data_ptr(), coefs[1].data_ptr(), coefs[0].data_ptr(), linp, _st())
     else:
+        partials, _ = _fold_partials(partials, c, m, 0)
+        p = partials.shape[0]
         _call("sh_bn_bwd_finalize", partials.data_ptr(), p, c, None if gamma is None else gamma.data_ptr(),
               coefs[1].data_ptr(), float(m), red[0].data_ptr(), red[1].data_ptr(), red[2].data_ptr(), red[3].data_ptr(),
               coefs[0].data_ptr(), linp, _st(), key=f"P{p} C{c}")

@@ -396,6 +396,55 @@ def test_batchnorm_train_fwd_bwd(ops, shape, relu, res):
         close(dres, resid.grad, 1e-6, 1e-6, "dres")
 
 
+@pytest.mark.parametrize("c,m,rows", [(64, 16 * 128 * 128, 64), (48, 16 * 128 * 128 - 37, 64), (560, 4100 * 64 - 5, 64), (12, 300000, 64), (9, 300000, 64)])
+def test_batchnorm_fold_partials_before_finalize(ops, c, m, rows, monkeypatch):
+    """Long statistics lists are folded 64:1 (sh_bn_fold_partials: centred merge in f64, same partial format) before the finalize
+    kernels: coefficients / running statistics (forward) and dgamma / dbeta / c1 / c2 (backward) equal those of the one-stage
+    finalize of the full list to fp32 rounding of the folded partials (1e-6 relative), and an f64 reference; ragged tails (last
+    partial short, last chunk short) and a channel count that is no multiple of 32 included."""
+    g = torch.Generator(device=DEV).manual_seed(c)
+    p = -(-m // rows)
+    # centred partials of random data: per partial (sum, M2 about its own mean) of n_p values ~ N(mu_c, sd_c) -- built in f64
+    n_p = torch.full((p,), rows, device=DEV, dtype=torch.float64); n_p[-1] = m - (p - 1) * rows
+    mu = torch.linspace(-3, 5, c, device=DEV, dtype=torch.float64)
+    mean_p = mu[None, :] + 0.3 * torch.randn((p, c), generator=g, device=DEV, dtype=torch.float64)
+    m2_p = (0.5 + torch.rand((p, c), generator=g, device=DEV, dtype=torch.float64)) * n_p[:, None]
+    part = torch.stack([mean_p * n_p[:, None], m2_p], 1).float().contiguous()
+    s64, q64 = part[:, 0].double(), part[:, 1].double()
+    tot = s64.sum(0)
+    mean_ref = tot / m
+    var_ref = (q64 + s64 * s64 / n_p[:, None]).sum(0) / m - mean_ref ** 2
+    gamma, beta = torch.rand(c, device=DEV) + 0.5, torch.randn(c, device=DEV)
+
+    def fwd(fold_min):
+        monkeypatch.setattr(ops, "FOLD_MIN", fold_min)
+        rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+        return ops.bn_finalize(part, m, gamma, beta, 1e-5, 0.1, rm, rv, c, DEV, rows=rows).clone(), rm, rv
+    (c0, rm0, rv0), (c1, rm1, rv1) = fwd(1 << 30), fwd(1024)
+    if c % 4 == 0:          # (else sh_bn_fold_partials answers SH_EUNSUPPORTED and the list is finalized as it is: bit-equal)
+        close(c1[0], mean_ref.float(), 1e-6, 1e-6, "mean vs f64")
+        close(c1[1], (1.0 / torch.sqrt(var_ref + 1e-5)).float(), 2e-6, 0, "invstd vs f64")
+    close(c1, c0, 2e-6, 1e-6, "folded vs one-stage coefficients")
+    close(rm1, rm0, 2e-6, 1e-7); close(rv1, rv0, 2e-6, 1e-7)
+    # backward: plain sums
+    bp = torch.randn((p, 2, c), generator=g, device=DEV) * 3
+
+    def bwd(fold_min):
+        monkeypatch.setattr(ops, "FOLD_MIN", fold_min)
+        red = torch.empty((4, c), device=DEV)
+        q, _ = ops._fold_partials(bp, c, m, 0)
+        assert q.shape[0] == (p if (fold_min > p or c % 4) else -(-p // 64))
+        ops._call("sh_bn_bwd_finalize", q.data_ptr(), q.shape[0], c, gamma.data_ptr(), c0[1].data_ptr(), float(m),
+                  red[0].data_ptr(), red[1].data_ptr(), red[2].data_ptr(), red[3].data_ptr(), c0[0].data_ptr(), None, ops._st())
+        return red
+    r0, r1 = bwd(1 << 30), bwd(1024)
+    ref = bp.double().sum(0)
+    scale = float(bp.abs().max()) * (p ** 0.5)
+    close(r1[1], ref[0].float(), 0, 2e-6 * scale, "dbeta vs f64")
+    close(r1[0], ref[1].float(), 0, 2e-6 * scale, "dgamma vs f64")
+    close(r1, r0, 0, 2e-6 * scale, "folded vs one-stage backward sums")
+
+
 def test_bn_eval_coefs(ops):
     g = torch.Generator().manual_seed(1)
     c = 24
