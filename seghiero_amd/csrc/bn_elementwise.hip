@@ -233,26 +233,34 @@ __global__ __launch_bounds__(NT) void bn_finalize_kernel(const float* __restrict
                                                           float* running_var, float* mean, float* invstd, float* scale,
                                                           float* shift, int R, long long ldp, const float* __restrict__ wmul, int wstride,
                                                           float* __restrict__ isy) {
+    // the per-channel operands of the epilogue are fetched BEFORE the reduction (threads 0..3 own channels c0..c0+3 there): the kernel is a
+    // chain of dependent memory round trips on a few blocks, and this takes one of them off the critical path
+    const int cpre = blockIdx.x * 4 + threadIdx.x;
+    float g = 1.f, b = 0.f, w = 1.f, rm0 = 0.f, rv0 = 0.f;
+    if (threadIdx.x < 4 && cpre < C) {
+        if (gamma) g = gamma[cpre];
+        if (beta) b = beta[cpre];
+        if (wmul) w = wmul[(long long)cpre * wstride];
+        if (running_mean) { rm0 = running_mean[cpre]; rv0 = running_var[cpre]; }
+    }
     reduce_partials_4ch<NT>(partials, P, C, blockIdx.x * 4, R, (long long)count, [&](int c, double s, double q) {
         const double mu = s / count;
         double var = q / count - mu * mu;
         if (var < 0) var = 0;
-        const float w = wmul ? wmul[(long long)c * wstride] : 1.f;
         const float fmu = (float)mu;
         const float fmu_y = wmul ? w * fmu : fmu;
         const double var_y = wmul ? (double)w * (double)w * var : var;
         const float is = 1.0f / sqrtf((float)var_y + eps);
         mean[c] = fmu;
         invstd[c] = wmul ? w * is : is;
-        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
         const float sc = g * is;
         scale[c] = wmul ? w * sc : sc;
         shift[c] = b - fmu_y * sc;
         if (isy) isy[c] = is;
         if (running_mean) {
             const double unbiased = count > 1 ? var_y * (count / (count - 1.0)) : var_y;
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * fmu_y;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+            running_mean[c] = (1.f - momentum) * rm0 + momentum * fmu_y;
+            running_var[c] = (1.f - momentum) * rv0 + momentum * (float)unbiased;
         }
     }, ldp);
 }
@@ -605,13 +613,16 @@ __global__ __launch_bounds__(NT) void bn_bwd_finalize_kernel(const float* __rest
                                                               const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                               double count, float* dgamma, float* dbeta, float* c1, float* c2,
                                                               const float* __restrict__ mean, float* __restrict__ lin) {
+    const int cpre = blockIdx.x * 4 + threadIdx.x;          // epilogue operands fetched before the reduction (see bn_finalize_kernel)
+    float ga = 1.f, is = 0.f, mu = 0.f;
+    if (lin && threadIdx.x < 4 && cpre < C) { if (gamma) ga = gamma[cpre]; is = invstd[cpre]; mu = mean[cpre]; }
     reduce_partials_4ch<NT>(partials, P, C, blockIdx.x * 4, 0, 0, [&](int c, double s, double q) {
         if (dbeta) dbeta[c] = (float)s;
         if (dgamma) dgamma[c] = (float)q;
         const float f1 = (float)(s / count), f2 = (float)(q / count);
         c1[c] = f1;
         c2[c] = f2;
-        if (lin) bn_bwd_lin(lin, C, c, gamma ? gamma[c] : 1.f, invstd[c], mean[c], f1, f2);
+        if (lin) bn_bwd_lin(lin, C, c, ga, is, mu, f1, f2);
     });
 }
 extern "C" int sh_bn_bwd_finalize(const float* partials, int n_partials, int C, const float* gamma, const float* invstd,
