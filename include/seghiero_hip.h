@@ -133,7 +133,8 @@ int sh_conv_dgrad_x6(const float* dy, int lddy, const float* wt, const float* ad
  * sh_bn_bwd_apply(relu = 0) on g.  y_prev: raw output of the producer conv [N*H*W][ldyp]; mean / invstd / scale / shift: its
  * BatchNorm coefficients [Cin]; relu: 0 / 1.  out_prev (optional): the ReLU mask is out_prev > 0 instead -- residual blocks, where
  * out = relu(bn3(y) + identity) (models/backbone/resnet.py via torchvision Bottleneck): then g is also the identity path's
- * gradient.  Stride-1 geometries only; SH_EUNSUPPORTED otherwise. */
+ * gradient; with act_flags bit 2, out_prev is that output's ReLU quad mask (sh_bn_act's relu_mask, ldop = bytes per pixel).
+ * Stride-1 geometries only; SH_EUNSUPPORTED otherwise. */
 int sh_conv_dgrad_x6_bnb(const float* dy, int lddy, const float* wt, const float* addend, int ldadd, float* g, int ldg,
                          const float* y_prev, int ldyp, const float* out_prev, int ldop, const float* mean,
                          const float* invstd, const float* scale, const float* shift, int relu, float* stat_partials,
@@ -264,13 +265,17 @@ int sh_channel_stats(const float* y, int ldy, int64_t M, int C, float* partials,
 /* out = [relu]( y*scale + shift [+ residual] ).  Replaces BN-apply + ReLU (+ the Bottleneck residual add).
  * res_scale / res_shift (optional, both or neither): `residual` is the RAW output of the block's downsample conv and its
  * BatchNorm is applied on the fly, residual*res_scale + res_shift (same operation order as applying it first: bit-identical),
- * so the downsample branch of torchvision's Bottleneck / BasicBlock never materialises its normalised output. */
+ * so the downsample branch of torchvision's Bottleneck / BasicBlock never materialises its normalised output.
+ * relu_mask (optional, 16-byte layouts only): the ReLU QUAD MASK of `out`, one byte per (pixel, 4 adjacent channels), bit j =
+ * (out[c + j] > 0), M * C / 4 bytes -- what the backward passes of a residual block need of its output (1/16 of its bytes):
+ * sh_bn_bwd_reduce / sh_bn_bwd_apply with relu = 3 and sh_conv_dgrad_x6_bnb with act_flags bit 2 take it in place of `out`. */
 int sh_bn_act(const float* y, int ldy, const float* scale, const float* shift, const float* residual,
               int ldr, const float* res_scale, const float* res_shift, float* out, int ldo, int64_t M, int C, int relu,
-              int act_flags, void* stream);
+              uint8_t* relu_mask, int act_flags, void* stream);
 /* Backward of the above.  g = dout * mask.  relu = 0: no mask; 1: mask = out > 0 (needed when a residual was added);
  * 2: mask = y*scale+shift > 0, the forward's own arithmetic recomputed from y (no residual) -- `out` is not read, which
- * saves one activation-sized HBM read in each of the two passes.  reduce: partials [n][2][C] of (sum g, sum g*xhat);
+ * saves one activation-sized HBM read in each of the two passes; 3: `out` points to the ReLU quad mask sh_bn_act wrote (ldo = bytes
+ * per pixel >= C / 4; 16-byte layouts only).  reduce: partials [n][2][C] of (sum g, sum g*xhat);
  * finalize: dgamma, dbeta; apply: dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)), optionally dres = g.
  * Deferred second half: reduce can also STORE g (g_out, 16-byte layouts only, else SH_EUNSUPPORTED) and finalize can emit
  * lin[4][C] = (A, B, mean, D) with dy = A*g + B*(y - mean) + D; the 1x1 consumers of dy (sh_conv_dgrad_x6_lin,

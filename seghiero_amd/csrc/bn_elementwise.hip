@@ -564,6 +564,10 @@ __global__ __launch_bounds__(256) void bn_bwd_partials_v4_kernel(const float* __
                     const f32x4 o = yv * sc + sh;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
+                } else if (relu == 3) {                 // `out` is the ReLU quad mask sh_bn_act wrote (ldo bytes per pixel)
+                    const f32x4 o = quad_mask_load(out, r * ldo + (c >> 2));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
                 }
                 s += g;
                 q += g * ((yv - mu) * is);
@@ -589,13 +593,13 @@ extern "C" int sh_bn_bwd_reduce(const float* dout, int lddo, const float* out, i
                                 int64_t M, int C, int relu, float* g_out, int ldg, int act_flags, void* stream) {
     if (!dout || !y || !mean || !invstd || !partials || M <= 0 || C <= 0 || lddo < C || ldy < C) return SH_EINVAL;
     if (g_out && (ldg < C || (ldg & 3) || ((uintptr_t)g_out & 15))) return SH_EINVAL;
-    if (relu < 0 || relu > 2 || (relu == 1 && (!out || ldo < C)) || (relu == 2 && (!scale || !shift))) return SH_EINVAL;
+    if (relu < 0 || relu > 3 || (relu == 1 && (!out || ldo < C)) || (relu == 2 && (!scale || !shift)) || (relu == 3 && (!out || ldo * 4 < C))) return SH_EINVAL;
     dim3 grid((unsigned)sh_cdiv(M, STAT_ROWS), (unsigned)sh_cdiv(C, 64));
     const bool v4 = (C & 3) == 0 && ((lddo | ldy | (relu == 1 ? ldo : 0)) & 3) == 0 && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
                     (relu != 1 || ((uintptr_t)out & 15) == 0) && ((uintptr_t)mean & 15) == 0 && ((uintptr_t)invstd & 15) == 0 &&
                     (relu != 2 || ((((uintptr_t)scale | (uintptr_t)shift) & 15) == 0));
     if (v4) bn_bwd_partials_v4_kernel<<<grid.x * grid.y, 256, 0, (hipStream_t)stream>>>(y, ldy, dout, lddo, out, ldo, mean, invstd, scale, shift, partials, M, C, relu, g_out, ldg, act_flags);
-    else if (g_out || act_flags) return SH_EUNSUPPORTED;          // masked-gradient output and bf16 tensors: the 16-byte kernel only
+    else if (g_out || act_flags || relu == 3) return SH_EUNSUPPORTED;          // masked-gradient output, bf16 tensors, quad masks: the 16-byte kernel only
     else channel_partials_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(y, ldy, dout, lddo, out, ldo, mean, invstd, scale, shift, partials, M, C, relu);
     return sh_launch_status();
 }
@@ -642,7 +646,8 @@ template <int V>
 __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y, long long ldy, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, const float* __restrict__ res, long long ldr,
                                                      float* __restrict__ out, long long ldo, long long M, int C, int relu,
-                                                     const float* __restrict__ rscale, const float* __restrict__ rshift, int af) {
+                                                     const float* __restrict__ rscale, const float* __restrict__ rshift, int af,
+                                                     unsigned char* __restrict__ qmask) {
     const int cv = C / V;
     // chunks of EW_ROWS rows per block iteration; 32-bit (row, column) split inside a chunk
     for (long long m0 = (long long)blockIdx.x * EW_ROWS; m0 < M; m0 += (long long)gridDim.x * EW_ROWS)
@@ -659,6 +664,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y
             }
             if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
             sta4(out, m * ldo + c, v, af & 4);
+            if (qmask) qmask[m * cv + (c >> 2)] = (unsigned char)quad_mask_bits(v);           // (common.h: ReLU quad mask)
         } else {
             float v = y[m * ldy + c] * scale[c] + shift[c];
             if (res) v += rscale ? res[m * ldr + c] * rscale[c] + rshift[c] : res[m * ldr + c];
@@ -679,17 +685,17 @@ static inline bool vec4_ok(int C, long long a, long long b = 0, long long c = 0,
 static inline bool ptr16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 extern "C" int sh_bn_act(const float* y, int ldy, const float* scale, const float* shift, const float* residual, int ldr,
-                         const float* res_scale, const float* res_shift, float* out, int ldo, int64_t M, int C, int relu, int act_flags,
-                         void* stream) {
+                         const float* res_scale, const float* res_shift, float* out, int ldo, int64_t M, int C, int relu, uint8_t* relu_mask,
+                         int act_flags, void* stream) {
     if (!y || !scale || !shift || !out || M <= 0 || C <= 0 || ldy < C || ldo < C) return SH_EINVAL;
     if (residual && ldr < C) return SH_EINVAL;
     if ((res_scale == nullptr) != (res_shift == nullptr) || (res_scale && !residual)) return SH_EINVAL;
     // (bf16 tensors: 8-byte accesses -- base pointers 8-byte aligned suffice, 16 is what the allocator gives anyway)
     const bool v4 = vec4_ok(C, ldy, ldo, residual ? ldr : 0) && ptr16(y) && ptr16(out) && ptr16(scale) && ptr16(shift) && (!residual || ptr16(residual)) &&
                     (!res_scale || (ptr16(res_scale) && ptr16(res_shift)));
-    if (act_flags && !v4) return SH_EUNSUPPORTED;
-    if (v4) bn_act_kernel<4><<<rows_grid(M, C / 4), 256, 0, (hipStream_t)stream>>>(y, ldy, scale, shift, residual, ldr, out, ldo, M, C, relu, res_scale, res_shift, act_flags);
-    else bn_act_kernel<1><<<rows_grid(M, C), 256, 0, (hipStream_t)stream>>>(y, ldy, scale, shift, residual, ldr, out, ldo, M, C, relu, res_scale, res_shift, 0);
+    if ((act_flags || relu_mask) && !v4) return SH_EUNSUPPORTED;
+    if (v4) bn_act_kernel<4><<<rows_grid(M, C / 4), 256, 0, (hipStream_t)stream>>>(y, ldy, scale, shift, residual, ldr, out, ldo, M, C, relu, res_scale, res_shift, act_flags, relu_mask);
+    else bn_act_kernel<1><<<rows_grid(M, C), 256, 0, (hipStream_t)stream>>>(y, ldy, scale, shift, residual, ldr, out, ldo, M, C, relu, res_scale, res_shift, 0, nullptr);
     return sh_launch_status();
 }
 
@@ -719,6 +725,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                 const f32x4 o = yv * ld4(scale + c) + ld4(shift + c);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) if (!(o[j] > 0.f)) g[j] = 0.f;
+            } else if (relu == 3) {
+                const f32x4 o = quad_mask_load(out, m * ldo + (c >> 2));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (!(o[j] > 0.f)) g[j] = 0.f;
             }
             const f32x4 is = ld4(invstd + c);
             const f32x4 xh = (yv - ld4(mean + c)) * is;
@@ -744,12 +754,12 @@ extern "C" int sh_bn_bwd_apply(const float* dout, int lddo, const float* out, in
                                const float* c1, const float* c2, float* dy, int lddy, float* dres, int lddres, int64_t M, int C, int relu,
                                int act_flags, void* stream) {
     if (!dout || !y || !mean || !invstd || !c1 || !c2 || !dy || M <= 0 || C <= 0 || lddo < C || ldy < C || lddy < C) return SH_EINVAL;
-    if (relu < 0 || relu > 2 || (relu == 1 && (!out || ldo < C)) || (relu == 2 && (!scale || !shift))) return SH_EINVAL;
+    if (relu < 0 || relu > 3 || (relu == 1 && (!out || ldo < C)) || (relu == 2 && (!scale || !shift)) || (relu == 3 && (!out || ldo * 4 < C))) return SH_EINVAL;
     if (dres && lddres < C) return SH_EINVAL;
     const bool v4 = vec4_ok(C, lddo, ldy, lddy, relu == 1 ? ldo : 0, dres ? lddres : 0) && ptr16(dout) && ptr16(y) && ptr16(dy) &&
                     ptr16(mean) && ptr16(invstd) && ptr16(c1) && ptr16(c2) && (!gamma || ptr16(gamma)) && (relu != 1 || ptr16(out)) &&
                     (relu != 2 || (ptr16(scale) && ptr16(shift))) && (!dres || ptr16(dres));
-    if (act_flags && !v4) return SH_EUNSUPPORTED;
+    if ((act_flags || relu == 3) && !v4) return SH_EUNSUPPORTED;
     if (v4) bn_bwd_apply_kernel<4><<<rows_grid(M, C / 4), 256, 0, (hipStream_t)stream>>>(dout, lddo, out, ldo, y, ldy, mean, invstd, scale, shift, gamma, c1, c2, dy, lddy, dres, lddres, M, C, relu, act_flags);
     else bn_bwd_apply_kernel<1><<<rows_grid(M, C), 256, 0, (hipStream_t)stream>>>(dout, lddo, out, ldo, y, ldy, mean, invstd, scale, shift, gamma, c1, c2, dy, lddy, dres, lddres, M, C, relu, 0);
     return sh_launch_status();

@@ -57,6 +57,15 @@ __device__ __forceinline__ f32x4 lda4(const float* base, long long idx, int bf) 
     if (bf) return bf16x4_to_f32(*reinterpret_cast<const sh_u32x2*>(reinterpret_cast<const unsigned short*>(base) + idx));
     return ld4(base + idx);
 }
+// ReLU quad mask: one byte per (pixel, 4 adjacent channels), bit j = (out[c + j] > 0); pixel stride in BYTES (>= C / 4).  Written by
+// sh_bn_act next to a residual block's output and read by the backward passes that need only the mask of that output (1/16 of its bytes).
+__device__ __forceinline__ unsigned quad_mask_bits(f32x4 v) {
+    return (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
+}
+__device__ __forceinline__ f32x4 quad_mask_load(const void* base, long long byte_idx) {     // -> 1.f / 0.f per channel
+    const unsigned b = reinterpret_cast<const unsigned char*>(base)[byte_idx];
+    return f32x4{(b & 1u) ? 1.f : 0.f, (b & 2u) ? 1.f : 0.f, (b & 4u) ? 1.f : 0.f, (b & 8u) ? 1.f : 0.f};
+}
 __device__ __forceinline__ void sta4(float* base, long long idx, f32x4 v, int bf) {
     if (bf) *reinterpret_cast<sh_u32x2*>(reinterpret_cast<unsigned short*>(base) + idx) = f32_to_bf16x4(v);
     else st4(base + idx, v);

@@ -825,7 +825,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                 const f32x4 yv = lda4(bnb.y, m * bnb.ldy + n, bnb.act & 4);
                 if (bnb.relu) {
                     // the forward's own arithmetic (bn_act_kernel), or the stored block output where a residual was added
-                    const f32x4 a = bnb.out != nullptr ? lda4(bnb.out, m * bnb.ldo + n, bnb.act & 8) : yv * b_sc + b_sh;
+                    const f32x4 a = bnb.out == nullptr ? yv * b_sc + b_sh
+                                    : ((bnb.act & 64) ? quad_mask_load(bnb.out, m * bnb.ldo + (n >> 2)) : lda4(bnb.out, m * bnb.ldo + n, bnb.act & 8));
 #pragma unroll
                     for (int j = 0; j < 4; ++j) if (!(a[j] > 0.f)) o[j] = 0.f;
                 }
@@ -1139,19 +1140,22 @@ extern "C" int sh_conv_dgrad_x6_bnb(const float* dy, int lddy, const float* wt, 
                                     int KH, int KW, int stride, int pad, int dil, float* workspace, int64_t workspace_bytes, int act_flags,
                                     void* stream) {
     ConvQ p{};
-    if (act_flags & ~3) return SH_EINVAL;
-    p.act = ((act_flags & 1) ? 4 : 0) | ((act_flags & 2) ? 8 : 0);          // bit 0: y_prev, bit 1: out_prev stored as bf16
+    if ((act_flags & ~7) || (act_flags & 6) == 6) return SH_EINVAL;
+    // bit 0: y_prev, bit 1: out_prev stored as bf16; bit 2: out_prev is the ReLU quad mask sh_bn_act wrote (ldop = bytes per pixel >= Cin / 4)
+    p.act = ((act_flags & 1) ? 4 : 0) | ((act_flags & 2) ? 8 : 0) | ((act_flags & 4) ? 64 : 0);
+    const bool qmask = (act_flags & 4) != 0;
     if (!dy || !wt || !g || !y_prev || !mean || !invstd || !scale || !shift || !stat_partials ||
         !geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil)) return SH_EINVAL;
     const int CoutP = (Cout + 3) & ~3;
-    if (lddy < CoutP || (lddy & 3) || ldg < Cin || ldyp < Cin || (addend && ldadd < Cin) || (out_prev && ldop < Cin)) return SH_EINVAL;
+    if (lddy < CoutP || (lddy & 3) || ldg < Cin || ldyp < Cin || (addend && ldadd < Cin) || (out_prev && (qmask ? ldop * 4 : ldop) < Cin) ||
+        (qmask && (!out_prev || (Cin & 3)))) return SH_EINVAL;
     if (stride != 1) return SH_EUNSUPPORTED;
     p.a = dy; p.b = wt; p.c = g; p.extra = addend; p.ldadd = ldadd; p.lda = lddy; p.ldc = ldg;
     p.Nn = Cin; p.Kc = CoutP; p.K = KH * KW * CoutP; p.M = N * H * W;
     p.partials = stat_partials; p.n_partials = (int)sh_cdiv(p.M, 64);
     p.bnb_y = y_prev; p.bnb_ldy = ldyp; p.bnb_mean = mean; p.bnb_invstd = invstd; p.bnb_scale = scale; p.bnb_shift = shift; p.bnb_relu = relu;
     p.bnb_out = out_prev; p.bnb_ldo = ldop;
-    if (out_prev && ((ldop & 3) || ((uintptr_t)out_prev & 15))) return SH_EUNSUPPORTED;
+    if (out_prev && !qmask && ((ldop & 3) || ((uintptr_t)out_prev & 15))) return SH_EUNSUPPORTED;
     const bool al = ((ldg | ldyp) & 3) == 0 && (((uintptr_t)g | (uintptr_t)y_prev | (uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)scale |
                                                  (uintptr_t)shift) & 15) == 0 && (!addend || ((ldadd & 3) == 0 && ((uintptr_t)addend & 15) == 0));
     if (al) use_splitk(p, workspace, workspace_bytes);

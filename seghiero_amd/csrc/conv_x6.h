@@ -54,6 +54,7 @@ struct ConvQ {
     // ---- bf16 activation storage (common.h): bit 0 the fprop input x, 1 the fprop output y, 2 bnb_y, 3 bnb_out, 4 the lin y stream (a2),
     // 5 the wgrad X operand are stored as bf16 (pixel strides count elements).  Loads inside a scheduled conv phase are selected by a
     // template parameter (ABF / XBF), epilogue accesses by this mask at run time.
+    // bit 6 (64): bnb_out is the ReLU quad mask written by sh_bn_act (common.h; bnb_ldo = bytes per pixel), not the output tensor.
     int act;
     int vec_epi;            // output / addend / bnb_y rows are 16-byte addressable: row-major float4 epilogue through LDS
     unsigned a_bytes, b_bytes;  // extents of the A / B operands for the buffer descriptors (bytes, < 2^31)

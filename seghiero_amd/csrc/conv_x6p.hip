@@ -424,7 +424,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
                         if (p.extra != nullptr) ad[kk] = ld4(p.extra + mrow[kk] * p.ldadd + ncv);
                         if constexpr (EPI == 2) {
                             yv[kk] = lda4(p.bnb_y, mrow[kk] * p.bnb_ldy + ncv, p.act & 4);
-                            if (p.bnb_out != nullptr) ov[kk] = lda4(p.bnb_out, mrow[kk] * p.bnb_ldo + ncv, p.act & 8);
+                            if (p.bnb_out != nullptr)
+                                ov[kk] = (p.act & 64) ? quad_mask_load(p.bnb_out, mrow[kk] * p.bnb_ldo + (ncv >> 2)) : lda4(p.bnb_out, mrow[kk] * p.bnb_ldo + ncv, p.act & 8);
                         }
                     }
                 }
@@ -658,7 +659,7 @@ int sh_x6p_launch(int mode, ConvQ& p, hipStream_t st) {
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     p.vec_epi = !p.parity && !p.scatter && (p.Nn & 3) == 0 && (p.ldc & 3) == 0 && al16(p.c) &&
                 (p.extra == nullptr || (al16(p.extra) && (mode == FPROP || (p.ldadd & 3) == 0))) &&
-                (!bnb || ((p.bnb_ldy & 3) == 0 && al16(p.bnb_y) && (p.bnb_out == nullptr || ((p.bnb_ldo & 3) == 0 && al16(p.bnb_out))) && al16(p.bnb_mean) && al16(p.bnb_invstd) && al16(p.bnb_scale) &&
+                (!bnb || ((p.bnb_ldy & 3) == 0 && al16(p.bnb_y) && (p.bnb_out == nullptr || (p.act & 64) || ((p.bnb_ldo & 3) == 0 && al16(p.bnb_out))) && al16(p.bnb_mean) && al16(p.bnb_invstd) && al16(p.bnb_scale) &&
                           al16(p.bnb_shift) && al16(p.partials)));
     if (bnb && !p.vec_epi) return SH_X6P_NO;
     { static int v = -2; if (v == -2) { const char* e = getenv("SEGHIERO_X6P_VEC"); v = e ? atoi(e) : 1; } if (!v && !bnb) p.vec_epi = 0; }

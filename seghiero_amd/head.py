@@ -127,7 +127,7 @@ def _aspp_branches_grouped(aspp, c4, cat, A, training, R):
         src, cf = sources[g]
         rec.x = src if cf is None else L.Lazy(src, cf)
         rec.y, rec.out, rec.coefs = ycat[:, g * A:(g + 1) * A], None, coefs_cat[:, g * A:(g + 1) * A]
-        rec.relu, rec.geom, rec.weight, rec.has_res = True, G1, weights[g], False
+        rec.relu, rec.geom, rec.weight, rec.has_res, rec.mask = True, G1, weights[g], False, None
         R["b0" if g == 0 else f"pw{g}"] = rec
     return True
 

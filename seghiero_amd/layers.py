@@ -98,7 +98,7 @@ def dense(x):
 
 # ----------------------------------------------------------------------------- conv + BN (+res) (+ReLU)
 class CBARec:
-    __slots__ = ("x", "y", "out", "coefs", "relu", "geom", "weight", "has_res")
+    __slots__ = ("x", "y", "out", "coefs", "relu", "geom", "weight", "has_res", "mask")      # mask: ReLU quad mask of `out` (ops.new_relu_mask) or None
 
 
 def _bn_coefs(bn, partials, count, training, c, device):
@@ -151,7 +151,8 @@ def _dgrad(rec_x, dy, weight, s, p, d, addend=None, pack_for=None):
     if pack_for is not None and FUSE_BN and not isinstance(rec_x, Lazy):
         g = ops.new_act(n, c, h, w, dev)
         partials = torch.empty((-(-n * h * w // 64), 2, c), device=dev, dtype=torch.float32)
-        if ops.conv_dgrad_bnb(dy, weight, g, pack_for.y, pack_for.coefs, True, partials, s, p, d, addend=addend, out_prev=pack_for.out):
+        if ops.conv_dgrad_bnb(dy, weight, g, pack_for.y, pack_for.coefs, True, partials, s, p, d, addend=addend,
+                              out_prev=pack_for.out if pack_for.mask is None else pack_for.mask):
             return GradPack(g, partials)
         ops.conv_dgrad(dy, weight, g, s, p, d, addend=addend)
         return g
@@ -177,6 +178,7 @@ def cba_fwd(x, weight, geom, bn, relu, training, residual=None, out=None, lazy=F
     ho, wo = ops.conv_out_hw(h, w, kh, kw, s, p, d)
     ld = ops.pad4(o)
     m = n * ho * wo
+    mask = None
     if not training and ops.FUSE_EVAL and ops.CONV_IMPL == "x6":
         # inference: eval-mode BN (+ residual) (+ ReLU) in the conv epilogue; y is never materialised
         coefs = _bn_coefs(bn, None, m, False, o, x.device)
@@ -196,14 +198,18 @@ def cba_fwd(x, weight, geom, bn, relu, training, residual=None, out=None, lazy=F
         else:
             if out is None:
                 out = ops.new_act(n, o, ho, wo, x.device, ld=ld, zero=ld != o, dtype=ops.stored_dtype())
+            # a residual block's output: its backward needs only the ReLU mask of `out` -- kept as a quad mask (1/16 of the bytes)
+            if training and relu and residual is not None and ops.RELU_MASK and FUSE_BN and o % 4 == 0 and ops.CONV_IMPL == "x6":
+                mask = ops.new_relu_mask(n, o, ho, wo, x.device)
             if isinstance(residual, LazyAffine):
-                ops.bn_act(y, coefs, out, relu, residual.y, res_coefs=residual.coefs)
+                ops.bn_act(y, coefs, out, relu, residual.y, res_coefs=residual.coefs, mask=mask)
             else:
-                ops.bn_act(y, coefs, out, relu, residual)
+                ops.bn_act(y, coefs, out, relu, residual, mask=mask)
     rec = CBARec()
     rec.x, rec.y, rec.coefs, rec.relu, rec.geom, rec.weight = x, y, coefs, relu, geom, weight
     rec.out = None if isinstance(out, (Lazy, LazyAffine)) else out
     rec.has_res = residual is not None
+    rec.mask = mask
     return out, rec
 
 
@@ -224,8 +230,8 @@ def cba_bwd(rec, bn, dout, need_dx=True, addend=None, want_dres=False, scatter_i
     mode = 0 if not rec.relu else (1 if rec.has_res else 2)
     # second half of the BatchNorm backward in the loaders of this conv's dgrad / wgrad (1x1 convs): no apply pass, no dy tensor
     defer = FUSE_BN and scatter_into is None and pack_for is None and ops.lin_ok(rec.x.shape, rec.weight, s, p, d)
-    dy, dgamma, dbeta, dres = ops.bn_backward(dout, rec.out if mode == 1 else None, rec.y, rec.coefs, bn.weight,
-                                              mode, want_dres, defer=defer)
+    dy, dgamma, dbeta, dres = ops.bn_backward(dout, (rec.out if rec.mask is None else rec.mask) if mode == 1 else None, rec.y, rec.coefs,
+                                              bn.weight, mode, want_dres, defer=defer)
     dw = new_grad(rec.weight)
     if not ops.WGRAD_AFTER_DGRAD:
         _wgrad(rec.x, dy, dw, s, p, d)

@@ -361,7 +361,10 @@ def conv_dgrad_bnb(dy, weight, g, y_prev, coefs, relu, partials, stride, pad, di
     if lddy < pad4(o):
         return False
     ap, lda = (None, 0) if addend is None else pm(addend)
-    opp, ldop, opb = (None, 0, 0) if out_prev is None else pmx(out_prev)
+    if out_prev is not None and out_prev.dtype == torch.uint8:      # ReLU quad mask of the previous block's output (new_relu_mask)
+        opp, ldop, opb = out_prev.data_ptr(), cin // 4, 2
+    else:
+        opp, ldop, opb = (None, 0, 0) if out_prev is None else pmx(out_prev)
     ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
     m = n * ho * wo
     cost = (2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin * (3 if addend is not None else 2) + m * o + o * cin * kh * kw))
@@ -743,15 +746,25 @@ def channel_stats(y):
     return partials
 
 
-def bn_act(y, coefs, out, relu, residual=None, res_coefs=None):
-    """res_coefs: `residual` is a raw conv output whose BatchNorm (no ReLU) is applied on the fly (the downsample branch)."""
+RELU_MASK = os.environ.get("SEGHIERO_RELU_MASK", "1") != "0"      # residual blocks keep a 1/16-size ReLU quad mask of their output for the backward
+
+
+def new_relu_mask(n, c, h, w, device):
+    """Buffer for sh_bn_act's ReLU quad mask of an [n, c, h, w] output: one byte per (pixel, 4 channels)."""
+    return torch.empty((n, h, w, c // 4), device=device, dtype=torch.uint8)
+
+
+def bn_act(y, coefs, out, relu, residual=None, res_coefs=None, mask=None):
+    """res_coefs: `residual` is a raw conv output whose BatchNorm (no ReLU) is applied on the fly (the downsample branch).
+    mask (new_relu_mask): also receives the ReLU quad mask of `out`."""
     n, c, h, w = y.shape
     yp, ldy, yb = pmx(y)
     op, ldo, ob = pmx(out)
     rp, ldr, rb = (None, 0, 0) if residual is None else pmx(residual)
     _call("sh_bn_act", yp, ldy, coefs[2].data_ptr(), coefs[3].data_ptr(), rp, ldr,
           None if res_coefs is None else res_coefs[2].data_ptr(), None if res_coefs is None else res_coefs[3].data_ptr(),
-          op, ldo, n * h * w, c, int(relu), yb | (rb << 1) | (ob << 2), _st(), key=f"{n}x{h}x{w} C{c}" + (" +res" if residual is not None else ""))
+          op, ldo, n * h * w, c, int(relu), None if mask is None else mask.data_ptr(), yb | (rb << 1) | (ob << 2), _st(),
+          key=f"{n}x{h}x{w} C{c}" + (" +res" if residual is not None else ""))
 
 
 class DeferredDy:
@@ -814,7 +827,12 @@ def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None, d
     m = n * h * w
     dev = y.device
     yp, ldy, yb = pmx(y)
-    op, ldo, ob = (None, 0, 0) if out is None else pmx(out)
+    if out is not None and out.dtype == torch.uint8:          # the ReLU quad mask of the output (new_relu_mask) instead of the output
+        if relu != 1:
+            raise SegHieroHipError("a ReLU quad mask stands in for `out` in mode 1 only")
+        op, ldo, ob, relu = out.data_ptr(), c // 4, 0, 3
+    else:
+        op, ldo, ob = (None, 0, 0) if out is None else pmx(out)
     af = yb | (ob << 1)
     packed = hasattr(dout, "partials")
     if packed:
@@ -977,7 +995,7 @@ def dense_copy(t, ld=None):
     ones[1].zero_()
     tp, ldt = pm(t)
     op, ldo = pm(out)
-    _call("sh_bn_act", tp, ldt, ones[0].data_ptr(), ones[1].data_ptr(), None, 0, None, None, op, ldo, n * h * w, c, 0, 0, _st())
+    _call("sh_bn_act", tp, ldt, ones[0].data_ptr(), ones[1].data_ptr(), None, 0, None, None, op, ldo, n * h * w, c, 0, None, 0, _st())
     return out
 
 

@@ -182,6 +182,14 @@ def test_conv_fused_batchnorm_hooks(ops, case):
     sums = bpart.double().sum(0).cpu()
     np.testing.assert_allclose(sums[1].numpy(), (gk * xhat).sum((0, 2, 3)).numpy(), rtol=1e-5,
                                atol=1e-5 * float((gk * xhat).abs().sum((0, 2, 3)).max()))
+    if cin % 4 == 0:
+        # ... or from that output's ReLU quad mask (one byte per pixel and 4 channels, written by sh_bn_act): bit-identical
+        qm = torch.zeros((n, h, w, cin // 4), dtype=torch.uint8)
+        bits = (outp > 0).permute(0, 2, 3, 1).reshape(n, h, w, cin // 4, 4).to(torch.uint8)
+        qm = (bits[..., 0] | (bits[..., 1] << 1) | (bits[..., 2] << 2) | (bits[..., 3] << 3)).contiguous().to(DEV)
+        gb4, bpart4 = ops.new_act(n, cin, h, w, DEV), torch.empty_like(bpart)
+        assert ops.conv_dgrad_bnb(dyg, wg, gb4, rawg, coefs, True, bpart4, 1, p, d, out_prev=qm)
+        assert torch.equal(gb4, gb3) and torch.equal(bpart4, bpart)
 
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 128), (1, 24, 16, 96, 64), (2, 32, 32, 256, 64), (1, 16, 48, 128, 512), (4, 16, 16, 2048, 512)])
@@ -443,6 +451,27 @@ def test_batchnorm_fold_partials_before_finalize(ops, c, m, rows, monkeypatch):
     close(r1[1], ref[0].float(), 0, 2e-6 * scale, "dbeta vs f64")
     close(r1[0], ref[1].float(), 0, 2e-6 * scale, "dgamma vs f64")
     close(r1, r0, 0, 2e-6 * scale, "folded vs one-stage backward sums")
+
+
+def test_relu_quad_mask_stands_in_for_the_block_output(ops):
+    """sh_bn_act's relu_mask output is bit j = (out[c + j] > 0) per (pixel, channel quad), and the BatchNorm backward fed the mask
+    (relu = 3) is bit-identical to the one fed the output itself (relu = 1): statistics pass, its stored masked gradient, apply pass."""
+    n, c, h, w = 3, 40, 9, 7
+    g = torch.Generator().manual_seed(11)
+    y, res, dout = nhwc(torch.randn(n, c, h, w, generator=g)), nhwc(torch.randn(n, c, h, w, generator=g)), nhwc(torch.randn(n, c, h, w, generator=g))
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).to(DEV), torch.randn(c, generator=g).to(DEV)
+    rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    coefs = ops.bn_finalize(ops.channel_stats(y), n * h * w, gamma, beta, 1e-5, 0.1, rm, rv, c, DEV, rows=256)
+    out, mask = ops.new_act(n, c, h, w, DEV), ops.new_relu_mask(n, c, h, w, DEV)
+    ops.bn_act(y, coefs, out, True, res, mask=mask)
+    bits = (out > 0).permute(0, 2, 3, 1).reshape(n, h, w, c // 4, 4).to(torch.uint8)
+    assert torch.equal(mask, bits[..., 0] | (bits[..., 1] << 1) | (bits[..., 2] << 2) | (bits[..., 3] << 3))
+    for defer in (False, True):
+        a = ops.bn_backward(dout, out, y, coefs, gamma, 1, want_dres=True, defer=defer)
+        b = ops.bn_backward(dout, mask, y, coefs, gamma, 1, want_dres=True, defer=defer)
+        da = a[0].materialize() if hasattr(a[0], "materialize") else a[0]
+        db = b[0].materialize() if hasattr(b[0], "materialize") else b[0]
+        assert torch.equal(da, db) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
 
 
 def test_bn_eval_coefs(ops):
