@@ -107,6 +107,21 @@ __device__ __forceinline__ f32x16 mma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3
 }
 
 
+// three-product accumulate: one operand is an exact bf16 value (its mid / lo planes are zero)
+__device__ __forceinline__ f32x16 mma3(const bf16x8 a0, const bf16x8 (&b)[3], f32x16 c) {
+    c = mfma_bf16(a0, b[2], c);        // smallest terms first
+    c = mfma_bf16(a0, b[1], c);
+    c = mfma_bf16(a0, b[0], c);
+    return c;
+}
+
+__device__ __forceinline__ f32x16 mma3b(const bf16x8 (&a)[3], const bf16x8 b0, f32x16 c) {
+    c = mfma_bf16(a[2], b0, c);
+    c = mfma_bf16(a[1], b0, c);
+    c = mfma_bf16(a[0], b0, c);
+    return c;
+}
+
 // conv_x6p.hip: software-pipelined fprop / dgrad with the fused BatchNorm hooks; SH_X6P_NO = shape not handled (fall back)
 #define SH_X6P_NO (-100)
 int sh_x6p_launch(int mode, ConvQ& p, hipStream_t st);

@@ -81,6 +81,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
     static_assert(AFF != 2 || (MODE == DGRAD && TAP == 0 && !GRP), "the deferred BatchNorm-backward loader exists for 1x1 dgrads");
     static_assert(!ABF || (MODE == FPROP && !GRP) || AFF == 2, "bf16 loader streams: the fprop input, or the y stream of the lin loader");
     constexpr bool A_BF = ABF && MODE == FPROP, A2_BF = ABF && AFF == 2;
+    // A3: the A operand is a STORED bf16 tensor read as is (no activation in the loader): x = x_hi exactly, its mid / lo planes are zero,
+    // so three of the six products vanish -- half the MFMA work and no split of A (the conv1 / downsample convs of a bf16-stored trunk)
+    constexpr bool A3 = A_BF && AFF == 0;
     auto load_a4 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned elem_off, unsigned ok, bool bf) -> f32x4 {
         // 4 consecutive elements: fp32 -> one 16-byte load; bf16 -> one 8-byte load parked in the first two lanes of the f32x4 (widened
         // by widen_a4 when the half-tile is stored); offsets beyond the buffer (masked rows / taps / K tail) read as zeros
@@ -239,6 +242,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
         if constexpr (AFF == 2) { lmu = *reinterpret_cast<const f32x4*>(coef + 2 * p.Kc + R.cc); ld_ = *reinterpret_cast<const f32x4*>(coef + 3 * p.Kc + R.cc); }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
+            if constexpr (A3) {          // the 8 loaded bytes ARE the hi plane's four elements (same element order as split4's packing)
+                *reinterpret_cast<u32x2*>(As + off0 + RPP * i * ROWB) = u32x2{__float_as_uint(R.a[i][0]), __float_as_uint(R.a[i][1])};
+                continue;
+            }
             f32x4 v = widen_a4(R.a[i], A_BF);
             if constexpr (AFF == 2) {
                 // dy = A*g + B*(y - mean) + D (sc = A, sh = B): rows beyond M / the K tail must stay exact zeros (D != 0)
@@ -295,12 +302,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
                 bfr[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + pl * B_PLANE + (brow + 32 * j) * ROWB + rd));
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            if constexpr (A3) {
+                const bf16x8 a0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + (arow + 32 * i) * ROWB + rd));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mma3(a0, bfr[j], acc[i][j]);
+            } else {
             bf16x8 af[3];
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
                 af[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + pl * A_PLANE + (arow + 32 * i) * ROWB + rd));
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = mma6(af, bfr[j], acc[i][j]);
+            }
         }
     };
 
@@ -308,16 +321,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
     // first, then every MFMA carries a few VALU instructions of the split in its issue shadow; the LDS stores, the global loads
     // and the remaining A-fragment reads are spread over the MFMA stream.
     auto phase_schedule = [&]() {
-        constexpr int NMFMA = TM * TN * 6, NVALU = 30 * (NA + NB) + (AFF == 2 ? 16 : 8 * AFF) * NA, NDSW = 3 * (NA + NB), NVM = NA + NB + (AFF == 2 ? NA : 0);
+        constexpr int PA = A3 ? 1 : 3, PP = A3 ? 3 : 6;                          // A planes, products per 32 x 32 x 16 tile
+        constexpr int NMFMA = TM * TN * PP, NVALU = 30 * ((A3 ? 0 : NA) + NB) + (AFF == 2 ? 16 : 8 * AFF) * NA, NDSW = PA * NA + 3 * NB,
+                      NVM = NA + NB + (AFF == 2 ? NA : 0);
         constexpr int VPM = (NVALU + NMFMA - 1) / NMFMA;
-        __builtin_amdgcn_sched_group_barrier(0x100, 3 * TN + 3, 0);             // DS read: B fragments + A fragment 0
+        __builtin_amdgcn_sched_group_barrier(0x100, 3 * TN + PA, 0);            // DS read: B fragments + A fragment 0
 #pragma unroll
         for (int g = 0; g < NMFMA; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // 1 MFMA
             __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);                // VALU of the split
             if (g * NDSW / NMFMA != (g + 1) * NDSW / NMFMA) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // DS write
             if (g * NVM / NMFMA != (g + 1) * NVM / NMFMA) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // VMEM read
-            if (g % (6 * TN) == 2 && g / (6 * TN) + 1 < TM) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);      // next A fragment
+            if (g % (PP * TN) == 2 && g / (PP * TN) + 1 < TM) __builtin_amdgcn_sched_group_barrier(0x100, PA, 0);   // next A fragment
         }
     };
     // ------------------------------------------------------------------ prologue
@@ -699,6 +714,7 @@ int sh_x6p_launch_dgrad(ConvQ& p, hipStream_t st, int force) {
 template <int WGM, int WGN, int AFF, int LIN = 0, int XBF = 0>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_x6p_kernel(const ConvQ p) {
     constexpr int NT = 64 * WGM * WGN, BM = 64 * WGM, BN = 64 * WGN;
+    constexpr bool X3 = XBF && AFF == 0;          // X is a stored bf16 tensor read as is: three products (see conv_x6p_kernel's A3)
     constexpr int AROWB = 2 * BM + 64, BROWB = 2 * BN + 64;
     constexpr int APLANE = 32 * AROWB, BPLANE = 32 * BROWB;
     constexpr int ACPR = BM / 4, BCPR = BN / 4;              // float4 chunks per k-row
@@ -803,6 +819,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_x6p_kernel(const
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
+            if constexpr (X3) {          // stored bf16 X read as is: the 8 loaded bytes are the hi plane's four elements, mid / lo planes are zero
+                *reinterpret_cast<u32x2*>(Bs + (16 * hb + bk0 + BKPP * i) * BROWB + brc * 8) = u32x2{__float_as_uint(R.b[i][0]), __float_as_uint(R.b[i][1])};
+                continue;
+            }
             f32x4 v = wg_widen(R.b[i], XBF);
             if constexpr (AFF) {
                 const bool ok = (R.okm >> i) & 1u;
@@ -836,30 +856,34 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_x6p_kernel(const
         return __builtin_bit_cast(bf16x8, r);
     };
     auto compute_half = [&](int hb) {
-        bf16x8 af[2][3], bfr[2][3];
+        bf16x8 af[2][3], bfr[2][X3 ? 1 : 3];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
                 af[i][pl] = frag(As + pl * APLANE, AROWB, hb, wm * 64 + 32 * i);
-                bfr[i][pl] = frag(Bs + pl * BPLANE, BROWB, hb, wn * 64 + 32 * i);
+                if (!X3 || pl == 0) bfr[i][X3 ? 0 : pl] = frag(Bs + pl * BPLANE, BROWB, hb, wn * 64 + 32 * i);
             }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = mma6(af[i], bfr[j], acc[i][j]);
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (X3) acc[i][j] = mma3b(af[i], bfr[j][0], acc[i][j]);
+                else acc[i][j] = mma6(af[i], bfr[j], acc[i][j]);
+            }
     };
     auto phase_schedule = [&]() {
-        constexpr int NVALU = (30 + 8 * AFF) * NB + (30 + 16 * LIN) * NA + 8 * NB, NDSW = 3 * (NA + NB), NVM = NA + NB + LIN * NA;
-        constexpr int VPM = (NVALU + 23) / 24;
-        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);                     // DS read: first A / B fragment pairs
+        constexpr int NMF = X3 ? 12 : 24, NDSR = X3 ? 8 : 12;                   // MFMAs per phase; fragment reads per batch (two batches)
+        constexpr int NVALU = (X3 ? 2 : 30 + 8 * AFF) * NB + (30 + 16 * LIN) * NA + 8 * NB, NDSW = 3 * NA + (X3 ? 1 : 3) * NB, NVM = NA + NB + LIN * NA;
+        constexpr int VPM = (NVALU + NMF - 1) / NMF;
+        __builtin_amdgcn_sched_group_barrier(0x100, NDSR, 0);                   // DS read: first A / B fragment pairs
 #pragma unroll
-        for (int gq = 0; gq < 24; ++gq) {
+        for (int gq = 0; gq < NMF; ++gq) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // 1 MFMA
             __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);                // VALU of the split / addressing
-            if (gq * NDSW / 24 != (gq + 1) * NDSW / 24) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // DS write
-            if (gq * NVM / 24 != (gq + 1) * NVM / 24) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // VMEM read
-            if (gq == 2) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);    // remaining fragment reads
+            if (gq * NDSW / NMF != (gq + 1) * NDSW / NMF) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // DS write
+            if (gq * NVM / NMF != (gq + 1) * NVM / NMF) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // VMEM read
+            if (gq == 2) __builtin_amdgcn_sched_group_barrier(0x100, NDSR, 0);  // remaining fragment reads
         }
     };
     Regs R0, R1;

@@ -251,6 +251,30 @@ def test_conv1x1_deferred_batchnorm_backward_apply(ops, case, mode, monkeypatch)
     close(dw, dw_ref, 0, 3e-6 * float(dw_ref.abs().max()) * (n * h * w) ** 0.5 / 16, "wgrad, both operands through their BatchNorms")
 
 
+@pytest.mark.parametrize("case", [(2, 32, 32, 256, 64, 1, 1, 0, 1), (2, 32, 32, 64, 128, 3, 1, 1, 1), (2, 32, 32, 560, 512, 1, 1, 0, 1),
+                                  (1, 64, 64, 128, 256, 1, 2, 0, 1), (2, 16, 16, 256, 256, 3, 1, 2, 2)])
+def test_conv_bf16_stored_input_three_product_plan(ops, case):
+    """A conv whose input is a STORED bf16 tensor read as is (the conv1 / downsample convs of a bf16-stored trunk) runs three MFMA
+    products per tile instead of six (the operand's mid / lo planes are zero): output, BatchNorm statistics partials and the weight
+    gradient are BIT-identical to the six-product kernels on the same values held as fp32."""
+    n, h, w, cin, cout, k, stride, pad, dil = case
+    g = torch.Generator().manual_seed(cin + k)
+    xb = nhwc(torch.randn(n, cin, h, w, generator=g)).to(torch.bfloat16)
+    xf = xb.float()
+    wt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(DEV).contiguous(memory_format=torch.channels_last)
+    ho, wo = ops.conv_out_hw(h, w, k, k, stride, pad, dil)
+    ya, yb_ = ops.new_act(n, cout, ho, wo, DEV), ops.new_act(n, cout, ho, wo, DEV)
+    pa, pb = ops.conv_partials(n * ho * wo, cout, DEV), ops.conv_partials(n * ho * wo, cout, DEV)
+    ops.conv_fprop(xf, wt, None, ya, pa, stride, pad, dil)
+    ops.conv_fprop(xb, wt, None, yb_, pb, stride, pad, dil)
+    assert torch.equal(ya, yb_) and torch.equal(pa, pb)
+    dy = nhwc(torch.randn(n, cout, ho, wo, generator=g))
+    dwa, dwb = torch.empty_like(wt), torch.empty_like(wt)
+    ops.conv_wgrad(xf, dy, dwa, stride, pad, dil)
+    ops.conv_wgrad(xb, dy, dwb, stride, pad, dil)
+    assert torch.equal(dwa, dwb)
+
+
 def test_conv_reads_and_writes_channel_slices(ops):
     g = torch.Generator().manual_seed(5)
     big_in = nhwc(torch.randn(2, 96, 10, 10, generator=g))
