@@ -1204,6 +1204,9 @@ static WgX6Plan wgrad_plan_x6(int Cout, long long Nn, long long npix) {
     // measured (tools/bench_conv.py): 128x256 helps the narrow-Cout shapes, 256x256 on 1024 threads does not help wgrad
     g.wgm = Cout <= 64 ? 1 : 2;
     g.wgn = (Nn >= 256 && Cout <= 128) ? 4 : 2;
+    // the stem (Cout 64, 7 x 7 x 4 = 196 columns): one 64 x 256 tile on 4 waves instead of two 64 x 128 tiles on 2 -- with 512 blocks the
+    // 2-wave blocks left every SIMD with ONE wave (381 us); padding 60 columns costs less than that
+    if (Cout <= 64 && Nn > 128 && Nn < 256) g.wgn = 4;
     if (Nn <= 64 && Cout >= 128) { g.wgn = 1; g.wgm = Cout >= 256 ? 4 : 2; }      // layer1's 64-channel inputs: 64-wide N tile
     const long long tiles = sh_cdiv(Cout, 64 * g.wgm) * sh_cdiv(Nn, 64 * g.wgn);
     // K slices: the grid should be a whole number of "rounds" of 512 resident blocks (2 per CU) -- measured
@@ -1212,7 +1215,15 @@ static WgX6Plan wgrad_plan_x6(int Cout, long long Nn, long long npix) {
     //   cost(r) = r * (npix / s_r) * t_pixel + s_r * dW_bytes * 2 / HBM,   s_r = floor(512 r / tiles)
     const long long maxs = sh_cdiv(npix, 256);
     const double t_pixel = 2.0 * (64 * g.wgm) * (64 * g.wgn) / 0.29e12, dwb = 4.0 * Cout * (double)Nn;
-    const long long slots = 512;             // 2 resident blocks per CU for every tile shape used here
+    // resident blocks per CU: the kernels are bounded to 2 waves per SIMD (8 waves per CU) and their [k][row] planes take
+    // 96 * ((128 wgm + 64) + (128 wgn + 64)) bytes of the 160 KB LDS -- 2 for the 256-thread tiles, 1 for 128 x 256 on 512 threads
+    const long long lds_b = 96ll * ((128 * g.wgm + 64) + (128 * g.wgn + 64));
+    long long bpc = 8 / (g.wgm * g.wgn);
+    if (bpc > 160 * 1024 / lds_b) bpc = 160 * 1024 / lds_b;
+    if (bpc < 1) bpc = 1;
+    static int slot_fix = -1;
+    if (slot_fix < 0) { const char* e = getenv("SEGHIERO_WG_SLOTS"); slot_fix = e ? atoi(e) : 0; }
+    const long long slots = slot_fix > 0 ? slot_fix : 256 * bpc;
     static int xcd_tiles = -1;
     if (xcd_tiles < 0) { const char* e = getenv("SEGHIERO_WG_XCD_TILES"); xcd_tiles = e ? atoi(e) : 32; }
     // few tiles per slice: one slice per XCD (see the kernel), slices in multiples of 8, slots/8 resident blocks per XCD
