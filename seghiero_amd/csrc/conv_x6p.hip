@@ -609,6 +609,8 @@ static int launch_x6p(ConvQ& p, hipStream_t st) {
     p.tiles_m = (int)sh_cdiv(p.M, BM);
     p.tiles_n = (int)sh_cdiv(p.Nn, BN);
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), p.parity ? 4u : (SK ? (unsigned)p.ksplit : 1u));
+    // (Wave quantisation -- 1024 or 2048 blocks on 768 resident slots -- was tried against TWO blocks per CU, enforced by a larger dynamic-LDS
+    // request, so that those grids run 2 or 4 full rounds: slower for every grid-size threshold, step 31.15 -> 31.16 / 31.3 / 31.4 ms.)
     conv_x6p_kernel<MODE, TM, TN, WGM, WGN, WPS, AFF, EPI, SK, TAP, GRP, ABF><<<grid, 64 * WGM * WGN, lds, st>>>(p);
     return sh_launch_status();
 }
