@@ -42,7 +42,25 @@ for fam, d in out.items():
     rd, wr = 2.0 * d["fetch_kib"] * 1024, d["write_kib"] * 1024
     res[fam] = dict(launches_per_step=round(d["launches"], 1), hbm_read_bytes_per_step=rd, hbm_write_bytes_per_step=wr,
                     hbm_bytes_per_launch=(rd + wr) / max(d["launches"], 1e-9))
+# achieved HBM rate per family: PMC bytes per step / kernel time per step from the trace pass (its stats file covers TRACE_STEPS steps:
+# 2 warm-up + 4 timed + 2 instrumented); 8 TB/s is the guide's HBM peak, ~6.3 TB/s what a plain streaming kernel reaches
+TRACE_STEPS = 8.0
+ms = collections.defaultdict(float)
+for r in csv.DictReader(open(stats)):
+    ms[family(r["Name"])] += float(r["TotalDurationNs"]) / TRACE_STEPS / 1e6
+for fam, d in res.items():
+    t = ms.get(fam, 0.0)
+    d["ms_per_step"] = round(t, 4)
+    d["achieved_TBps"] = round((d["hbm_read_bytes_per_step"] + d["hbm_write_bytes_per_step"]) / (t * 1e-3) / 1e12, 3) if t > 0 else None
 top = dict(sorted(res.items(), key=lambda kv: -(kv[1]["hbm_read_bytes_per_step"] + kv[1]["hbm_write_bytes_per_step"]))[:25])
+with open(f"profiles/{tag}_hbm_rates.txt", "w") as fh:
+    fh.write("# HBM bytes per step (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE) / kernel time per step (rocprofv3 --kernel-trace --stats), by kernel family\n")
+    fh.write("# peak 8.0 TB/s (MI355X_MICROARCH.md); the MFMA-bound conv families are listed for their traffic, not as a bandwidth claim\n")
+    fh.write(f"{'family':34s} {'launches':>8s} {'ms/step':>8s} {'GB/step':>8s} {'TB/s':>6s} {'of 8 TB/s':>9s}\n")
+    for fam, d in top.items():
+        gb = (d["hbm_read_bytes_per_step"] + d["hbm_write_bytes_per_step"]) / 1e9
+        r = d["achieved_TBps"]
+        fh.write(f"{fam[:34]:34s} {d['launches_per_step']:8.1f} {d['ms_per_step']:8.3f} {gb:8.2f} {(r if r is not None else 0):6.2f} {(r / 8.0 if r else 0):9.2f}\n")
 import hashlib
 import os
 _h = hashlib.sha1()
