@@ -863,18 +863,34 @@ __global__ __launch_bounds__(256) void trip_class_kernel(const float* __restrict
     int m = min(min(cnt[0], cnt[1]), min(cnt[2], max_triplet));
     if (m == 0) { if (t == 0) { rec[0] = 0; W.closs[cls] = 0.f; } return; }
     float part = 0.f;
-    for (int j = wv; j < m; j += 4) {
-        const float* a = emb + (long long)idx[0][j] * D;
-        const float* p = emb + (long long)idx[1][j] * D;
-        const float* n = emb + (long long)idx[2][j] * D;
-        float dap = 0.f, dan = 0.f;
-        for (int d = lane; d < D; d += 64) { const float av = a[d]; dap += av * p[d]; dan += av * n[d]; }
-        dap = wave_sum(dap); dan = wave_sum(dan);
-        const float tl = (1.f - dap) - (1.f - dan) + margin;
-        if (lane == 0) {
-            rec[4 + j] = idx[0][j]; rec[4 + TRIP_MAX + j] = idx[1][j]; rec[4 + 2 * TRIP_MAX + j] = idx[2][j];
-            rec[4 + 3 * TRIP_MAX + j] = tl > 0.f ? 1 : 0;
-            part += tl > 0.f ? tl : 0.f;
+    // a wave takes triplets wv, wv + 4, ...; FOUR of them per pass with all twelve row loads of a 64-column slice issued before the first
+    // use (indices clamped instead of branched, so nothing separates the loads): the embedding rows are cold in this XCD's L2 and one
+    // triplet at a time paid three dependent misses per slice.  Per-triplet sums and the per-wave accumulation order are unchanged.
+    for (int j0 = wv; j0 < m; j0 += 16) {
+        const float* a[4]; const float* p[4]; const float* n[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = min(j0 + 4 * u, m - 1);
+            a[u] = emb + (long long)idx[0][j] * D; p[u] = emb + (long long)idx[1][j] * D; n[u] = emb + (long long)idx[2][j] * D;
+        }
+        float dap[4] = {0.f, 0.f, 0.f, 0.f}, dan[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int d = lane; d < D; d += 64) {
+            float av[4], pv[4], nv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { av[u] = a[u][d]; pv[u] = p[u][d]; nv[u] = n[u][d]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { dap[u] += av[u] * pv[u]; dan[u] += av[u] * nv[u]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 4 * u;
+            const float sp = wave_sum(dap[u]), sn = wave_sum(dan[u]);
+            const float tl = (1.f - sp) - (1.f - sn) + margin;
+            if (lane == 0 && j < m) {
+                rec[4 + j] = idx[0][j]; rec[4 + TRIP_MAX + j] = idx[1][j]; rec[4 + 2 * TRIP_MAX + j] = idx[2][j];
+                rec[4 + 3 * TRIP_MAX + j] = tl > 0.f ? 1 : 0;
+                part += tl > 0.f ? tl : 0.f;
+            }
         }
     }
     if (lane == 0) wsum[wv] = part;
@@ -906,14 +922,33 @@ __global__ __launch_bounds__(256) void trip_bwd_kernel(const float* __restrict__
     const int m = rec[0];
     if (m == 0) return;
     const float coef = gscale * (gscale_dev ? gscale_dev[0] : 1.f) / ((float)m * out[1]);
-    for (int j = wv; j < m; j += 4) {
-        if (!rec[4 + 3 * TRIP_MAX + j]) continue;
-        const long long ia = rec[4 + j], ip = rec[4 + TRIP_MAX + j], in = rec[4 + 2 * TRIP_MAX + j];
+    // the wave's triplets are wv, wv + 4, ... (at most 64 with TRIP_MAX = 256): lane l first fetches the record of triplet wv + 4 l, so
+    // the loop below reads records from registers (readlane) instead of paying a memory round trip per triplet before the row loads
+    const int jl = wv + 4 * lane;
+    int r_act = 0, r_a = 0, r_p = 0, r_n = 0;
+    if (jl < m) { r_act = rec[4 + 3 * TRIP_MAX + jl]; r_a = rec[4 + jl]; r_p = rec[4 + TRIP_MAX + jl]; r_n = rec[4 + 2 * TRIP_MAX + jl]; }
+    const int nl = (m - wv + 3) / 4;                          // triplets of this wave
+    for (int l0 = 0; l0 < nl; l0 += 4) {                     // four per pass: their twelve row loads of a slice are in flight together
+        long long ia[4], ip[4], in[4];
+        float cf[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int l = min(l0 + u, nl - 1);
+            ia[u] = __shfl(r_a, l, 64); ip[u] = __shfl(r_p, l, 64); in[u] = __shfl(r_n, l, 64);
+            cf[u] = (l0 + u < nl && __shfl(r_act, l, 64)) ? coef : 0.f;          // inactive / padding triplets add exact zeros ... (skipped below)
+        }
         for (int d = lane; d < D; d += 64) {
-            const float av = emb[ia * D + d], pv = emb[ip * D + d], nv = emb[in * D + d];
-            atomicAdd(demb + ia * D + d, coef * (nv - pv));
-            atomicAdd(demb + ip * D + d, -coef * av);
-            atomicAdd(demb + in * D + d, coef * av);
+            float av[4], pv[4], nv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { av[u] = emb[ia[u] * D + d]; pv[u] = emb[ip[u] * D + d]; nv[u] = emb[in[u] * D + d]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (cf[u] != 0.f) {                           // wave-uniform
+                    atomicAdd(demb + ia[u] * D + d, cf[u] * (nv[u] - pv[u]));
+                    atomicAdd(demb + ip[u] * D + d, -cf[u] * av[u]);
+                    atomicAdd(demb + in[u] * D + d, cf[u] * av[u]);
+                }
+            }
         }
     }
 }
