@@ -107,15 +107,28 @@ __global__ __launch_bounds__(256) void label_counts_kernel(const uint8_t* __rest
                                                            unsigned long long* __restrict__ cnt) {
     __shared__ unsigned int red[2][4];
     unsigned int a = 0, b = 0;
-    const bool al4 = ((uintptr_t)labels & 3) == 0;
-    const long long n4 = al4 ? total / 4 : 0;                   // 4 labels per load; the tail (and unaligned maps) byte-wise
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-        const unsigned int v = reinterpret_cast<const unsigned int*>(labels)[i];
+    // 16 labels per load, four loads per thread in flight (all-255 = ignore words beyond the end); the tail and unaligned maps byte-wise.
+    // (One 4-byte load per pass, 16 dependent passes per thread: 27 us for a 4 MB map.)
+    const bool al16 = ((uintptr_t)labels & 15) == 0;
+    const long long n16 = al16 ? total / 16 : 0, gs = (long long)gridDim.x * 256;
+    const long long n4 = 4 * n16;                               // (name kept for the tail loop below: labels covered = 4 * n4)
+    for (long long i0 = (long long)blockIdx.x * 256 + threadIdx.x; i0 < n16; i0 += 4 * gs) {
+        typedef unsigned int lab16_t __attribute__((ext_vector_type(4)));
+        lab16_t v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int f = (v >> (8 * k)) & 255;
-            if (f != IGN) { ++a; if (with_coarse && coarse_of(f, T) != IGN) ++b; }
+        for (int u = 0; u < 4; ++u) {
+            const long long i = i0 + u * gs;
+            v[u] = i < n16 ? reinterpret_cast<const lab16_t*>(labels)[i] : lab16_t{~0u, ~0u, ~0u, ~0u};
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int f = (v[u][q] >> (8 * k)) & 255;
+                    if (f != IGN) { ++a; if (with_coarse && coarse_of(f, T) != IGN) ++b; }
+                }
     }
     for (long long i = 4 * n4 + (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int f = labels[i];

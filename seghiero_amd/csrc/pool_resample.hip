@@ -104,12 +104,18 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restric
     const long long n = blockIdx.x;
     double s = 0;
     if (c < C) {
-        float part = 0.f;
-        int cnt = 0;
-        for (int r = g; r < HW; r += 4) {
-            part += x[(n * HW + r) * ldx + c];
-            if (++cnt == 64) { s += part; part = 0.f; cnt = 0; }
+        // eight rows per pass with their loads issued together (one load per pass and a counter branch made 64 dependent passes of a
+        // 16 x 16 map: 28 us for 8 MB); the f32 partial of a pass goes to the f64 sum
+        const float* base = x + n * HW * ldx + c;
+        int r = g;
+        for (; r + 28 < HW; r += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = base[(long long)(r + 4 * u) * ldx];
+            s += (double)(((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
         }
+        float part = 0.f;
+        for (; r < HW; r += 4) part += base[(long long)r * ldx];
         s += part;
     }
     red[g][cl] = s;
