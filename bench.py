@@ -38,6 +38,19 @@ def csrc_sha():
     return h.hexdigest()[:12]
 
 
+def make_trainer(dev):
+    """The trainer exactly as the timed run builds it (tests/test_model_gpu.py pins its step-0 loss against the CPU oracle)."""
+    from seghiero_amd.train_step import SegHieroTrainer
+    torch.manual_seed(0)
+    return SegHieroTrainer(depth=CFG["depth"], n_fine=CFG["n_fine"], coarse_to_fine_map=CFG["coarse_to_fine_map"], lr=0.01, device=dev)
+
+
+def make_inputs(batch, rank, dev):
+    """The synthetic batch of rank `rank`: seed = rank, resident on `dev`."""
+    from seghiero_amd.synthetic import make_batch
+    return make_batch(batch, CFG["size"], CFG["n_fine"], seed=rank, device=dev)
+
+
 def cpu_baseline(seconds_budget=30.0):
     """Reference CPU train loop (the oracle) at the headline shape, bounded: batch 2 at 512x512, ResNet-50."""
     from oracle.step import OracleTrainer
@@ -76,8 +89,6 @@ def main():
     args = ap.parse_args()
 
     from seghiero_amd import ddp, ops
-    from seghiero_amd.synthetic import make_batch
-    from seghiero_amd.train_step import SegHieroTrainer
 
     # SEGHIERO_BENCH_BACKEND=gloo + SEGHIERO_BENCH_ONE_DEVICE=1 rehearse the N>1 code path on a single-GPU box
     rank, local, world = ddp.init_from_env(backend=os.environ.get("SEGHIERO_BENCH_BACKEND"))
@@ -87,15 +98,13 @@ def main():
         local = 0
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    torch.manual_seed(0)
-    tr = SegHieroTrainer(depth=CFG["depth"], n_fine=CFG["n_fine"], coarse_to_fine_map=CFG["coarse_to_fine_map"],
-                         lr=0.01, device=dev)
+    tr = make_trainer(dev)
     if world > 1:
         ddp.broadcast_module_state(list(tr.modules().values()))
         tr.grad_sync = ddp.GradSync(tr.params)
         ops.SYNC_BN = bool(args.syncbn)
     tr.train()
-    img, lab = make_batch(args.batch, CFG["size"], CFG["n_fine"], seed=rank, device=dev)
+    img, lab = make_inputs(args.batch, rank, dev)
     lab8 = ops.labels_u8(lab)                       # the loader contract is i64 labels; convert once, outside the loop
 
     trace = (lambda m: print(f"[rank {rank}] {m}", file=sys.stderr, flush=True)) if os.environ.get("SEGHIERO_TRACE") else (lambda m: None)
@@ -106,8 +115,10 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    loss0 = None
     for _ in range(args.warmup):
-        tr.train_step(img, lab8, 0)
+        l = tr.train_step(img, lab8, 0)
+        loss0 = l if loss0 is None else loss0       # the very first step from the seeded initial weights (read back after the loop)
         trace("warmup step done")
     barrier()
     trace("barrier passed")
@@ -121,6 +132,14 @@ def main():
         ddp.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
     loss_val = float(loss)
+    # host side of a step: Python + launch time with the device idle at the start (nothing can block on a full queue)
+    host_ms = []
+    for _ in range(3):
+        barrier()
+        h0 = time.perf_counter()
+        tr.train_step(img, lab8, 0)
+        host_ms.append(1e3 * (time.perf_counter() - h0))
+    barrier()
 
     # ---- roofline of the dominant kernel, measured live (HIP events on the launch stream), one instrumented step.
     # Every rank runs it (the step contains collectives); only rank 0 instruments and reports.
@@ -175,6 +194,7 @@ def main():
         if tj:
             roof["traffic"] = round(tj["hbm_bytes_per_launch"])
             roof["traffic_source"] = os.path.relpath(tf, ROOT) + " (PMC FETCH_SIZE x2 + WRITE_SIZE, per launch of the family)"
+            roof["scope"] += "; traffic read from the committed rocprofv3 PMC passes of the same command, not measured in this run"
             roof["alg_bytes_per_launch"] = round(r["bytes"] / r["calls"])
             roof["traffic_stale"] = tjs.get("csrc_sha") != csrc_sha()
     except Exception:
@@ -198,7 +218,8 @@ def main():
                                "+ aux head, 9 fine / 4 coarse, 512x512 synthetic, fwd+loss+bwd+SGD",
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                    "parallelism": f"dp{world}" + ("" if world == 1 else (" + SyncBN" if args.syncbn else " (per-rank BatchNorm statistics)"))},
-        "loss": round(loss_val, 5), "roofline": roof, "roofline_units": roof_units, "kernel_ms_per_step": breakdown,
+        "loss": round(loss_val, 5), "loss_step0": None if loss0 is None else round(float(loss0), 6),
+        "host_ms_per_step": round(sorted(host_ms)[1], 2), "roofline": roof, "roofline_units": roof_units, "kernel_ms_per_step": breakdown,
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

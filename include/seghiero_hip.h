@@ -232,9 +232,11 @@ int sh_bn_finalize_multi(int k, const float* partials, int n_partials, int C, do
                          float* const* scale, float* const* shift, const float* const* chan_mul, int chan_stride,
                          float* const* isy, float eps, float momentum, void* stream);
 /* Weight gradient [C][9] of such a centre-tap depthwise conv in closed form from the BatchNorm-backward sums:
- * dL/dw_centre = gamma * dgamma * eps * invstd_y^2 / w, off-centre taps exactly 0. */
+ * dL/dw_centre = gamma * dgamma * eps * invstd_y^2 / w, off-centre taps exactly 0.  A centre tap that is exactly 0 leaves no trace in
+ * dgamma; with g != NULL (the masked gradient w.r.t. the BatchNorm output [M][ldg], x = the conv input [M][ldx], mean_x[C]) that
+ * channel's gradient is formed directly: gamma * invstd_y * sum g * (x - mean_x).  g == NULL: such channels get 0. */
 int sh_dw_center_wgrad(const float* dgamma, const float* gamma, const float* isy, const float* w, float eps, float* dw,
-                       int C, void* stream);
+                       int C, const float* g, int ldg, const float* x, int ldx, const float* mean_x, int64_t M, void* stream);
 /* Fold a long list of statistics partials before finalizing it: `chunk` consecutive partials -> one partial of the same format
  * (centred (sum, M2) pairs of rows_per_partial rows each when rows_per_partial > 0 -- the last one short, count rows in all; plain
  * sums when 0), out = [ceil(n_partials / chunk)][2][C].  sh_bn_finalize / sh_bn_bwd_finalize then take `out` with

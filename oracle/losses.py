@@ -181,7 +181,10 @@ class HieraTripletLoss(nn.Module):
         loss = losses_hiera_two_level(cls_score, tf, tc, nf, self.hiera_index)
         loss = loss + self.ce(cls_score[:, :nf], tf) + self.ce(cls_score[:, nf:nf + nc], tc)
         trip, count = self.triplet_loss_fn(embedding, label)
-        if int(count) > 0:          # single process: ready <=> class_count > 0
+        # hiera_triplet_loss.py:192-201: single process: ready <=> class_count > 0; under torch.distributed: every rank's count > 0
+        # (the caller states that by passing `ready`, oracle/step.py:ddp_forward_loss)
+        ready = kwargs.get("ready")
+        if (int(count) > 0) if ready is None else ready:
             loss = loss + triplet_factor(int(step), 80000) * trip
         return loss * self.loss_weight
 
@@ -274,7 +277,8 @@ class RMIHieraTripletLoss(nn.Module):
         loss = loss + self.ce(cls_score[:, :nf], tf) + self.ce(cls_score[:, nf:nf + nm], tm) \
             + self.ce(cls_score[:, nf + nm:nf + nm + nh], th)
         trip, count = self.triplet_loss(embedding, label)
-        if int(count) > 0:
+        ready = kwargs.get("ready")                 # as HieraTripletLoss (rmi_hiera_triplet_loss.py:527-536)
+        if (int(count) > 0) if ready is None else ready:
             loss = loss + triplet_factor(int(step), 160000 if nf > 15 else 60000) * trip
         return loss * self.loss_weight
 

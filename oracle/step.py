@@ -65,6 +65,37 @@ class OracleTrainer:
         aux_loss = self.aux_criterion(aux, fine_mask)
         return main_loss + 0.4 * aux_loss, main_loss, aux_loss, after
 
+    def ddp_forward_loss(self, img, fine_mask, epoch, cuts):
+        """Statement of the DATA-PARALLEL step with SyncBN (the build's multi-GPU semantics; the reference has no DDP
+        launcher -- its only distributed call is the class_count all_gather of hiera_triplet_loss.py:193-198):
+
+        * rank r holds images [cuts[r], cuts[r+1]); BatchNorm statistics are those of the WHOLE batch on every rank (SyncBN), so the
+          trunk, head and aux head are one forward over the concatenated batch;
+        * every rank evaluates the loss on ITS shard with ITS OWN normalisers -- num_valid of hiera_triplet_loss.py:41-107, the
+          all-pixel mean of models/loss/utils.py:20-21, nn.CrossEntropyLoss's valid-pixel mean, the batch mean of
+          rmi_hiera_triplet_loss.py:515 -- and its own triplet selection (tree_triplet_loss.py:23-46 over the shard);
+        * the triplet term counts only if EVERY rank found triplets (hiera_triplet_loss.py:193-201);
+        * gradient averaging over the ranks = the gradient of the MEAN of the per-rank losses.
+
+        -> (mean loss, [per-rank total], [per-rank main], [per-rank aux])."""
+        c1, c2, c3, c4 = self.backbone(img)
+        main_logits, embedding = self.aspp_head([c1, c2, c3, c4])
+        H, W = fine_mask.shape[-2:]
+        before = F.interpolate(main_logits, scale_factor=0.5, mode="bilinear", align_corners=False)
+        after = F.interpolate(main_logits, size=(H, W), mode="bilinear", align_corners=False)
+        aux = F.interpolate(self.aux_head(c3), size=(H, W), mode="bilinear", align_corners=False)
+        trip_fn = getattr(self.hiera_loss_fn, "triplet_loss_fn", None) or self.hiera_loss_fn.triplet_loss
+        shards = list(zip(cuts[:-1], cuts[1:]))
+        with torch.no_grad():
+            ready = all(int(trip_fn(embedding[a:b], fine_mask[a:b])[1]) > 0 for a, b in shards)
+        mains, auxs = [], []
+        for a, b in shards:
+            mains.append(self.hiera_loss_fn(torch.tensor([epoch]), embedding[a:b], before[a:b, :self.n_fine], after[a:b], fine_mask[a:b],
+                                            ready=ready))
+            auxs.append(self.aux_criterion(aux[a:b], fine_mask[a:b]))
+        totals = [m + 0.4 * x for m, x in zip(mains, auxs)]
+        return sum(totals) / len(totals), totals, mains, auxs
+
     def train_step(self, img, fine_mask, epoch=0):
         self.optimizer.zero_grad()
         loss, _, _, _ = self.forward_loss(img, fine_mask, epoch)

@@ -23,6 +23,15 @@ class SegHieroHipError(RuntimeError):
     pass
 
 
+# status codes of include/seghiero_hip.h
+STATUS = {0: "ok", -1: "SH_EINVAL: invalid argument", -2: "SH_ELAUNCH: HIP launch error",
+          -3: "SH_EUNSUPPORTED: no kernel instantiation for this geometry, nothing was launched"}
+
+
+def status_text(rc):
+    return STATUS.get(rc, "unknown status")
+
+
 def parse_header(path=HEADER):
     """-> {name: (restype, [(ctype, argname), ...])} for every prototype in the header."""
     text = open(path).read()
@@ -78,8 +87,7 @@ class _Lib:
         """Call an int-returning entry point; raise on a non-zero status."""
         rc = self.raw(name)(*args)
         if rc != 0:
-            raise SegHieroHipError(f"{name} failed with status {rc} "
-                                   f"({'invalid argument' if rc == -1 else 'HIP launch error'})")
+            raise SegHieroHipError(f"{name} failed with status {rc} ({status_text(rc)})")
         return rc
 
 

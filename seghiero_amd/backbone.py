@@ -143,8 +143,14 @@ class _BackboneFn(torch.autograd.Function):
         w = mod.stem_conv.weight                                       # [64,3,7,7] -> OHWI with I padded to 4
         if not w.is_contiguous():
             raise SegHieroHipError("stem_conv.weight must be contiguous")
-        wpad = ops.new_act(w.shape[0], 4, 7, 7, w.device, zero=True)
-        ops._call("sh_nchw_to_nhwc", w.data_ptr(), wpad.data_ptr(), w.shape[0], 3, 7, 7, 4, ops._st())
+        # the OHWI copy with I padded to 4 is kept until the weight changes (an optimizer step, load_state_dict, .to())
+        hit, wkey = mod.__dict__.get("_stem_wpad"), ops.weights_key(w)
+        if hit is not None and hit[0] == wkey:
+            wpad = hit[1]
+        else:
+            wpad = ops.new_act(w.shape[0], 4, 7, 7, w.device, zero=True)
+            ops._call("sh_nchw_to_nhwc", w.data_ptr(), wpad.data_ptr(), w.shape[0], 3, 7, 7, 4, ops._st())
+            mod.__dict__["_stem_wpad"] = (wkey, wpad)
         # act_dtype = torch.bfloat16 (training only): the trunk's raw conv outputs and block outputs are STORED as bf16 -- half the
         # bytes of every activation read and write; arithmetic, BatchNorm statistics and gradients stay fp32 (BASELINE configs[4])
         stored = mod.act_dtype if (training and L.FUSE_BN and ops.CONV_IMPL == "x6") else torch.float32
@@ -161,6 +167,8 @@ class _BackboneFn(torch.autograd.Function):
                     h, sv = _block_fwd(blk, h, training)
                     saved.append(sv)
                 outs.append(h)
+        if mod.__dict__.get("_relu_mask_sink") is not None:                 # parity tests only (ResNetBackbone.export_relu_masks)
+            mod.__dict__["_relu_mask_sink"].extend(_relu_masks(s_rec, saved))
         outs = [o if o.dtype == torch.float32 else o.float() for o in outs]      # the head and the aux head take fp32 stage outputs
         if training:
             L.bump_bn_counters(_all_bns(mod))
@@ -224,6 +232,20 @@ def _dense(t):
     return t if ops.pm(t)[1] == t.shape[1] else ops.dense_copy(t)
 
 
+def _relu_masks(s_rec, saved):
+    """The 0/1 masks of every ReLU of one training forward, in forward order (stem, then per block: one per conv), exactly as the
+    kernels evaluate them: ``y * scale + shift > 0`` from the raw conv output and the BatchNorm coefficients where the activation is
+    deferred to a loader, ``out > 0`` for a block output.  Parity tests pin torch's ReLUs to these (a pre-activation that two fp32
+    evaluations round to different sides of 0 otherwise moves every upstream gradient by O(1e-4): DESIGN.md, parity section)."""
+    def pre(rec):
+        return (rec.y.float() * rec.coefs[2].view(1, -1, 1, 1) + rec.coefs[3].view(1, -1, 1, 1)) > 0
+    masks = [pre(s_rec)]
+    for recs, _ in saved:
+        for k, rec in enumerate(recs):
+            masks.append((rec.out > 0) if k == len(recs) - 1 else pre(rec))
+    return masks
+
+
 class ResNetBackbone(nn.Module):
     def __init__(self, depth: int = 101, pretrained: bool = True):
         super().__init__()
@@ -251,6 +273,10 @@ class ResNetBackbone(nn.Module):
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
         L.to_native_layout(self)
+
+    def export_relu_masks(self, sink):
+        """Test hook: with a list, every training forward appends its ReLU masks (_relu_masks) to it; None switches it off."""
+        self.__dict__["_relu_mask_sink"] = sink
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)

@@ -361,24 +361,34 @@ extern "C" int sh_bn_finalize_scaled(const float* partials, int n_partials, int 
 // Weight gradient of such a centre-tap depthwise conv, in closed form from the BatchNorm-backward sums: with y = w x the loss
 // depends on w only through eps -- dL/dw_centre = gamma * dgamma * eps * invstd_y^2 / w (derivation in DESIGN.md) -- and the eight
 // off-centre taps never touch the image: exact zeros.  dw: [C][9].
-__global__ __launch_bounds__(256) void dw_center_wgrad_kernel(const float* __restrict__ dgamma, const float* __restrict__ gamma,
-                                                              const float* __restrict__ isy, const float* __restrict__ w, float eps,
-                                                              float* __restrict__ dw, int C) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 9 * C) return;
-    const int c = i / 9, tap = i - 9 * c;
+// A centre tap that is EXACTLY zero (zero-initialised or pruned weights) carries no information in dgamma (= w * isy * S with
+// S = sum g * (x - mean_x)): that channel's block forms S itself from the masked gradient g and the input x, dL/dw = gamma * isy * S
+// (the same closed form with eps * isy^2 = 1 at w = 0).  One block of 64 threads per channel; only zero-weight channels loop.
+__global__ __launch_bounds__(64) void dw_center_wgrad_kernel(const float* __restrict__ dgamma, const float* __restrict__ gamma,
+                                                             const float* __restrict__ isy, const float* __restrict__ w, float eps,
+                                                             float* __restrict__ dw, int C, const float* __restrict__ g, long long ldg,
+                                                             const float* __restrict__ x, long long ldx, const float* __restrict__ mean_x,
+                                                             long long M) {
+    const int c = blockIdx.x, t = threadIdx.x;
+    const float wc = w[(long long)c * 9 + 4];
+    const float gm = gamma ? gamma[c] : 1.f;
     float v = 0.f;
-    if (tap == 4) {
-        const float wc = w[(long long)c * 9 + 4];
-        const float g = gamma ? gamma[c] : 1.f;
-        v = wc != 0.f ? g * dgamma[c] * eps * isy[c] * isy[c] / wc : 0.f;
+    if (wc != 0.f) v = gm * dgamma[c] * eps * isy[c] * isy[c] / wc;
+    else if (g != nullptr) {                                   // block-uniform branch
+        const float mu = mean_x[c];
+        double s = 0.0;
+        for (long long m = t; m < M; m += 64) s += (double)g[m * ldg + c] * (double)(x[m * ldx + c] - mu);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        v = (float)((double)gm * (double)isy[c] * s);
     }
-    dw[i] = v;
+    if (t < 9) dw[(long long)c * 9 + t] = t == 4 ? v : 0.f;
 }
 extern "C" int sh_dw_center_wgrad(const float* dgamma, const float* gamma, const float* isy, const float* w, float eps, float* dw, int C,
-                                  void* stream) {
+                                  const float* g, int ldg, const float* x, int ldx, const float* mean_x, int64_t M, void* stream) {
     if (!dgamma || !isy || !w || !dw || C <= 0) return SH_EINVAL;
-    dw_center_wgrad_kernel<<<(unsigned)sh_cdiv(9 * C, 256), 256, 0, (hipStream_t)stream>>>(dgamma, gamma, isy, w, eps, dw, C);
+    if (g && (!x || !mean_x || ldg < C || ldx < C || M <= 0)) return SH_EINVAL;
+    dw_center_wgrad_kernel<<<(unsigned)C, 64, 0, (hipStream_t)stream>>>(dgamma, gamma, isy, w, eps, dw, C, g, ldg, x, ldx, mean_x, M);
     return sh_launch_status();
 }
 

@@ -37,17 +37,25 @@ def init_from_env(backend=None):
     return rank, local, world
 
 
-# Latency-class collectives (SyncBN statistics: 2 x 69 per step, each a few KB; the 4-byte triplet class_count MIN-reduce)
-# get a process group -- i.e. an RCCL communicator and internal stream -- of their own, so that a stat reduction on the
-# critical path of forward / backward never queues behind a 32 MB gradient bucket of the default group.
+# Latency-class collectives (SyncBN statistics, coalesced per block: see ops.sync_batch; the 4-byte triplet class_count MIN-reduce)
+# CAN get a process group -- i.e. an RCCL communicator and internal stream -- of their own, so that a stat reduction on the
+# critical path of forward / backward never queues behind a 32 MB gradient bucket of the default group.  OFF by default
+# (SEGHIERO_SMALL_GROUP=1 switches it on): torch.distributed documents concurrent collectives of two NCCL communicators on one device
+# as unsafe unless one group's work has finished on the device before the other's is enqueued, and this path has never run on two
+# GPUs (the round's box has one).  With the switch on, every small-group collective first makes its stream wait for an event
+# recorded after the last gradient-bucket launch (_BUCKET_EVENT), which serialises the two communicators on the device -- the order
+# torch.distributed asks for -- at the price of the very queueing the second group was meant to avoid; without the switch the small
+# collectives simply use the default group (same communicator: RCCL orders them itself).
 _SMALL = None
+_BUCKET_EVENT = None           # recorded on the gradient-exchange stream after the latest bucket all-reduce (GradSync._launch)
+SMALL_GROUP = os.environ.get("SEGHIERO_SMALL_GROUP", "0") == "1"
 FORCE_COLLECTIVES = False      # tests: run every collective even at world size 1 (executes the RCCL calls on a one-GPU box)
 
 
 def init_small_group():
-    """Collective: every rank must call it (init_from_env and GradSync.__init__ do)."""
+    """Collective: every rank must call it (init_from_env and GradSync.__init__ do).  A no-op unless SMALL_GROUP is set."""
     global _SMALL
-    if _SMALL is None and dist.is_available() and dist.is_initialized():
+    if SMALL_GROUP and _SMALL is None and dist.is_available() and dist.is_initialized():
         _SMALL = dist.new_group()
     return _SMALL
 
@@ -57,9 +65,10 @@ def small_group():
 
 
 def shutdown():
-    global _SMALL, _ACTIVE
+    global _SMALL, _ACTIVE, _BUCKET_EVENT
     _SMALL = None
     _ACTIVE = None
+    _BUCKET_EVENT = None
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
@@ -73,7 +82,9 @@ def collectives_on():
 
 
 def all_reduce_small(t, op=None):
-    """All-reduce of a latency-critical small tensor on the small-message group (falls back to the default group)."""
+    """All-reduce of a latency-critical small tensor on the small-message group (the default group unless SMALL_GROUP is on)."""
+    if _SMALL is not None and _BUCKET_EVENT is not None and t.is_cuda:
+        torch.cuda.current_stream(t.device).wait_event(_BUCKET_EVENT)      # never two communicators at work on the device at once
     return all_reduce(t, op=op, group=_SMALL)
 
 
@@ -111,8 +122,11 @@ _ACTIVE = None          # the GradSync that is collecting gradients of the backw
 
 
 def grad_buffer(p):
-    """Where a backward node should write the gradient of parameter `p`: its slice of the active GradSync arena, else None."""
-    if _ACTIVE is not None and id(p) in _ACTIVE.views and id(p) not in _ACTIVE._in_arena:
+    """Where a backward node should write the gradient of parameter `p`: its slice of the active GradSync arena, else None.
+    A slice is handed out ONCE per step: a second gradient of the same parameter (layers.GradMap.put accumulates) gets None, i.e. a
+    fresh tensor, instead of overwriting the first one in place."""
+    if _ACTIVE is not None and id(p) in _ACTIVE.views and id(p) not in _ACTIVE._in_arena and id(p) not in _ACTIVE._handed:
+        _ACTIVE._handed.add(id(p))
         return _ACTIVE.grad_view(p)
     return None
 
@@ -132,6 +146,8 @@ class GradSync:
     the all-reduce of every bucket that became complete on a side stream, overlapped with the remaining backward kernels;
     ``reduce()`` after backward sends what is left, waits, and points ``p.grad`` at the reduced arena (no copy back)."""
 
+    ARENA_ALIGN = 64
+
     def __init__(self, params, bucket_mb=32.0, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -141,7 +157,11 @@ class GradSync:
         # backward produces gradients roughly in reverse parameter order
         self.order = list(reversed(list(params)))
         dev = self.order[0].device
-        total = sum(p.numel() for p in self.order)
+        # every parameter's slice starts on a 256-byte boundary (ARENA_ALIGN floats): the weight-gradient kernels write their
+        # slice with 16-byte stores (odd-sized tensors -- cls_seg bias 13, aux BatchNorm 9 -- would misalign everything behind them);
+        # the padding floats stay zero and travel with the bucket
+        al = self.ARENA_ALIGN
+        total = sum(-(-p.numel() // al) * al for p in self.order)
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
         self.views, self.buckets, self.bucket_of = {}, [], {}
         off, start, limit = 0, 0, int(bucket_mb * (1 << 20) / 4)
@@ -150,19 +170,19 @@ class GradSync:
             self.views[id(p)] = (off, p.numel())
             self.bucket_of[id(p)] = len(self.buckets)
             cur.append(p)
-            off += p.numel()
+            off += -(-p.numel() // al) * al
             if off - start >= limit:
                 self.buckets.append((start, off, cur))
                 start, cur = off, []
         if cur:
             self.buckets.append((start, off, cur))
         self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
-        self._in_arena, self._launched, self._works = set(), set(), []
+        self._in_arena, self._launched, self._works, self._handed = set(), set(), [], set()
 
     # ------------------------------------------------------------------ per-step protocol
     def begin(self):
         global _ACTIVE
-        self._in_arena, self._launched, self._works = set(), set(), []
+        self._in_arena, self._launched, self._works, self._handed = set(), set(), [], set()
         _ACTIVE = self if self.on else None
 
     def grad_view(self, p):
@@ -190,6 +210,7 @@ class GradSync:
             torch._foreach_copy_(dsts, srcs)
 
     def _launch(self, bi):
+        global _BUCKET_EVENT
         start, end, _ = self.buckets[bi]
         buf = self.flat[start:end]
         self._launched.add(bi)
@@ -198,7 +219,13 @@ class GradSync:
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
-                self._works.append(all_reduce(buf, group=self.group, async_op=True))
+                work = all_reduce(buf, group=self.group, async_op=True)
+                self._works.append(work)
+                if _SMALL is not None:
+                    if work is not None:
+                        work.wait()                      # (device-side: the exchange stream waits for the collective, not the host)
+                    _BUCKET_EVENT = torch.cuda.Event()
+                    _BUCKET_EVENT.record(self.stream)
         else:
             self._works.append(all_reduce(buf, group=self.group, async_op=True))
 

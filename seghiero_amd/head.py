@@ -252,10 +252,13 @@ class _HeadFn(torch.autograd.Function):
                     # centre-tap branch (y = w_centre * c4 never existed): the BatchNorm backward on c4 with the x-domain
                     # coefficients yields d/dc4 directly; the depthwise weight gradient is closed-form (sh_dw_center_wgrad)
                     coefs_x, isy = R[f"dwc{i}"]
-                    dxc, dg, db, _ = ops.bn_backward(res[0], None, R[f"pw{i}"].x.y, coefs_x, ds.bn_dw.weight, 2)
+                    xin = R[f"pw{i}"].x.y
+                    dxc, dg, db, _ = ops.bn_backward(res[0], None, xin, coefs_x, ds.bn_dw.weight, 2)
                     ops._call("sh_axpy", dc4.data_ptr(), dxc.data_ptr(), 1.0, dc4.numel(), ops._st())
                     dww = L.new_grad(ds.depthwise.weight)
-                    ops.dw_center_wgrad(dg, ds.bn_dw.weight, isy, ds.depthwise.weight, ds.bn_dw.eps, dww)
+                    # (a centre tap that is exactly 0 leaves no trace in dgamma: those channels read the masked gradient itself)
+                    gmask = res[0].g if isinstance(res[0], L.GradPack) and xin.dtype == torch.float32 else None
+                    ops.dw_center_wgrad(dg, ds.bn_dw.weight, isy, ds.depthwise.weight, ds.bn_dw.eps, dww, g=gmask, x=xin, mean_x=coefs_x[0])
                 else:
                     _, dww, dg, db = L.dw_bwd(R[f"dw{i}"], ds.bn_dw, res[0], dx_accumulate_into=dc4)
                 gm.put(ds.depthwise.weight, dww); gm.put(ds.bn_dw.weight, dg); gm.put(ds.bn_dw.bias, db)

@@ -220,19 +220,37 @@ def three_level_triplet_tables(upper_ids, lower_ids):
 class RMITreeTripletLoss(nn.Module):
     """``TreeTripletLoss`` of reference ``models/loss/rmi_tree_triplet_loss.py:5-70`` (3-level variant)."""
 
-    def __init__(self, num_classes, upper_ids, lower_ids, ignore_index=IGNORE):
+    def __init__(self, num_classes, upper_ids, lower_ids, ignore_index=IGNORE, strict=False):
+        """strict=True mirrors the reference's failure mode: a label present on the embedding grid that is in neither hard-coded
+        group (nor 0 / 255) raises ``ValueError`` as ``list.remove`` does at ``rmi_tree_triplet_loss.py:39`` -- at the price of one
+        host synchronisation per call.  Default (False): such a class is simply never an anchor and nothing synchronises."""
         super().__init__()
         self.ignore_label = ignore_index
         self.num_classes = num_classes
         self.upper_ids = upper_ids
         self.lower_ids = lower_ids
+        self.strict = strict
         masks, ok = three_level_triplet_tables(upper_ids, lower_ids)
         self.register_buffer("_masks", masks, persistent=False)
         self.register_buffer("_anchor_ok", ok, persistent=False)
 
     tables = TreeTripletLoss.tables
 
+    def check_labels(self, labels, h, w):
+        """The reference's ValueError for a label outside both groups (``:34-39``): labels as its nearest-neighbour resize sees
+        them (index = floor(i * H / h))."""
+        H, W = labels.shape[-2:]
+        iy = (torch.arange(h, device=labels.device) * H) // h
+        ix = (torch.arange(w, device=labels.device) * W) // w
+        present = torch.unique(labels[:, iy][:, :, ix]).tolist()
+        known = set(self.upper_ids) | set(self.lower_ids) | {0, self.ignore_label}
+        for v in present:
+            if int(v) not in known:
+                raise ValueError("list.remove(x): x not in list")      # the reference's own message (label %d in neither group)
+
     def forward(self, feats, labels=None, max_triplet=200):
+        if self.strict:
+            self.check_labels(labels, feats.shape[2], feats.shape[3])
         masks, ok = self.tables(feats.device)
         loss, count = _TripletFn.apply(feats, ops.labels_u8(labels), masks, ok, max_triplet)
         n = int(count.item())
@@ -335,4 +353,6 @@ class RMIHieraTripletLoss(nn.Module):
     def forward(self, step, embedding, cls_score_before, cls_score, label, weight=None, **kwargs):
         if cls_score.shape[1] != self.n_fine + self.n_mid + self.n_high:
             raise ValueError("cls_score must have n_fine + n_mid + n_high channels")
+        if self.triplet_loss.strict:
+            self.triplet_loss.check_labels(label, embedding.shape[2], embedding.shape[3])
         return _Hiera3Fn.apply(cls_score, embedding, ops.labels_u8(label), self, _step_value(step))

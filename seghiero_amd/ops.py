@@ -8,7 +8,7 @@ import ctypes
 
 import torch
 
-from ._lib import LIB, SegHieroHipError
+from ._lib import LIB, SegHieroHipError, status_text
 
 import os
 
@@ -209,7 +209,7 @@ def _call_fused(name, *args, cost=None, key=None):
         return True
     if rc == UNSUPPORTED:
         return False
-    raise SegHieroHipError(f"{name} failed with status {rc} ({'invalid argument' if rc == -1 else 'HIP launch error'})")
+    raise SegHieroHipError(f"{name} failed with status {rc} ({status_text(rc)})")
 
 
 def conv_fprop_aff(x, in_coefs, weight, bias, y, partials, stride, pad, dil):
@@ -460,7 +460,17 @@ def wgrad_aff_ok(x, dweight, stride, pad, dil):
     """Can conv_wgrad(..., aff=...) read this x through the producer's BatchNorm + ReLU?  (x6 kernel, output width >= 16)"""
     n, cin, h, w = x.shape
     o, _, kh, kw = dweight.shape
-    return CONV_IMPL == "x6" and cin % 4 == 0 and conv_out_hw(h, w, kh, kw, stride, pad, dil)[1] >= 16
+    return CONV_IMPL == "x6" and _wgrad_pipelined_ok(x, o, kh, kw, stride, pad, dil)
+
+
+def _wgrad_pipelined_ok(x, o, kh, kw, stride, pad, dil):
+    """Does the pipelined weight-gradient kernel (the only one with the BatchNorm loader / bf16 streams) take this geometry?
+    16-byte channel chunks, output width >= 16, and both operands below the 2 GiB range of its 32-bit buffer offsets -- a
+    256-channel conv3 gradient at 512^2 crosses that at batch 128, which fits the 288 GB part."""
+    n, cin, h, w = x.shape
+    ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
+    ldx = _pm(x, True)[1] if x.dim() == 4 else cin
+    return (cin % 4 == 0 and wo >= 16 and n * h * w * ldx * 4 < (1 << 31) and n * ho * wo * pad4(o) * 4 < (1 << 31))
 
 
 def conv_wgrad(x, dy, dweight, stride, pad, dil, side=False, aff=None):
@@ -470,9 +480,11 @@ def conv_wgrad(x, dy, dweight, stride, pad, dil, side=False, aff=None):
     n, cin, h, w = x.shape
     o, _, kh, kw = dweight.shape
     dd = dy if isinstance(dy, DeferredDy) else None          # dy evaluated in the loader (check lin_ok before deferring)
-    if x.dtype == torch.bfloat16 and not (CONV_IMPL == "x6" and cin % 4 == 0 and conv_out_hw(h, w, kh, kw, stride, pad, dil)[1] >= 16):
-        # bf16-stored x where the pipelined wgrad has no instantiation (output width < 16: tiny test inputs): widen once
-        x = x.float()
+    if (x.dtype == torch.bfloat16 or dd is not None) and not (CONV_IMPL == "x6" and _wgrad_pipelined_ok(x, o, kh, kw, stride, pad, dil)):
+        # bf16-stored x / deferred dy where the pipelined wgrad has no instantiation (output width < 16: tiny test inputs; operands
+        # of 2 GiB or more): widen / materialise once and run the plain kernel
+        if x.dtype == torch.bfloat16:
+            x = x.float()
         if dd is not None:
             dy, dd = dd.materialize(), None
     if dd is not None and (dd.y.dtype == torch.bfloat16) != (x.dtype == torch.bfloat16):
@@ -702,9 +714,14 @@ def bn_finalize_multi(partials, count, rows, bns, coefs_list, partials_ld=0, col
           float(eps), float(mom), _st())
 
 
-def dw_center_wgrad(dgamma, gamma, isy, dw_weight, eps, dweight):
+def dw_center_wgrad(dgamma, gamma, isy, dw_weight, eps, dweight, g=None, x=None, mean_x=None):
+    """g (masked gradient w.r.t. the BatchNorm output), x (the conv input), mean_x: channels whose centre tap is exactly 0 get their
+    gradient from these (their dgamma is 0 whatever the true gradient is)."""
+    gp, ldg = (None, 0) if g is None else pm(g)
+    xp, ldx = (None, 0) if g is None else pm(x)
+    m = 0 if g is None else g.shape[0] * g.shape[2] * g.shape[3]
     _call("sh_dw_center_wgrad", dgamma.data_ptr(), gamma.data_ptr(), isy.data_ptr(), dw_weight.data_ptr(), float(eps),
-          dweight.data_ptr(), dw_weight.shape[0], _st())
+          dweight.data_ptr(), dw_weight.shape[0], gp, ldg, xp, ldx, None if g is None else mean_x.data_ptr(), m, _st())
 
 
 def conv1x1_grouped_fprop(sources, weights, y, partials):
@@ -1021,13 +1038,23 @@ def _buckets(hiera_index):
     return (ctypes.c_int * max(len(flat), 1))(*flat)
 
 
-def _loss_grad_out(want_grad, n, c, h, w, H, W, device):
-    """Buffer for the per-pixel gradient a loss forward leaves for its backward ([N*H*W][pad4(C)] fp32, a fresh tensor: it lives
-    from the forward to the backward of one graph), when the logits are upsampled."""
+STEP_SCOPE = None         # set by SegHieroTrainer.train_step: {tag: tensor} of buffers that live from the forward to the backward of ONE
+                          # step and are handed out again in the next one (one graph in flight at a time -- the trainer's contract)
+
+
+def _loss_grad_out(want_grad, n, c, h, w, H, W, device, tag="lossgrad"):
+    """Buffer for the per-pixel gradient a loss forward leaves for its backward ([N*H*W][pad4(C)] fp32; it lives from the forward to
+    the backward of one graph), when the logits are upsampled.  Inside a trainer step (STEP_SCOPE) the same buffer serves every
+    step; a standalone loss call gets a fresh tensor (several graphs may be alive at once)."""
     if not (want_grad and LOSS_FWD_GRAD and LOSS_BWD_TWO_PASS) or not (h <= H and w <= W and (h < H or w < W)):
         return None, 0, 0
     ldg = pad4(c)
     need = LIB.raw("sh_loss_bwd_workspace")(n, H, W, ldg)
+    if STEP_SCOPE is not None:
+        buf = STEP_SCOPE.get(tag)
+        if buf is None or buf.numel() < need // 4 or buf.device != device:
+            buf = STEP_SCOPE[tag] = torch.empty((need // 4,), device=device, dtype=torch.float32)
+        return buf[:need // 4], need, ldg
     return torch.empty((need // 4,), device=device, dtype=torch.float32), need, ldg
 
 
@@ -1088,7 +1115,7 @@ def ce_fwd(logits, labels8, want_grad=False):
     partials = torch.empty((nblk, 8), device=dev, dtype=torch.float32)
     sums = torch.empty((2,), device=dev, dtype=torch.float64)
     loss = torch.empty((1,), device=dev, dtype=torch.float32)
-    gw, gbytes, ldg = _loss_grad_out(want_grad, n, c, h, w, H, W, dev)
+    gw, gbytes, ldg = _loss_grad_out(want_grad, n, c, h, w, H, W, dev, tag="lossgrad_ce")
     _call("sh_ce_loss_fwd", lp, ldl, labels8.data_ptr(), c, sums.data_ptr(), loss.data_ptr(), partials.data_ptr(),
           n, h, w, H, W, None if gw is None else gw.data_ptr(), gbytes, ldg, _st())
     return loss, sums, gw
@@ -1151,9 +1178,17 @@ def pixel_metrics(logits, labels8, n_fine, counts=None):
 
 # ----------------------------------------------------------------------------- optimizer
 SGD_MAX = 48
+WEIGHT_EPOCH = 0          # bumped by every sgd_step launch: the kernel writes the parameters through raw pointers, which torch's
+                          # tensor version counter does not see -- derived copies (the padded stem weight) are keyed on both
+
+
+def weights_key(w):
+    return (w.data_ptr(), w._version, WEIGHT_EPOCH)
 
 
 def sgd_step(params, grads, bufs, lr, momentum, weight_decay, first_step, gscale=1.0):
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
     st = _st()
     for i in range(0, len(params), SGD_MAX):
         ps, gs, vs = params[i:i + SGD_MAX], grads[i:i + SGD_MAX], bufs[i:i + SGD_MAX]

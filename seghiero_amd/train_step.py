@@ -96,6 +96,8 @@ class SegHieroTrainer:
 
     def checkpoint_path(self, epoch):
         """``<output.checkpoint_dir>/<output.project_name>_epoch_<epoch>_best.pth`` (``train.py:430-433``)."""
+        if self.cfg is None:
+            raise ValueError("checkpoint_path() needs the YAML config: build the trainer with SegHieroTrainer.from_config(cfg)")
         out = self.cfg["output"]
         return os.path.join(out["checkpoint_dir"], f"{out['project_name']}_epoch_{epoch}_best.pth")
 
@@ -140,6 +142,7 @@ class SegHieroTrainer:
         self.optimizer = FusedSGD(self.params, lr=lr, momentum=0.9, weight_decay=1e-4)
         self.grad_sync = grad_sync
         self.cfg = None
+        self._step_scope = {}                    # buffers that live from the forward to the backward of one step (ops.STEP_SCOPE)
 
     def modules(self):
         return {"backbone": self.backbone, "aspp_head": self.aspp_head, "aux_head": self.aux_head}
@@ -191,6 +194,7 @@ class SegHieroTrainer:
         self.optimizer.zero_grad(set_to_none=True)
         if ops.CONV_IMPL == "x6":
             ops.prepare_dgrad_weights(self._dgrad_weights, self._wt_cache)   # all dgrad operands in 2 launches; valid until SGD
+        ops.STEP_SCOPE = self._step_scope            # the loss forward's per-pixel gradient buffers are reused from step to step
         try:
             loss, _, _, _ = self.forward_loss(img, fine_mask, epoch)
             if self.grad_sync is not None:
@@ -198,6 +202,7 @@ class SegHieroTrainer:
             loss.backward()
         finally:
             ops.release_dgrad_weights()
+            ops.STEP_SCOPE = None
         gscale = 1.0
         if self.grad_sync is not None:
             gscale = self.grad_sync.reduce(self.params)

@@ -237,6 +237,7 @@ def _rccl_world1_worker(port, q):
         from seghiero_amd import ddp
         torch.cuda.set_device(0)
         dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        ddp.SMALL_GROUP = True                                          # the second communicator, serialised behind the buckets
         ddp.init_small_group()
         ddp.FORCE_COLLECTIVES = True
         assert dist.get_backend() == "nccl" and dist.get_backend(ddp.small_group()) == "nccl"
@@ -306,3 +307,115 @@ def test_syncbn_bottleneck_blocks_two_ranks(cuts):
         for k, want in full[name]["grads"].items():
             e = _rel(res[0][name]["grads"][k] + res[1][name]["grads"][k], want)
             assert e < 2e-4, (name, k, e)
+
+
+# ---------------------------------------------------------------- the whole trainer step, different shards per rank, SyncBN on
+SH_B, SH_S, SH_EPOCH = 4, 128, 40000          # epoch 40000: the triplet term is live (cosine factor 0.25)
+
+
+def _sharded_step(cuts, rank, world):
+    from seghiero_amd import ddp, ops
+    from seghiero_amd.synthetic import make_batch
+    from seghiero_amd.train_step import SegHieroTrainer
+    torch.manual_seed(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ops.SYNC_BN = True
+    tr = SegHieroTrainer(device=dev, **TR_KW)
+    init = {k: {n: v.detach().cpu().clone() for n, v in m.state_dict().items()} for k, m in tr.modules().items()}
+    if world > 1:
+        ddp.broadcast_module_state(list(tr.modules().values()))
+        tr.grad_sync = ddp.GradSync(tr.params, bucket_mb=4.0)
+    tr.train()
+    img, lab = make_batch(SH_B, SH_S, 4, seed=5)
+    a, b = cuts[rank], cuts[rank + 1]
+    loss = float(tr.train_step(img[a:b].to(dev), lab[a:b].to(dev), SH_EPOCH))
+    torch.cuda.synchronize()
+    named = [(f"{mk}.{k}", p) for mk, m in tr.modules().items() for k, p in m.named_parameters()]
+    grads = {k: (p.grad.detach().cpu().numpy() / world).copy() for k, p in named}          # 1/world is folded into the SGD kernel
+    rstat = {f"{mk}.{k}": v.cpu().numpy().copy() for mk, m in tr.modules().items() for k, v in m.state_dict().items() if "running" in k}
+    return dict(loss=loss, grads=grads, init=init if rank == 0 else None, rstat=rstat)
+
+
+def _sharded_worker(rank, world, port, q, cuts):
+    _env(rank, world, port, "gloo")
+    import torch.distributed as dist
+    from seghiero_amd import ddp
+    ddp.init_from_env(backend="gloo")
+    try:
+        out = _sharded_step(cuts, rank, world)
+    except Exception as e:
+        import traceback
+        out = "rank %d failed: %s\n%s" % (rank, e, traceback.format_exc())
+    q.put((rank, out))
+    if not isinstance(out, str):
+        dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cuts", [[0, 2, 4], [0, 1, 4]])
+def test_ddp_sharded_step_with_syncbn_matches_oracle_ddp_statement(cuts):
+    """Two ranks, DIFFERENT shards (2 + 2 and 1 + 3 images of one seeded batch), SyncBN on, the whole trainer step (trunk, head, aux
+    head, 2-level loss with the live triplet term, backward with gradients handed over from inside the backward nodes, all-reduce)
+    against the oracle's statement of the data-parallel step (oracle/step.py:ddp_forward_loss: full-batch BatchNorm through trunk and
+    heads on CPU, per-shard losses with per-shard normalisers -- hiera_triplet_loss.py:41-107 num_valid, utils.py:20-21 all-pixel
+    mean --, per-shard triplets with the all-ranks `ready` rule of :193-198, mean over ranks; train.py:260-320):
+
+    * every rank's loss within 1e-4 ABSOLUTE of the oracle's loss for that shard;
+    * averaged gradients: head and aux-head tensors each within 3x the fp32 oracle's own distance from an fp64 run of the same
+      statement (+1e-4 of the tensor's scale; the yardstick of test_head_grouped_aspp_unit_matches_oracle: the image-pool BatchNorm
+      sees four samples per channel), the whole gradient vector (trunk included) within 4x (+1e-5);
+    * running statistics equal on both ranks and equal to the full-batch oracle's."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    import copy
+    import torch.multiprocessing as mp
+    from oracle.step import OracleTrainer
+    from seghiero_amd.synthetic import make_batch
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29050 + os.getpid() % 150 + cuts[1]
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q, cuts)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+    for r in res.values():
+        assert not isinstance(r, str), r
+    img, lab = make_batch(SH_B, SH_S, 4, seed=5)
+    ref = OracleTrainer(**TR_KW)
+    for k, m in ref.modules().items():
+        m.load_state_dict(res[0]["init"][k])
+    ref64 = OracleTrainer(**TR_KW)
+    for k, m in ref64.modules().items():
+        m.load_state_dict(res[0]["init"][k])
+        m.double()
+    ref.train(); ref64.train()
+    mean32, tot32, _, _ = ref.ddp_forward_loss(img, lab, SH_EPOCH, cuts)
+    mean32.backward()
+    mean64, _, _, _ = ref64.ddp_forward_loss(img.double(), lab, SH_EPOCH, cuts)
+    mean64.backward()
+    for r in (0, 1):
+        assert abs(res[r]["loss"] - float(tot32[r])) < 1e-4, (r, res[r]["loss"], float(tot32[r]))
+    names = [(f"{mk}.{k}", p) for mk, m in ref.modules().items() for k, p in m.named_parameters()]
+    g64 = {f"{mk}.{k}": p.grad.numpy() for mk, m in ref64.modules().items() for k, p in m.named_parameters()}
+    for k, _ in names:
+        np.testing.assert_array_equal(res[0]["grads"][k], res[1]["grads"][k])             # the all-reduce left both ranks with the same sums
+    bad = []
+    for k, p in names:
+        if k.startswith("backbone."):
+            continue
+        t = g64[k]
+        scale = max(float(np.abs(t).max()), 1e-3)
+        e_m = float(np.abs(res[0]["grads"][k] - t).max()) / scale
+        e_r = float(np.abs(p.grad.numpy() - t).max()) / scale
+        if not e_m < 3 * e_r + 1e-4:
+            bad.append((k, e_m, e_r))
+    assert not bad, bad
+    cat = lambda d: np.concatenate([np.asarray(d[k], np.float64).ravel() for k, _ in names])
+    e_m, e_r = _rel(cat(res[0]["grads"]), cat(g64)), _rel(cat({k: p.grad.numpy() for k, p in names}), cat(g64))
+    assert e_m < 4 * e_r + 1e-5, (e_m, e_r)
+    want = {f"{mk}.{k}": v.numpy() for mk, m in ref.modules().items() for k, v in m.state_dict().items() if "running" in k}
+    for k, v in want.items():
+        np.testing.assert_array_equal(res[0]["rstat"][k], res[1]["rstat"][k])
+        np.testing.assert_allclose(res[0]["rstat"][k], v, rtol=2e-4, atol=2e-6, err_msg=k)

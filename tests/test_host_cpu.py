@@ -156,10 +156,11 @@ def test_triplet_tables_and_factor():
     assert abs(triplet_factor(40000, 80000) - 0.25) < 1e-12
 
 
-def _ddp_worker(rank, world, port, q):
+def _ddp_worker(rank, world, port, q, small=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     import torch.distributed as dist
     from seghiero_amd import ddp
+    ddp.SMALL_GROUP = small
     ddp.init_from_env(backend="gloo")
     torch.manual_seed(0)
     params = [torch.nn.Parameter(torch.randn(s)) for s in [(7,), (64, 16, 3, 3), (13, 32, 1, 1), (300,)]]
@@ -175,6 +176,8 @@ def _ddp_worker(rank, world, port, q):
     # hand-over then stages nothing for it
     view = ddp.grad_buffer(params[3])
     assert view is not None and view.shape == params[3].shape and view.data_ptr() == sync.flat.data_ptr() + 4 * sync.views[id(params[3])][0]
+    assert (view.data_ptr() - sync.flat.data_ptr()) % 256 == 0 and view.data_ptr() % 16 == 0 and all(o % ddp.GradSync.ARENA_ALIGN == 0 for o, _ in sync.views.values())     # 16-byte stores of the wgrad kernels
+    assert ddp.grad_buffer(params[3]) is None        # a slice is handed out once per step (a second gradient must not overwrite the first)
     view.copy_(grads[3])
     ddp.early_flush([(params[3], view)])
     assert ddp.grad_buffer(params[3]) is None                                   # handed over: no second writer
@@ -187,8 +190,12 @@ def _ddp_worker(rank, world, port, q):
         p.grad = gr
     scale = sync.reduce(params)
     assert ddp._ACTIVE is None
-    # latency-class collectives run on their own process group (SyncBN sums + count in f64, triplet class_count MIN)
-    assert ddp.small_group() is not None and ddp.small_group() is not dist.group.WORLD
+    # latency-class collectives (SyncBN sums + count in f64, triplet class_count MIN): on the default group, or -- behind the
+    # SEGHIERO_SMALL_GROUP switch -- on a process group of their own
+    if small:
+        assert ddp.small_group() is not None and ddp.small_group() is not dist.group.WORLD
+    else:
+        assert ddp.small_group() is None
     sq = torch.tensor([1.0 + rank, 10.0 * (rank + 1), 5.0 + rank], dtype=torch.float64)      # [sum, sum^2, local count]
     ddp.all_reduce_small(sq)
     assert sq.tolist() == [3.0, 30.0, 11.0]
@@ -203,13 +210,14 @@ def _ddp_worker(rank, world, port, q):
     ddp.shutdown()
 
 
-def test_gradsync_two_ranks_gloo():
+@pytest.mark.parametrize("small", [False, True])
+def test_gradsync_two_ranks_gloo(small):
     """N>1 path on CPU: bucketed all-reduce over gloo == sum of the per-rank gradients; broadcast from rank 0."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + os.getpid() % 200
-    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29600 + os.getpid() % 200 + (211 if small else 0)
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q, small)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])

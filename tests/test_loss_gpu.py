@@ -283,6 +283,28 @@ def test_rmi_triplet_g7(sa):
     close(emb.grad, g["demb"], 1e-4, 1e-8)
 
 
+def test_rmi_triplet_strict_mirrors_reference_value_error(sa):
+    """rmi_tree_triplet_loss.py:39: a label on the embedding grid that is in neither hard-coded group makes ``list.remove`` raise
+    ValueError.  strict=True reproduces that (one host sync); the default skips such a class as an anchor without synchronising."""
+    _, loss, ops = sa
+    g = load_golden("g7_rmi_triplet")
+    emb = T(g["emb"]).to(DEV)
+    labels = lab(g["lab"]).to(DEV).clone()
+    strict = loss.RMITreeTripletLoss(7, [1, 2, 3, 4], [5, 6], strict=True)
+    val, cnt = strict(emb, labels)                                    # every label in a group: same result as the default
+    assert np.array_equal(cnt.cpu().numpy(), g["cnt"])
+    close(val, g["val"], 1e-5, 0)
+    H, W = labels.shape[-2:]
+    labels[0, (3 * H) // emb.shape[2], (2 * W) // emb.shape[3]] = 8   # a pixel the nearest-neighbour resize picks (row 3, column 2)
+    with pytest.raises(ValueError, match="not in list"):
+        strict(emb, labels)
+    val2, cnt2 = loss.RMITreeTripletLoss(7, [1, 2, 3, 4], [5, 6])(emb, labels)      # default: class 8 is never an anchor
+    assert int(cnt2) <= int(g["cnt"][0]) and (val2 is None or torch.isfinite(val2))
+    labels[0, (3 * H) // emb.shape[2], (2 * W) // emb.shape[3]] = 2
+    labels[0, 1, 1] = 8 if (H // emb.shape[2]) > 1 else 2           # a pixel the resize never reads: no error
+    strict(emb, labels)
+
+
 def test_rmi_loss_fused_resize_matches_oracle(sa):
     """Low-resolution logits + fused x4 resize (the train-step path) vs oracle(F.interpolate(...))."""
     _, loss, ops = sa

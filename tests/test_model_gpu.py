@@ -146,20 +146,80 @@ def test_head_grouped_aspp_unit_matches_oracle(sa, hw, c4hw):
             assert err < 2e-2, (k, err)          # i.e. within 2e-5 absolute of autograd's cancellation-noise value
 
 
+def test_grouped_aspp_zero_centre_tap_gets_its_true_gradient(sa):
+    """A depthwise centre tap that is exactly 0 (zero-initialised / pruned weights) on a centre-tap ASPP branch: dgamma carries no
+    trace of it (dgamma = w * isy * S), so sh_dw_center_wgrad forms S = sum g * (x - mean_x) for that channel from the masked
+    gradient itself.  Against autograd of the oracle head: 1e-3 of the tensor's scale for the zeroed channels; the other channels
+    keep the closed form (test_head_grouped_aspp_unit_matches_oracle)."""
+    from oracle import nets
+    from seghiero_amd.head import DepthwiseSeparableASPPContrastHead
+    kw = dict(in_channels=64, c1_in_channels=16, c1_channels=8, aspp_channels=128, dilations=(1, 12, 24, 36), num_classes=6,
+              proj_dim=8, proj_type="convmlp")
+    torch.manual_seed(6)
+    ref = nets.DepthwiseSeparableASPPContrastHead(**kw).train()
+    for m in ref.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            torch.nn.init.uniform_(m.weight, 0.5, 1.5)
+            torch.nn.init.normal_(m.bias, 0.0, 0.2)
+    zeroed = [3, 17, 40]
+    with torch.no_grad():
+        for c in zeroed:
+            ref.aspp.branches[2][0].depthwise.weight[c, 0, 1, 1] = 0.0           # dilation 24 at 16 x 16: centre tap only
+        ref.aspp.branches[2][0].bn_dw.bias[zeroed[0]] = 0.3                      # beta > 0: the ReLU passes, gradient non-zero
+        ref.aspp.branches[2][0].bn_dw.bias[zeroed[1]] = 0.2
+        ref.aspp.branches[2][0].bn_dw.bias[zeroed[2]] = -0.2                     # beta < 0: masked, gradient exactly 0
+    mine = DepthwiseSeparableASPPContrastHead(**kw)
+    _sync_modules(mine, ref)
+    mine.to(DEV).train()
+    g = torch.Generator().manual_seed(18)
+    c1 = torch.randn(4, 16, 64, 64, generator=g)
+    c4 = torch.relu(torch.randn(4, 64, 16, 16, generator=g))
+    lr_, er = ref([c1, None, None, c4])
+    gl, ge = torch.randn(lr_.shape, generator=g), torch.randn(er.shape, generator=g)
+    ((lr_ * gl).sum() + (er * ge).sum()).backward()
+    lm, em = mine([c1.to(DEV), None, None, c4.to(DEV)])
+    ((lm * gl.to(DEV)).sum() + (em * ge.to(DEV)).sum()).backward()
+    want = ref.aspp.branches[2][0].depthwise.weight.grad[:, 0, 1, 1]
+    got = mine.aspp.branches[2][0].depthwise.weight.grad[:, 0, 1, 1].cpu()
+    scale = float(want.abs().max())
+    assert float(want[zeroed[0]].abs()) > 1e-3 * scale                           # the case is not vacuous
+    for c in zeroed:
+        assert abs(float(got[c]) - float(want[c])) < 1e-3 * scale, (c, float(got[c]), float(want[c]))
+    assert float(got[zeroed[2]]) == 0.0
+
+
 def _sync_modules(dst, src):
     dst.load_state_dict({k: v.clone() for k, v in src.state_dict().items()})
 
 
+def _trunk_with_pinned_masks(net, x, masks):
+    """Forward of the oracle trunk with every ReLU replaced by multiplication with the given 0/1 mask (forward order: stem, then
+    one per conv of every block) -> (c1..c4, pre-activations)."""
+    it = iter(masks)
+    pres = []
+    h = net.stem_bn(net.stem_conv(x))
+    pres.append(h)
+    h = net.stem_pool(h * next(it).to(h.dtype))
+    outs = []
+    for li in range(1, 5):
+        for blk in getattr(net, f"layer{li}"):
+            n = 3 if hasattr(blk, "conv3") else 2
+            h, pre = _block_with_pinned_masks(blk, h, [next(it) for _ in range(n)])
+            pres += pre
+        outs.append(h)
+    return outs, pres
+
+
 @pytest.mark.parametrize("depth,size", [(18, 64), (50, 96), (50, 128)])
 def test_backbone_matches_oracle(sa, depth, size):
-    """fp32 HIP trunk vs the oracle.  Tolerance is principled: an fp64 run of the oracle is the ground truth, and the
-    HIP result must be no further from it than 4x the oracle's own fp32 rounding error (+1e-6).  For parameter
-    gradients the bound must hold for >= 95 % of the tensors and for the concatenated gradient as a whole: with
-    only 12-24 samples per BatchNorm channel in layer4 at these tiny inputs, a single ReLU whose pre-activation
-    rounds to the other side of 0 moves one channel's gradient by O(1/12) in EITHER fp32 implementation.
-    (A 64x96 input -- 12 samples per layer4 channel -- is past that edge: whether it passes depends on the summation
-    order of layer4's convs, e.g. it flips with the split-K slices on or off (SEGHIERO_SPLITK), so the sizes used here
-    keep >= 24 samples per channel.)"""
+    """fp32 HIP trunk (the real autograd node, every fusion on) vs the oracle, end to end, EVERY tensor, no allowance.
+
+    Ground truth is an fp64 run of the oracle; the HIP result must be no further from it than 4x the fp32 oracle's own distance
+    (+1e-6 outputs / buffers, +1e-5 gradients).  A ReLU whose pre-activation two fp32 evaluations round to different sides of 0
+    moves every upstream gradient by O(1e-4) in EITHER implementation (which is what a "95 % of the tensors" rule used to absorb),
+    so the two torch evaluations use the HIP forward's own ReLU masks (ResNetBackbone.export_relu_masks); the masks themselves must
+    agree with the fp64 pre-activations except where those are numerically zero (|pre| < 1e-3 of O(1) values after up to 50 layers
+    of fp32 rounding).  With the masks pinned no drift source is left."""
     import copy
     from oracle import nets
     from seghiero_amd.backbone import ResNetBackbone
@@ -170,26 +230,32 @@ def test_backbone_matches_oracle(sa, depth, size):
     _sync_modules(mine, ref)
     mine.to(DEV).train()
     x = torch.randn(2, 3, size, size + 32)
-    outs_r = ref(x)
-    gs = [torch.randn(o.shape) for o in outs_r]
-    sum((o * g).sum() for o, g in zip(outs_r, gs)).backward()
-    outs_64 = ref64(x.double())
-    sum((o * g.double()).sum() for o, g in zip(outs_64, gs)).backward()
+    masks = []
+    mine.export_relu_masks(masks)
     outs_m = mine(x.to(DEV))
+    mine.export_relu_masks(None)
+    masks = [m.cpu() for m in masks]
+    gs = [torch.randn(o.shape) for o in outs_m]
     sum((o * g.to(DEV)).sum() for o, g in zip(outs_m, gs)).backward()
+    outs_r, _ = _trunk_with_pinned_masks(ref, x, masks)
+    sum((o * g).sum() for o, g in zip(outs_r, gs)).backward()
+    outs_64, pre64 = _trunk_with_pinned_masks(ref64, x.double(), masks)
+    sum((o * g.double()).sum() for o, g in zip(outs_64, gs)).backward()
+    flips = 0
+    for k, (pre, m) in enumerate(zip(pre64, masks)):
+        bad = (pre.detach() > 0) != m
+        flips += int(bad.sum())
+        assert (not bool(bad.any())) or float(pre.detach()[bad].abs().max()) < 1e-3, (k, float(pre.detach()[bad].abs().max()))
     for i, (a, b, t) in enumerate(zip(outs_m, outs_r, outs_64)):
         assert a.shape == b.shape
         assert relerr(a, t) < 4 * relerr(b, t) + 1e-6, (i, relerr(a, t), relerr(b, t))
     gm, g64 = dict(mine.named_parameters()), dict(ref64.named_parameters())
-    bad, names = [], [k for k, _ in ref.named_parameters()]
+    rows = []
     for k, p in ref.named_parameters():
         e_m, e_r = relerr(gm[k].grad, g64[k].grad), relerr(p.grad, g64[k].grad)
-        if not e_m < 4 * e_r + 1e-5:
-            bad.append((k, e_m, e_r))
-    assert len(bad) <= 0.05 * len(names), bad
-    cat = lambda d: torch.cat([d[k].grad.detach().cpu().double().flatten() for k in names])
-    e_m, e_r = relerr(cat(gm), cat(g64)), relerr(cat(dict(ref.named_parameters())), cat(g64))
-    assert e_m < 4 * e_r + 1e-5, (e_m, e_r)
+        rows.append((e_m / (4 * e_r + 1e-5), k, e_m, e_r))
+    rows.sort(reverse=True)
+    assert rows[0][0] < 1.0, (rows[:5], flips)
     for k, v in ref64.state_dict().items():
         if v.dtype.is_floating_point:
             assert relerr(mine.state_dict()[k], v) < 4 * relerr(ref.state_dict()[k], v) + 1e-6, k
@@ -337,18 +403,19 @@ def test_train_steps_match_oracle_config1(sa):
         if step == 0:
             assert abs(lm - l32) < 1e-4, (lm, l32)
         assert abs(lm - l64) < (4 if step < 2 else 10) * abs(l32 - l64) + 1e-4 * max(1.0, abs(l64)), (step, lm, l32, l64)
-    bad, total = [], 0
+    # state after the three steps, module by module (all weights and BatchNorm buffers of a module as ONE vector, no allowance): the
+    # HIP trajectory is no further from the fp64 one than 4x the fp32 oracle's.  (Per tensor, a three-step batch-4 trajectory only
+    # measures which ReLUs flipped; every tensor is held to the bound where masks can be pinned or the batch is large --
+    # test_backbone_matches_oracle, test_bench_configuration_b16_step0_matches_oracle, the reference-golden head test.)
     for name, m in ref64.modules().items():
         sm, s32 = mine.modules()[name].state_dict(), ref.modules()[name].state_dict()
+        keys = [k for k, v in m.state_dict().items() if v.dtype.is_floating_point]
+        cat = lambda d: torch.cat([d[k].detach().cpu().double().flatten() for k in keys])
+        e_m, e_r = relerr(cat(sm), cat(m.state_dict())), relerr(cat(s32), cat(m.state_dict()))
+        assert e_m < 4 * e_r + 1e-5, (name, e_m, e_r)
         for k, v in m.state_dict().items():
-            if v.dtype.is_floating_point:
-                total += 1
-                e_m, e_r = relerr(sm[k], v), relerr(s32[k], v)
-                if not e_m < 4 * e_r + 1e-5:
-                    bad.append((name, k, e_m, e_r))
-            else:
+            if not v.dtype.is_floating_point:
                 assert torch.equal(sm[k].cpu(), v), (name, k)
-    assert len(bad) <= 0.05 * total, bad
     # validation step: loss + pixel-accuracy counts (train.py:341-393)
     for k, m in ref.modules().items():
         mine.modules()[k].load_state_dict(m.state_dict())
@@ -436,6 +503,68 @@ def test_config2_full_size_step0_matches_oracle(sa):
     sm, sr = mine.aspp_head.state_dict(), ref.modules()["aspp_head"].state_dict()
     for k in ("cls_seg.weight", "sep_bottleneck.1.pointwise.weight", "sep_bottleneck.0.depthwise.weight", "c1_bottleneck.0.weight"):
         assert relerr(sm[k], sr[k]) < 1e-3, (k, relerr(sm[k], sr[k]))
+
+
+def test_bench_configuration_b16_step0_matches_oracle(sa):
+    """The bench's OWN configuration, built by bench.py's own functions (make_trainer: manual_seed(0) default init; make_inputs:
+    make_batch(16, 512, 9, seed=0)): ResNet-50, 9 fine / 4 coarse, 512 x 512, batch 16.  The CPU oracle gets the same weights and
+    inputs (fp32, and an fp64 copy as ground truth; ~1 min of CPU time on the GPU box).
+
+    * step-0 main / aux loss (training-mode forward) and the training step's total: |HIP - oracle| <= 1e-4 ABSOLUTE -- the total is
+      the `loss_step0` bench.py prints;
+    * after that ONE SGD step: EVERY parameter gradient and EVERY updated parameter tensor, trunk included, no allowance, within 4x
+      the fp32 oracle's own distance from the fp64 run (+1e-5 relative for gradients, +1e-7 for parameters: the fp32 representation
+      floor).  At batch 16 the image-pool BatchNorm has 16 samples per channel, so the batch-2 excuse of
+      test_config2_full_size_step0_matches_oracle does not apply."""
+    import bench
+    from oracle.step import OracleTrainer
+    kw = dict(depth=bench.CFG["depth"], n_fine=bench.CFG["n_fine"], coarse_to_fine_map=bench.CFG["coarse_to_fine_map"], lr=0.01)
+    mine = bench.make_trainer(torch.device(DEV))
+    init = {k: {n: v.detach().cpu().clone() for n, v in m.state_dict().items()} for k, m in mine.modules().items()}
+    ref = OracleTrainer(**kw)
+    for k, m in ref.modules().items():
+        m.load_state_dict(init[k])
+    ref64 = _oracle64(ref, kw)
+    ref.train(); ref64.train(); mine.train()
+    img, lab = bench.make_inputs(bench.CFG["batch"], 0, "cpu")
+    assert tuple(img.shape) == (16, 3, 512, 512)
+
+    def manual_step(tr, x):
+        tr.optimizer.zero_grad()
+        loss, m, a, _ = tr.forward_loss(x, lab, 0)
+        loss.backward()
+        tr.optimizer.step()
+        return float(loss), float(m), float(a)
+
+    l_r, m_r, a_r = manual_step(ref, img)
+    l_64, _, _ = manual_step(ref64, img.double())
+    xg, lg = img.to(DEV), lab.to(DEV)
+    with torch.no_grad():
+        _, m_m, a_m, _ = mine.forward_loss(xg, lg, 0)
+    for k, m in mine.modules().items():          # the probe forward moved the BatchNorm running statistics and `step`: back to the start
+        m.load_state_dict(init[k])
+    l_m = float(mine.train_step(xg, lg, 0))
+    print(f"bench configuration step 0: HIP {l_m:.6f}  oracle fp32 {l_r:.6f}  fp64 {l_64:.6f}")
+    assert abs(float(m_m) - m_r) < 1e-4, (float(m_m), m_r)
+    assert abs(float(a_m) - a_r) < 1e-4, (float(a_m), a_r)
+    assert abs(l_m - l_r) < 1e-4, (l_m, l_r)
+    rows = []
+    for name, mod64 in ref64.modules().items():
+        pm_, p32 = dict(mine.modules()[name].named_parameters()), dict(ref.modules()[name].named_parameters())
+        for k, p64 in mod64.named_parameters():
+            e_m, e_r = relerr(pm_[k].grad, p64.grad), relerr(p32[k].grad, p64.grad)
+            rows.append((e_m / (4 * e_r + 1e-5), f"{name}.{k}.grad", e_m, e_r))
+            e_m, e_r = relerr(pm_[k], p64), relerr(p32[k], p64)
+            rows.append((e_m / (4 * e_r + 1e-7), f"{name}.{k}", e_m, e_r))
+        sm, s32 = mine.modules()[name].state_dict(), ref.modules()[name].state_dict()
+        for k, v in mod64.state_dict().items():
+            if "running" in k:
+                rows.append((relerr(sm[k], v) / (4 * relerr(s32[k], v) + 1e-6), f"{name}.{k}", relerr(sm[k], v), relerr(s32[k], v)))
+            elif not v.dtype.is_floating_point:
+                assert torch.equal(sm[k].cpu(), v), (name, k)
+    rows.sort(reverse=True)
+    print("worst ratios:", rows[:6])
+    assert rows[0][0] < 1.0, rows[:8]
 
 
 @pytest.mark.parametrize("cfg", ["C4", "C5"])
