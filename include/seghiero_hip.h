@@ -281,7 +281,9 @@ int sh_bn_act(const float* y, int ldy, const float* scale, const float* shift, c
  * finalize: dgamma, dbeta; apply: dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)), optionally dres = g.
  * Deferred second half: reduce can also STORE g (g_out, 16-byte layouts only, else SH_EUNSUPPORTED) and finalize can emit
  * lin[4][C] = (A, B, mean, D) with dy = A*g + B*(y - mean) + D; the 1x1 consumers of dy (sh_conv_dgrad_x6_lin,
- * sh_conv_wgrad_x6_lin) then evaluate dy in their loaders and sh_bn_bwd_apply / the dy tensor are skipped. */
+ * sh_conv_wgrad_x6_lin) then evaluate dy in their loaders and sh_bn_bwd_apply / the dy tensor are skipped.
+ * act_flags (16-byte layouts): bit 0 y, 1 out stored as bf16; bf16 COMPUTE mode also stores gradients as bf16: bit 2 dout, bit 3 g_out
+ * (reduce) / dy (apply), bit 4 dres (apply). */
 int sh_bn_bwd_reduce(const float* dout, int lddo, const float* out, int ldo, const float* y, int ldy,
                      const float* mean, const float* invstd, const float* scale, const float* shift,
                      float* partials, int64_t M, int C, int relu, float* g_out, int ldg, int act_flags, void* stream);
@@ -421,6 +423,38 @@ int sh_sgd_step(int n_tensors, float* const* w, const float* const* g, float* co
 int sh_fill(float* p, float v, int64_t n, void* stream);
 int sh_axpy(float* y, const float* x, float a, int64_t n, void* stream);   /* y += a*x */
 int sh_copy(void* dst, const void* src, int64_t bytes, void* stream);      /* async device-to-device copy */
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * bf16 COMPUTE mode (BASELINE configs[4]: "bf16 storage / f32 accumulate"; seghiero_amd/csrc/conv_b16.hip).  Operands are rounded once
+ * to bf16 on their way to LDS (after the producer's BatchNorm + ReLU where that runs in the loader), ONE MFMA product per tile instead
+ * of six, fp32 accumulators, BatchNorm statistics from the fp32 accumulators, fp32 weight gradients / master weights / SGD.
+ * Activations are bf16 tensors (pixel strides count elements, multiples of 8; 16-byte aligned rows); gradients w.r.t. activations are
+ * bf16 or fp32 tensors.  Same reference op chains as the sh_conv_*_x6* entry points (models/backbone/resnet.py:65-73 via torchvision,
+ * models/head/sep_aspp_contrast_head.py:43-62, 100-131, 172-191).  SH_EUNSUPPORTED = no instantiation for the geometry, nothing
+ * launched: run the fp32-accurate entry point. */
+/* bf16 copies of n (<= 40) dense conv weights [Cout][taps][Cin] fp32 (OHWI): wb[i] = the same layout in bf16 (forward operand),
+ * wtb[i] = [taps][Cin][pad8(Cout)] bf16, zero padded (input-gradient operand); entries of wb / wtb may be NULL.  Host arrays of device pointers. */
+int sh_weights_to_bf16_multi(int n, const float* const* w, void* const* wb, void* const* wtb, const int* cout, const int* taps,
+                             const int* cin, void* stream);
+/* act_flags bit 1: y stored as bf16 (else fp32).  in_scale / in_shift (both or neither): x read as relu(x * scale + shift). */
+int sh_conv_fprop_b16(const void* x, int ldx, const float* in_scale, const float* in_shift, const void* w_bf16, const float* bias,
+                      void* y, int ldy, float* stat_partials, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                      int pad, int dil, float* workspace, int64_t workspace_bytes, int act_flags, void* stream);
+int sh_conv1x1_grouped_fprop_b16(int ngroups, const void* const* x, const int* ldx, const float* const* in_scale,
+                                 const float* const* in_shift, const void* const* w_bf16, void* y, int ldy, float* stat_partials,
+                                 int N, int H, int W, int Cin, int Cout, int act_flags, void* stream);
+/* act_flags: bit 0 dy is bf16 (else fp32), 1 dx stored bf16, 2 addend bf16, 3 y_prev bf16, 4 out_prev bf16, 5 out_prev = ReLU quad mask.
+ * y_lin / lin (both or neither, 1x1 only, dy = the masked gradient g in bf16): operand = lin(g, y_lin) as sh_conv_dgrad_x6_lin.
+ * y_prev != NULL: BatchNorm-backward epilogue as sh_conv_dgrad_x6_bnb. */
+int sh_conv_dgrad_b16(const void* dy, int lddy, const void* y_lin, int ldyl, const float* lin, const void* wt_bf16, const void* addend,
+                      int ldadd, void* dx, int lddx, const void* y_prev, int ldyp, const void* out_prev, int ldop, const float* mean,
+                      const float* invstd, const float* scale, const float* shift, int relu, float* stat_partials, int N, int H,
+                      int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, float* workspace,
+                      int64_t workspace_bytes, int act_flags, void* stream);
+/* act_flags bit 0: dy is bf16 (else fp32).  workspace: sh_conv_wgrad_x6_workspace(...) bytes. */
+int sh_conv_wgrad_b16(const void* x, int ldx, const float* in_scale, const float* in_shift, const void* dy, int lddy, const void* y_lin,
+                      int ldyl, const float* lin, float* dw, float* workspace, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                      int stride, int pad, int dil, int act_flags, void* stream);
 
 #ifdef __cplusplus
 }

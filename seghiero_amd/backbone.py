@@ -91,14 +91,17 @@ def _block_fwd(blk, x, training):
     return h, (recs, ds_rec)
 
 
-def _block_bwd(blk, saved, dout, gm, prev_rec=None, extra=None):
+def _block_bwd(blk, saved, dout, gm, prev_rec=None, extra=None, in32=False):
     """dout: gradient w.r.t. the block output (tensor, or a GradPack made by the NEXT block's first conv).  prev_rec: last CBARec of
     the previous block when this block's input is that block's output and no downsample path adds into the input gradient -- the
     first conv's dgrad epilogue then runs the front half of that block's bn3 backward (mask from its `out`) and the identity
     gradient needs no separate tensor.  extra (blocks with a downsample path only): a tensor of the input's shape summed into the
-    input gradient by the first conv's dgrad epilogue -- the previous stage's own output gradient (c1 / c3 feed the head)."""
+    input gradient by the first conv's dgrad epilogue -- the previous stage's own output gradient (c1 / c3 feed the head).
+    in32 (bf16 compute mode): the block's input gradient goes to an fp32-only consumer (the max-pool backward)."""
     recs, ds_rec = saved
     chain = blk.chain()
+    # a strided downsample branch scatters into the input gradient with the fp32-accurate kernel: that tensor is fp32 then
+    in32 = in32 or (ds_rec is not None and blk.downsample[0].stride[0] > 1)
     # last conv: g = dout * relu-mask feeds BN backward AND (as dres) the identity / downsample path
     conv, bn = chain[-1]
     d, dw, dg, db, dres = L.cba_bwd(recs[-1], bn, dout, need_dx=True, want_dres=True)
@@ -108,14 +111,14 @@ def _block_bwd(blk, saved, dout, gm, prev_rec=None, extra=None):
         first = i == 0
         addend = dres if (first and ds_rec is None) else (extra if first else None)      # identity path summed in the dgrad epilogue
         d, dw, dg, db, _ = L.cba_bwd(recs[i], bn, d, need_dx=True, addend=addend,
-                                     pack_for=prev_rec if (first and ds_rec is None) else None)
+                                     pack_for=prev_rec if (first and ds_rec is None) else None, dx32=first and in32)
         gm.put(conv.weight, dw); gm.put(bn.weight, dg); gm.put(bn.bias, db)
     if ds_rec is not None:
         dconv, dbn = blk.downsample[0], blk.downsample[1]
         if dconv.stride[0] > 1:
             _, dw, dg, db, _ = L.cba_bwd(ds_rec, dbn, dres, scatter_into=d)          # accumulate at strided pixels
         else:
-            d, dw, dg, db, _ = L.cba_bwd(ds_rec, dbn, dres, need_dx=True, addend=d)
+            d, dw, dg, db, _ = L.cba_bwd(ds_rec, dbn, dres, need_dx=True, addend=d, dx32=in32)
         gm.put(dconv.weight, dw); gm.put(dbn.weight, dg); gm.put(dbn.bias, db)
     return d
 
@@ -154,7 +157,10 @@ class _BackboneFn(torch.autograd.Function):
         # act_dtype = torch.bfloat16 (training only): the trunk's raw conv outputs and block outputs are STORED as bf16 -- half the
         # bytes of every activation read and write; arithmetic, BatchNorm statistics and gradients stay fp32 (BASELINE configs[4])
         stored = mod.act_dtype if (training and L.FUSE_BN and ops.CONV_IMPL == "x6") else torch.float32
-        with ops.stored_as(stored):
+        # compute_dtype = torch.bfloat16 (with bf16 storage): ONE bf16 MFMA product per tile on operands rounded once to bf16 in the
+        # loaders (csrc/conv_b16.hip) instead of the fp32-accurate six-product plan; stage outputs are then handed on as bf16 tensors
+        compute = mod.compute_dtype if stored == torch.bfloat16 else torch.float32
+        with ops.stored_as(stored), ops.compute_as(compute):
             s_out, s_rec = L.cba_fwd(x4, wpad, L.conv_geom(mod.stem_conv), mod.stem_bn, True, training, lazy=True)
             if isinstance(s_out, L.Lazy):          # stem_bn + stem_relu run in the pooling kernel's loader
                 pooled, pool_idx = ops.maxpool_fwd(s_out.y, want_argmax=training, aff=s_out.coefs)
@@ -169,7 +175,7 @@ class _BackboneFn(torch.autograd.Function):
                 outs.append(h)
         if mod.__dict__.get("_relu_mask_sink") is not None:                 # parity tests only (ResNetBackbone.export_relu_masks)
             mod.__dict__["_relu_mask_sink"].extend(_relu_masks(s_rec, saved))
-        outs = [o if o.dtype == torch.float32 else o.float() for o in outs]      # the head and the aux head take fp32 stage outputs
+        outs = [o if o.dtype == torch.float32 else o.float() for o in outs]          # the head and aux head take fp32 stage outputs
         if training:
             L.bump_bn_counters(_all_bns(mod))
         if training:
@@ -177,12 +183,18 @@ class _BackboneFn(torch.autograd.Function):
         ctx.mod, ctx.saved, ctx.stem = mod, saved, (x4, wpad, s_rec, pool_idx, tuple(s_out.shape[2:]))
         ctx.training = training
         ctx.params = params
+        ctx.compute = compute
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *douts):
         if not ctx.training:
             raise SegHieroHipError("backward through eval-mode BatchNorm is not on the SegHiero hot path")
+        with ops.compute_as(ctx.compute):
+            return _BackboneFn._backward(ctx, *douts)
+
+    @staticmethod
+    def _backward(ctx, *douts):
         mod, saved = ctx.mod, ctx.saved
         gm = L.GradMap()
         layers = [mod.layer1, mod.layer2, mod.layer3, mod.layer4]
@@ -199,6 +211,9 @@ class _BackboneFn(torch.autograd.Function):
                 if d is None:
                     d = g
                 else:
+                    if isinstance(d, L.GradPack):
+                        raise SegHieroHipError("a packed gradient cannot take a stage gradient (STAGE_GRAD_IN_EPILOGUE covers this case)")
+                    d = ops.f32(d)
                     ops._call("sh_axpy", d.data_ptr(), _dense(g).data_ptr(), 1.0, d.numel(), ops._st())
             if d is None:
                 continue
@@ -212,12 +227,12 @@ class _BackboneFn(torch.autograd.Function):
                 lp = blocks[idx - 1][0]
                 extra = L.grad_as_nhwc_padded(douts[lp], douts[lp].shape[1])
                 summed.add(lp)
-            d = _block_bwd(blk, saved[idx], d, gm, prev_rec, extra)
+            d = _block_bwd(blk, saved[idx], d, gm, prev_rec, extra, in32=idx == 0)
             if idx == 0 or blocks[idx - 1][0] != li:                      # first block of a stage: the stage's gradients are final
                 gm.flush(L.params_of(layers[li]))
         if d is not None:
             x4, wpad, s_rec, pool_idx, (sh, sw) = ctx.stem
-            dpool = ops.maxpool_bwd(pool_idx, d, sh, sw)
+            dpool = ops.maxpool_bwd(pool_idx, ops.f32(d), sh, sw)
             _, dwp, dg, db, _ = L.cba_bwd(s_rec, mod.stem_bn, dpool, need_dx=False)
             dw = L.new_grad(mod.stem_conv.weight)
             ops.join_wgrad()                                               # dwp comes from the weight-gradient stream
@@ -269,6 +284,7 @@ class ResNetBackbone(nn.Module):
         # storage type of the trunk's activations in training (not a reference argument): torch.float32, or torch.bfloat16 =
         # BASELINE configs[4]'s bf16 activation storage (see _BackboneFn.forward); set the attribute after construction
         self.act_dtype = torch.float32
+        self.compute_dtype = torch.float32      # torch.bfloat16 (needs act_dtype = bfloat16): bf16 compute mode, see _BackboneFn.forward
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")

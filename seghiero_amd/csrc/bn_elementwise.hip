@@ -564,8 +564,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partials_v4_kernel(const float* __
         for (int k = 0; k < STAT_ROWS / 16; ++k) {
             const long long r = rbeg + rl + 16 * k;
             if (r < M) {
-                f32x4 g = ld4(dout + r * lddo + c);
-                const f32x4 yv = lda4(y, r * ldy + c, af & 1);            // af: bit 0 y, 1 out stored as bf16
+                f32x4 g = lda4(dout, r * lddo + c, af & 4);                 // af: bit 0 y, 1 out, 2 dout, 3 g_out stored as bf16
+                const f32x4 yv = lda4(y, r * ldy + c, af & 1);
                 if (relu == 1) {
                     const f32x4 o = lda4(out, r * ldo + c, af & 2);
 #pragma unroll
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partials_v4_kernel(const float* __
                 }
                 s += g;
                 q += g * ((yv - mu) * is);
-                if (g_out) st4(g_out + r * ldg + c, g);
+                if (g_out) sta4(g_out, r * ldg + c, g, af & 8);
             }
         }
     }
@@ -725,8 +725,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const long long m = m0 + r;
         const int c = (e - r * cv) * V;
         if (V == 4) {
-            f32x4 g = ld4(dout + m * lddo + c);
-            const f32x4 yv = lda4(y, m * ldy + c, af & 1);                // af: bit 0 y, 1 out stored as bf16
+            f32x4 g = lda4(dout, m * lddo + c, af & 4);                     // af: bit 0 y, 1 out, 2 dout, 3 dy, 4 dres stored as bf16
+            const f32x4 yv = lda4(y, m * ldy + c, af & 1);
             if (relu == 1) {
                 const f32x4 o = lda4(out, m * ldo + c, af & 2);
 #pragma unroll
@@ -745,8 +745,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             f32x4 ga = {1.f, 1.f, 1.f, 1.f};
             if (gamma) ga = ld4(gamma + c);
             const f32x4 r = ga * is * (g - ld4(c1 + c) - xh * ld4(c2 + c));
-            st4(dy + m * lddy + c, r);
-            if (dres) st4(dres + m * lddres + c, g);
+            sta4(dy, m * lddy + c, r, af & 8);
+            if (dres) sta4(dres, m * lddres + c, g, af & 16);
         } else {
             float g = dout[m * lddo + c];
             const float yv = y[m * ldy + c];

@@ -17,7 +17,7 @@ for part in 3 4 5 6 1 2; do
   fi
   OBJS+=("conv_x6p_$part.o")
 done
-for f in conv_gemm conv_bf16x6 bn_elementwise pool_resample dwconv loss loss3 sgd; do
+for f in conv_b16 conv_gemm conv_bf16x6 bn_elementwise pool_resample dwconv loss loss3 sgd; do
   if stale "$f.o" "$f.hip"; then
     $HIPCC $FLAGS -c "$f.hip" -o "$f.o" &
     pids+=($!)

@@ -797,7 +797,7 @@ extern "C" int sh_weight_transpose_multi(int n, const float* const* w, float* co
 // BatchNorm backward (BNB: g = relumask * dx stored, (sum g, sum g*xhat) per 64 rows -> partials, see conv_x6p.hip).
 // Block = 64 rows x 64 columns, thread = 4 rows x 4 columns.
 struct BnbQ { const float* y; long long ldy; const float* mean; const float* invstd; const float* scale; const float* shift; int relu; const float* out; long long ldo;
-              int act; };      // act: ConvQ::act (bit 1 the fprop output, 2 y, 3 out stored as bf16)
+              int act; int out_bf, add_bf; };      // act: ConvQ::act (bit 2 y, 3 out stored as bf16); out_bf / add_bf: the output / addend are bf16 tensors
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, long long ldslab, int S, long long M, int Nn,
                                                             const float* __restrict__ bias, const float* __restrict__ addend, long long ldadd,
                                                             float* __restrict__ out, long long ldc, float* __restrict__ partials, const BnbQ bnb) {
@@ -820,7 +820,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             for (int s2 = 0; s2 < S; ++s2) v[k] += ld4(slab + ((long long)s2 * M + m) * ldslab + n);
             f32x4 o = v[k];
             if (bias) o += ld4(bias + n);
-            if (addend) o += ld4(addend + m * ldadd + n);
+            if (addend) o += lda4(addend, m * ldadd + n, bnb.add_bf);
             if (bnb.y != nullptr) {
                 const f32x4 yv = lda4(bnb.y, m * bnb.ldy + n, bnb.act & 4);
                 if (bnb.relu) {
@@ -833,7 +833,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                 v[k] = o;                                                // statistics of g, not of the raw sum
                 gq += o * ((yv - b_mu) * b_is);
             }
-            sta4(out, m * ldc + n, o, bnb.y == nullptr ? (bnb.act & 2) : 0);       // (a bf16 output exists for fprop only; the statistics below use the fp32 sums)
+            sta4(out, m * ldc + n, o, bnb.out_bf);       // (the statistics below use the fp32 sums)
         }
     }
     if (partials == nullptr) return;         // block-uniform
@@ -873,7 +873,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // reduce launch shared with conv_x6p.hip
 int sh_x6_splitk_reduce(const ConvQ& p, int mode, hipStream_t st) {
     dim3 rg((unsigned)sh_cdiv(p.M, 64), (unsigned)sh_cdiv(p.Nn, 64));
-    BnbQ bnb{p.bnb_y, p.bnb_ldy, p.bnb_mean, p.bnb_invstd, p.bnb_scale, p.bnb_shift, p.bnb_relu, p.bnb_out, p.bnb_ldo, mode == FPROP ? p.act : (p.act & ~2)};
+    BnbQ bnb{p.bnb_y, p.bnb_ldy, p.bnb_mean, p.bnb_invstd, p.bnb_scale, p.bnb_shift, p.bnb_relu, p.bnb_out, p.bnb_ldo, mode == FPROP ? p.act : (p.act & ~2),
+             mode == FPROP ? (p.act & 2) : (p.act & 128), mode == DGRAD ? (p.act & 256) : 0};
     splitk_reduce_kernel<<<rg, 256, 0, st>>>(p.slab, p.ldslab, p.ksplit, p.M, p.Nn, mode == FPROP ? p.extra : nullptr,
                                              mode == DGRAD ? p.extra : nullptr, p.ldadd, p.c, p.ldc,
                                              (mode == FPROP || p.bnb_y != nullptr) ? p.partials : nullptr, bnb);
@@ -1335,4 +1336,188 @@ extern "C" int sh_conv_wgrad_x6_lin(const float* x, int ldx, const float* in_sca
     if (!y || !lin || ldy < Cout || (ldy & 3) || (((uintptr_t)y | (uintptr_t)lin) & 15)) return SH_EINVAL;
     if ((in_scale == nullptr) != (in_shift == nullptr) || (((uintptr_t)in_scale | (uintptr_t)in_shift) & 15)) return SH_EINVAL;
     return wgrad_x6_any(x, ldx, in_scale, in_shift, g, ldg, dw, workspace, N, H, W, Cin, Cout, KH, KW, stride, pad, dil, stream, y, ldy, lin, act_flags);
+}
+
+
+// ============================================================================================ bf16 COMPUTE mode (conv_b16.hip)
+// bf16 copies of the dense conv weights, made once per step from the fp32 masters: wb = the forward operand in the parameter's own OHWI
+// layout [Cout][taps][Cin], wtb = the dgrad operand [taps][Cin][pad8(Cout)] (K-contiguous, zero padded); either may be NULL.
+struct WbTab {
+    const float* w[SH_WT_MAX]; unsigned short* wb[SH_WT_MAX]; unsigned short* wtb[SH_WT_MAX];
+    int cout[SH_WT_MAX], taps[SH_WT_MAX], cin[SH_WT_MAX];
+    long long start[SH_WT_MAX + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void weights_to_bf16_multi_kernel(const WbTab T) {
+    __shared__ float tile[32][33];
+    const long long b = blockIdx.x;
+    int lo = 0, hi = T.n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (T.start[mid] <= b) lo = mid; else hi = mid - 1; }
+    const int Cout = T.cout[lo], Cin = T.cin[lo], taps = T.taps[lo], CoutP = (Cout + 7) & ~7;
+    const int tco = (CoutP + 31) / 32, tci = (Cin + 31) / 32;
+    long long e = b - T.start[lo];
+    const int ci0 = (int)(e % tci) * 32; e /= tci;
+    const int co0 = (int)(e % tco) * 32;
+    const int tap = (int)(e / tco);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* w = T.w[lo];
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        const float v = (co < Cout && ci < Cin) ? w[((long long)co * taps + tap) * Cin + ci] : 0.f;
+        tile[r][tx] = v;
+        if (T.wb[lo] && co < Cout && ci < Cin) T.wb[lo][((long long)co * taps + tap) * Cin + ci] = (unsigned short)f32_to_bf16_rne(v);
+    }
+    __syncthreads();
+    if (T.wtb[lo] == nullptr) return;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        if (ci < Cin && co < CoutP) T.wtb[lo][((long long)tap * Cin + ci) * CoutP + co] = (unsigned short)f32_to_bf16_rne(tile[tx][r]);
+    }
+}
+extern "C" int sh_weights_to_bf16_multi(int n, const float* const* w, void* const* wb, void* const* wtb, const int* cout, const int* taps,
+                                        const int* cin, void* stream) {
+    if (n <= 0 || n > SH_WT_MAX || !w || !wb || !wtb || !cout || !taps || !cin) return SH_EINVAL;
+    WbTab T;
+    T.n = n;
+    long long acc = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!w[i] || cout[i] <= 0 || taps[i] <= 0 || cin[i] <= 0) return SH_EINVAL;
+        T.w[i] = w[i]; T.wb[i] = (unsigned short*)wb[i]; T.wtb[i] = (unsigned short*)wtb[i]; T.cout[i] = cout[i]; T.taps[i] = taps[i]; T.cin[i] = cin[i];
+        T.start[i] = acc;
+        acc += (long long)taps[i] * sh_cdiv((cout[i] + 7) & ~7, 32) * sh_cdiv(cin[i], 32);
+    }
+    T.start[n] = acc;
+    if (acc >= (1ll << 31)) return SH_EINVAL;
+    weights_to_bf16_multi_kernel<<<(unsigned)acc, 256, 0, (hipStream_t)stream>>>(T);
+    return sh_launch_status();
+}
+
+// y = conv(x', w) in bf16 compute mode: x is a bf16 tensor read as is or through the producer's BatchNorm + ReLU (in_scale / in_shift, as
+// sh_conv_fprop_x6_aff), w_bf16 = sh_weights_to_bf16_multi's forward copy; one MFMA product per tile, fp32 accumulate, BatchNorm
+// statistics partials from the fp32 accumulators; y is stored as bf16 (act_flags bit 1) or fp32.  SH_EUNSUPPORTED: no instantiation
+// (channel counts not multiples of 8, unaligned rows, K x K taps with Cin % 64 != 0, extents >= 2 GiB): run the fp32-accurate entry point.
+extern "C" int sh_conv_fprop_b16(const void* x, int ldx, const float* in_scale, const float* in_shift, const void* w_bf16, const float* bias,
+                                 void* y, int ldy, float* stat_partials, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                                 int pad, int dil, float* workspace, int64_t workspace_bytes, int act_flags, void* stream) {
+    ConvQ p{};
+    if (!x || !w_bf16 || !y || !geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil) || (act_flags & ~2)) return SH_EINVAL;
+    if ((in_scale == nullptr) != (in_shift == nullptr) || (((uintptr_t)in_scale | (uintptr_t)in_shift) & 15)) return SH_EINVAL;
+    if (ldx < Cin || ldy < Cout) return SH_EINVAL;
+    p.act = 1 | (act_flags & 2);
+    p.a = (const float*)x; p.b = (const float*)w_bf16; p.c = (float*)y; p.extra = bias; p.partials = stat_partials; p.lda = ldx; p.ldc = ldy;
+    p.M = N * p.Ho * p.Wo; p.Nn = Cout; p.K = KH * KW * Cin; p.Kc = Cin;
+    p.n_partials = (int)sh_cdiv(p.M, 64);
+    p.aff_scale = in_scale; p.aff_shift = in_shift;
+    if ((ldy & 3) == 0 && ((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0)) use_splitk(p, workspace, workspace_bytes);
+    const long long a = ((long long)N * H * W - 1) * ldx + Cin, b = (long long)Cout * p.K;
+    if (a * 2 >= (1ll << 31) || b * 2 >= (1ll << 31)) return SH_EUNSUPPORTED;
+    p.a_bytes = (unsigned)(a * 2); p.b_bytes = (unsigned)(b * 2);
+    const int rc = sh_b16_launch(FPROP, p, 0, (hipStream_t)stream);
+    return rc == SH_X6P_NO ? SH_EUNSUPPORTED : rc;
+}
+// the grouped ASPP launch (sh_conv1x1_grouped_fprop_x6) in bf16 compute mode: x[g] bf16 tensors, w[g] bf16 copies, y bf16 (bit 1) or fp32
+extern "C" int sh_conv1x1_grouped_fprop_b16(int ngroups, const void* const* x, const int* ldx, const float* const* in_scale,
+                                            const float* const* in_shift, const void* const* w_bf16, void* y, int ldy, float* stat_partials,
+                                            int N, int H, int W, int Cin, int Cout, int act_flags, void* stream) {
+    ConvQ p{};
+    if (ngroups < 1 || ngroups > 6 || !x || !ldx || !in_scale || !in_shift || !w_bf16 || !y || !geom(p, N, H, W, Cin, Cout, 1, 1, 1, 0, 1) ||
+        (act_flags & ~2)) return SH_EINVAL;
+    if ((Cout & 127) || (Cin & 15) || ldy < ngroups * Cout) return SH_EUNSUPPORTED;
+    const long long M = (long long)N * H * W;
+    for (int g = 0; g < ngroups; ++g) {
+        if (!x[g] || !w_bf16[g] || ldx[g] < Cin || ((in_scale[g] == nullptr) != (in_shift[g] == nullptr))) return SH_EINVAL;
+        if ((((uintptr_t)in_scale[g] | (uintptr_t)in_shift[g]) & 15)) return SH_EINVAL;
+        const long long ab = ((M - 1) * ldx[g] + Cin) * 2;
+        if (ab >= (1ll << 31)) return SH_EUNSUPPORTED;
+        p.ga[g] = (const float*)x[g]; p.ga_bytes[g] = (unsigned)ab; p.glda[g] = ldx[g]; p.gb[g] = (const float*)w_bf16[g]; p.gsc[g] = in_scale[g]; p.gsh[g] = in_shift[g];
+    }
+    p.act = 1 | (act_flags & 2);
+    p.ngroups = ngroups; p.group_n = Cout;
+    p.c = (float*)y; p.ldc = ldy; p.partials = stat_partials;
+    p.M = (int)M; p.Nn = ngroups * Cout; p.K = Cin; p.Kc = Cin;
+    p.b_bytes = (unsigned)((long long)Cout * Cin * 2);
+    p.n_partials = (int)sh_cdiv(p.M, 64);
+    const int rc = sh_b16_grouped_launch(p, (hipStream_t)stream);
+    return rc == SH_X6P_NO ? SH_EUNSUPPORTED : rc;
+}
+// Input gradient in bf16 compute mode, every hook of the fp32-accurate entry points optional:
+//   dy: the gradient operand [N*Ho*Wo][lddy] (lddy >= pad8(Cout), padding lanes zero), bf16 (act_flags bit 0) or fp32; with
+//   y_lin / lin (1x1 convs) it is the masked gradient g (bf16 only) and the operand is lin(g, y_lin) as sh_conv_dgrad_x6_lin;
+//   wt_bf16: sh_weights_to_bf16_multi's transposed copy; addend (bit 2: bf16) summed into the result; dx stored bf16 (bit 1) or fp32;
+//   y_prev != NULL: BatchNorm-backward epilogue as sh_conv_dgrad_x6_bnb (bit 3: y_prev bf16, bit 4: out_prev bf16, bit 5: out_prev is the
+//   ReLU quad mask).  Stride-1 geometries; SH_EUNSUPPORTED: run the fp32-accurate entry point.
+extern "C" int sh_conv_dgrad_b16(const void* dy, int lddy, const void* y_lin, int ldyl, const float* lin, const void* wt_bf16, const void* addend,
+                                 int ldadd, void* dx, int lddx, const void* y_prev, int ldyp, const void* out_prev, int ldop, const float* mean,
+                                 const float* invstd, const float* scale, const float* shift, int relu, float* stat_partials, int N, int H,
+                                 int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, float* workspace,
+                                 int64_t workspace_bytes, int act_flags, void* stream) {
+    ConvQ p{};
+    if (!dy || !wt_bf16 || !dx || !geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil) || (act_flags & ~63)) return SH_EINVAL;
+    const int CoutP = (Cout + 7) & ~7;
+    const bool dy_bf = act_flags & 1, qmask = (act_flags & 32) != 0;
+    if (lddy < CoutP || lddx < Cin || (addend && ldadd < Cin)) return SH_EINVAL;
+    if ((y_lin == nullptr) != (lin == nullptr) || (y_lin && (ldyl < Cout || KH * KW != 1))) return SH_EINVAL;
+    if (y_prev && (!mean || !invstd || !scale || !shift || !stat_partials || ldyp < Cin)) return SH_EINVAL;
+    if (out_prev && (!y_prev || (qmask ? ldop * 4 : ldop) < Cin || (qmask && (Cin & 3)))) return SH_EINVAL;
+    if (stride != 1 || (y_lin && !dy_bf)) return SH_EUNSUPPORTED;
+    p.act = (y_lin ? 16 : 0) | ((act_flags & 2) ? 128 : 0) | ((act_flags & 4) ? 256 : 0) | ((act_flags & 8) ? 4 : 0) | ((act_flags & 16) ? 8 : 0) | (qmask ? 64 : 0);
+    p.a = (const float*)dy; p.lda = lddy; p.a2 = (const float*)y_lin; p.lda2 = ldyl; p.lin = lin;
+    p.b = (const float*)wt_bf16; p.c = (float*)dx; p.extra = (const float*)addend; p.ldadd = ldadd; p.ldc = lddx;
+    p.Nn = Cin; p.Kc = CoutP; p.K = KH * KW * CoutP; p.M = N * H * W;
+    bool al = (lddx & 3) == 0 && ((uintptr_t)dx & 15) == 0 && (!addend || ((ldadd & 3) == 0 && ((uintptr_t)addend & 15) == 0));
+    if (y_prev) {
+        p.partials = stat_partials; p.n_partials = (int)sh_cdiv(p.M, 64);
+        p.bnb_y = (const float*)y_prev; p.bnb_ldy = ldyp; p.bnb_mean = mean; p.bnb_invstd = invstd; p.bnb_scale = scale; p.bnb_shift = shift; p.bnb_relu = relu;
+        p.bnb_out = (const float*)out_prev; p.bnb_ldo = ldop;
+        al = al && (ldyp & 3) == 0 && (((uintptr_t)y_prev | (uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0 &&
+             (!out_prev || qmask || ((ldop & 3) == 0 && ((uintptr_t)out_prev & 15) == 0));
+    }
+    if (al) use_splitk(p, workspace, workspace_bytes);
+    const long long a = ((long long)N * p.Ho * p.Wo - 1) * lddy + CoutP, b = (long long)KH * KW * Cin * CoutP;
+    if (a * 4 >= (1ll << 31) || b * 2 >= (1ll << 31)) return SH_EUNSUPPORTED;
+    p.a_bytes = (unsigned)(a * (dy_bf ? 2 : 4)); p.b_bytes = (unsigned)(b * 2);
+    if (y_lin) {
+        const long long a2 = ((long long)p.M - 1) * ldyl + Cout;
+        if (a2 * 2 >= (1ll << 31)) return SH_EUNSUPPORTED;
+        p.a2_bytes = (unsigned)(a2 * 2);
+    }
+    const int rc = sh_b16_launch(DGRAD, p, dy_bf ? 0 : 1, (hipStream_t)stream);
+    return rc == SH_X6P_NO ? SH_EUNSUPPORTED : rc;
+}
+// Weight gradient (fp32) in bf16 compute mode: x a bf16 tensor read as is or through the producer's BatchNorm + ReLU (in_scale /
+// in_shift); dy bf16 (act_flags bit 0) or fp32, or -- 1x1 stride-1 convs -- the masked gradient g (bf16) with y_lin / lin as
+// sh_conv_wgrad_x6_lin.  workspace: sh_conv_wgrad_x6_workspace bytes.  SH_EUNSUPPORTED: run the fp32-accurate entry point.
+extern "C" int sh_conv_wgrad_b16(const void* x, int ldx, const float* in_scale, const float* in_shift, const void* dy, int lddy, const void* y_lin,
+                                 int ldyl, const float* lin, float* dw, float* workspace, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                 int stride, int pad, int dil, int act_flags, void* stream) {
+    ConvQ p{};
+    if (!x || !dy || !dw || !workspace || !geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil) || (act_flags & ~1)) return SH_EINVAL;
+    if ((in_scale == nullptr) != (in_shift == nullptr) || (((uintptr_t)in_scale | (uintptr_t)in_shift | (uintptr_t)lin) & 15)) return SH_EINVAL;
+    if ((y_lin == nullptr) != (lin == nullptr) || (y_lin && ldyl < Cout)) return SH_EINVAL;
+    if (lddy < Cout || ldx < Cin) return SH_EINVAL;
+    const bool dy_bf = act_flags & 1;
+    if ((Cout & 7) || (y_lin && !dy_bf) || ((uintptr_t)dw & 15)) return SH_EUNSUPPORTED;
+    p.a = (const float*)dy; p.b = (const float*)x; p.c = workspace; p.lda = lddy; p.ldb = ldx;
+    p.M = Cout; p.Nn = KH * KW * Cin; p.K = N * p.Ho * p.Wo;
+    p.aff_scale = in_scale; p.aff_shift = in_shift;
+    if (y_lin) {
+        const long long a2 = ((long long)p.K - 1) * ldyl + Cout;
+        if (a2 * 2 >= (1ll << 31)) return SH_EUNSUPPORTED;
+        p.a2 = (const float*)y_lin; p.lda2 = ldyl; p.a2_bytes = (unsigned)(a2 * 2); p.lin = lin;
+    }
+    const WgX6Plan g = wgrad_plan_x6(Cout, p.Nn, p.K);
+    p.kchunk = g.kchunk;
+    p.scatter = g.per_xcd;
+    hipStream_t st = (hipStream_t)stream;
+    const long long ab = ((long long)p.K - 1) * lddy + Cout, bb = ((long long)N * H * W - 1) * ldx + Cin;
+    if (ab * 4 >= (1ll << 31) || bb * 2 >= (1ll << 31)) return SH_EUNSUPPORTED;
+    p.a_bytes = (unsigned)(ab * (dy_bf ? 2 : 4)); p.b_bytes = (unsigned)(bb * 2);
+    int rc = sh_b16_wgrad_launch(p, dy_bf ? 0 : 1, g.wgm, g.wgn, g.splits, st);
+    if (rc == SH_X6P_NO) return SH_EUNSUPPORTED;
+    if (rc != SH_OK) return rc;
+    const long long n = (long long)Cout * p.Nn, n4 = n / 4;
+    slab_reduce_x6_kernel<<<(unsigned)sh_cdiv(n4, 64), 256, 0, st>>>(workspace, dw, n4, n, g.splits);
+    return sh_launch_status();
 }

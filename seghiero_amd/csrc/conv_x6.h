@@ -127,5 +127,9 @@ __device__ __forceinline__ f32x16 mma3b(const bf16x8 (&a)[3], const bf16x8 b0, f
 int sh_x6p_launch(int mode, ConvQ& p, hipStream_t st);
 int sh_x6p_grouped_launch(ConvQ& p, hipStream_t st);
 int sh_x6p_wgrad_launch(ConvQ& p, int wgm, int wgn, int splits, hipStream_t st);
+// conv_b16.hip: bf16 COMPUTE mode (one MFMA product per tile, operands rounded once to bf16); SH_X6P_NO = shape not handled
+int sh_b16_launch(int mode, ConvQ& p, int a32, hipStream_t st);
+int sh_b16_grouped_launch(ConvQ& p, hipStream_t st);
+int sh_b16_wgrad_launch(ConvQ& p, int dy32, int wgm, int wgn, int splits, hipStream_t st);
 // conv_bf16x6.hip: sum of the split-K slabs + bias / addend / BN statistics / BN-backward front half (p.slab, p.ksplit set)
 int sh_x6_splitk_reduce(const ConvQ& p, int mode, hipStream_t st);

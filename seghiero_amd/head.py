@@ -135,6 +135,18 @@ def _aspp_branches_grouped(aspp, c4, cat, A, training, R):
 class _HeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mod, c1, c4, *params):
+        # compute_dtype = torch.bfloat16: the convolutions whose input is a bf16-stored tensor (the decoder with act_dtype = bfloat16)
+        # run in bf16 compute mode (ops.compute_as / csrc/conv_b16.hip)
+        with ops.compute_as(mod.compute_dtype):
+            return _HeadFn._forward(ctx, mod, c1, c4, *params)
+
+    @staticmethod
+    def backward(ctx, dlogits, demb):
+        with ops.compute_as(ctx.mod.compute_dtype):
+            return _HeadFn._backward(ctx, dlogits, demb)
+
+    @staticmethod
+    def _forward(ctx, mod, c1, c4, *params):
         training = mod.training
         c4 = ops.to_nhwc(c4)
         if ops.pm(c4)[1] != c4.shape[1]:
@@ -201,7 +213,7 @@ class _HeadFn(torch.autograd.Function):
         return logits, emb
 
     @staticmethod
-    def backward(ctx, dlogits, demb):
+    def _backward(ctx, dlogits, demb):
         if not ctx.training:
             raise SegHieroHipError("backward through eval-mode BatchNorm is not on the SegHiero hot path")
         mod, R = ctx.mod, ctx.R
@@ -303,6 +315,7 @@ class DepthwiseSeparableASPPContrastHead(nn.Module):
             DepthwiseSeparableConv(aspp_channels, aspp_channels, kernel_size=3, padding=1, bias=False))
         self.cls_seg = nn.Conv2d(aspp_channels, num_classes, kernel_size=1)
         self.act_dtype = torch.float32          # torch.bfloat16: the decoder stores its activations as bf16 (see _HeadFn.forward)
+        self.compute_dtype = torch.float32      # torch.bfloat16 (with act_dtype = bfloat16): bf16 compute mode for those convolutions
         self.align_corners = False
         for name, v in (("in_channels", in_channels), ("aspp_channels", aspp_channels), ("c1_channels", c1_channels),
                         ("proj_dim", proj_dim), ("c1_in_channels", max(c1_in_channels, 0))):

@@ -52,10 +52,11 @@ class Lazy:
     """relu(y * scale + shift) of a raw conv output, NOT materialised: the consumer convolution applies it in its loader
     (ops.conv_fprop_aff / conv_wgrad(aff=...)), so conv -> BN -> ReLU -> conv chains never write or re-read the activated
     tensor.  `materialize()` is the fallback for consumers without a fused loader."""
-    __slots__ = ("y", "coefs", "_out")
+    __slots__ = ("y", "coefs", "_out", "grad32")
 
-    def __init__(self, y, coefs):
-        self.y, self.coefs, self._out = y, coefs, None
+    def __init__(self, y, coefs, grad32=False):
+        # grad32: the gradient w.r.t. this activation goes to a kernel that only takes fp32 (a depthwise producer's backward)
+        self.y, self.coefs, self._out, self.grad32 = y, coefs, None, grad32
 
     @property
     def shape(self):
@@ -69,7 +70,7 @@ class Lazy:
         if self._out is None:
             n, c, h, w = self.y.shape
             ld = ops.pad4(c)
-            self._out = ops.new_act(n, c, h, w, self.y.device, ld=ld, zero=ld != c)
+            self._out = ops.new_act(n, c, h, w, self.y.device, ld=ld, zero=ld != c, dtype=self.y.dtype)
             ops.bn_act(self.y, self.coefs, self._out, True)
         return self._out
 
@@ -129,43 +130,59 @@ def _wgrad(x, dy, dw, s, p, d):
     ops.conv_wgrad(x, dy, dw, s, p, d, side=True)
 
 
-def _dgrad(rec_x, dy, weight, s, p, d, addend=None, pack_for=None):
+def _dgrad(rec_x, dy, weight, s, p, d, addend=None, pack_for=None, grad32=False):
     """Gradient w.r.t. a conv input.  For a deferred activation the dgrad epilogue also runs the front half of the producer's
     BatchNorm backward (-> GradPack); otherwise a plain tensor.  pack_for: the CBARec of the residual block whose OUTPUT is this
-    conv's input (out = relu(bn(y) + identity)): the same fusion with the mask taken from `out`."""
+    conv's input (out = relu(bn(y) + identity)): the same fusion with the mask taken from `out`.
+    In bf16 compute mode the result is stored like the input it belongs to (ops.grad_dtype); fp32 when its consumer only takes fp32
+    (grad32, or a depthwise producer: Lazy.grad32) or when only the fp32-accurate kernels have the geometry."""
+    like = rec_x.y if isinstance(rec_x, Lazy) else rec_x
+    g32 = grad32 or (isinstance(rec_x, Lazy) and rec_x.grad32)
+    if ops.grad_dtype(like, g32) == torch.bfloat16:
+        out = _dgrad_as(torch.bfloat16, rec_x, dy, weight, s, p, d, addend, pack_for)
+        if out is not None:
+            return out
+    return _dgrad_as(torch.float32, rec_x, dy, weight, s, p, d, addend, pack_for)
+
+
+def _dgrad_as(gdt, rec_x, dy, weight, s, p, d, addend, pack_for):
+    """_dgrad with its result stored as `gdt`.  bf16 results exist in the bf16 compute kernels only: None when they have no
+    instantiation for the geometry (nothing launched; the caller repeats with fp32)."""
     n, c, h, w = rec_x.shape
+    dev = (rec_x.y if isinstance(rec_x, Lazy) else rec_x).device
+    strict = gdt != torch.float32
+    new = lambda: ops.new_act(n, c, h, w, dev, dtype=gdt)
+    parts = lambda: torch.empty((-(-n * h * w // 64), 2, c), device=dev, dtype=torch.float32)
+
+    def plain(cur, dx):
+        if not strict:
+            ops.conv_dgrad(cur, weight, dx, s, p, d, addend=addend)
+            return dx
+        return dx if ops._dgrad_b16(cur, weight, dx, s, p, d, addend=addend) else None
+
     if isinstance(dy, ops.DeferredDy):
-        dd, dev = dy, dy.g.device
         if pack_for is None:
             if isinstance(rec_x, Lazy) and FUSE_BN:
-                g = ops.new_act(n, c, h, w, dev)
-                partials = torch.empty((-(-n * h * w // 64), 2, c), device=dev, dtype=torch.float32)
-                if ops.conv_dgrad_lin(dd, weight, g, addend=addend, bnb=(rec_x.y, rec_x.coefs, partials)):
+                g, partials = new(), parts()
+                if ops.conv_dgrad_lin(dy, weight, g, addend=addend, bnb=(rec_x.y, rec_x.coefs, partials)):
                     return GradPack(g, partials)
             elif not isinstance(rec_x, Lazy):
-                dx = ops.new_act(n, c, h, w, dev)
-                if ops.conv_dgrad_lin(dd, weight, dx, addend=addend):
+                dx = new()
+                if ops.conv_dgrad_lin(dy, weight, dx, addend=addend):
                     return dx
-        dy = dd.materialize()
-    dev = dy.device
+        dy = dy.materialize()
     if pack_for is not None and FUSE_BN and not isinstance(rec_x, Lazy):
-        g = ops.new_act(n, c, h, w, dev)
-        partials = torch.empty((-(-n * h * w // 64), 2, c), device=dev, dtype=torch.float32)
+        g, partials = new(), parts()
         if ops.conv_dgrad_bnb(dy, weight, g, pack_for.y, pack_for.coefs, True, partials, s, p, d, addend=addend,
                               out_prev=pack_for.out if pack_for.mask is None else pack_for.mask):
             return GradPack(g, partials)
-        ops.conv_dgrad(dy, weight, g, s, p, d, addend=addend)
-        return g
+        return plain(dy, g)
     if isinstance(rec_x, Lazy) and FUSE_BN:
-        g = ops.new_act(n, c, h, w, dev)
-        partials = torch.empty((-(-n * h * w // 64), 2, c), device=dev, dtype=torch.float32)
+        g, partials = new(), parts()
         if ops.conv_dgrad_bnb(dy, weight, g, rec_x.y, rec_x.coefs, True, partials, s, p, d, addend=addend):
             return GradPack(g, partials)
-        dx = g
-    else:
-        dx = ops.new_act(n, c, h, w, dev)
-    ops.conv_dgrad(dy, weight, dx, s, p, d, addend=addend)
-    return dx
+        return plain(dy, g)
+    return plain(dy, new())
 
 
 def cba_fwd(x, weight, geom, bn, relu, training, residual=None, out=None, lazy=False):
@@ -221,17 +238,21 @@ def new_grad(param):
     return torch.empty_like(param) if buf is None else buf
 
 
-def cba_bwd(rec, bn, dout, need_dx=True, addend=None, want_dres=False, scatter_into=None, pack_for=None):
+def cba_bwd(rec, bn, dout, need_dx=True, addend=None, want_dres=False, scatter_into=None, pack_for=None, dx32=False):
     """-> (dx, dweight, dgamma, dbeta, dres).  `addend` is summed into dx by the dgrad epilogue;
-    `scatter_into` (1x1 strided convs) accumulates the result into an existing dx instead."""
+    `scatter_into` (1x1 strided convs) accumulates the result into an existing dx instead.  dx32: dx goes to an fp32-only consumer."""
     s, p, d = rec.geom
+    # bf16 compute mode: dy (the gradient w.r.t. this conv's raw output) is stored like that output, except where its consumers are
+    # the fp32-accurate kernels: strided input gradients (parity classes / scatter) and convs whose input is an fp32 tensor
+    xin = rec.x.y if isinstance(rec.x, Lazy) else rec.x
+    dy32 = s > 1 or scatter_into is not None or xin.dtype == torch.float32
     # ReLU mask: from `out` only where a residual was added; otherwise recomputed from y (one activation read less).
     # dout may be a GradPack (mask applied, statistics partials done by the consumer's dgrad epilogue).
     mode = 0 if not rec.relu else (1 if rec.has_res else 2)
     # second half of the BatchNorm backward in the loaders of this conv's dgrad / wgrad (1x1 convs): no apply pass, no dy tensor
     defer = FUSE_BN and scatter_into is None and pack_for is None and ops.lin_ok(rec.x.shape, rec.weight, s, p, d)
     dy, dgamma, dbeta, dres = ops.bn_backward(dout, (rec.out if rec.mask is None else rec.mask) if mode == 1 else None, rec.y, rec.coefs,
-                                              bn.weight, mode, want_dres, defer=defer)
+                                              bn.weight, mode, want_dres, defer=defer, grad32=dy32)
     dw = new_grad(rec.weight)
     if not ops.WGRAD_AFTER_DGRAD:
         _wgrad(rec.x, dy, dw, s, p, d)
@@ -240,7 +261,7 @@ def cba_bwd(rec, bn, dout, need_dx=True, addend=None, want_dres=False, scatter_i
         ops.conv_dgrad(dy, rec.weight, scatter_into, s, p, d, mode=1)
         dx = scatter_into
     elif need_dx:
-        dx = _dgrad(rec.x, dy, rec.weight, s, p, d, addend=addend, pack_for=pack_for)
+        dx = _dgrad(rec.x, dy, rec.weight, s, p, d, addend=addend, pack_for=pack_for, grad32=dx32)
     if ops.WGRAD_AFTER_DGRAD:
         # enqueued after the dgrad: the side stream then starts this (MFMA-bound) wgrad when the dgrad has finished, i.e.
         # next to the HBM-bound BatchNorm backward of the previous layer instead of next to another MFMA-bound kernel
@@ -265,7 +286,7 @@ def dw_fwd(x, weight, dil, bn, training, lazy=False):
         ops.dwconv_fprop(x, weight, y, partials, dil)
     coefs = _bn_coefs(bn, partials, n * h * w, training, c, x.device)
     if lazy and FUSE_BN and training and ops.CONV_IMPL == "x6":
-        out = Lazy(y, coefs)
+        out = Lazy(y, coefs, grad32=True)              # the depthwise backward kernels take fp32 gradients
     else:
         out = ops.new_act(n, c, h, w, x.device)
         ops.bn_act(y, coefs, out, True)
@@ -278,7 +299,12 @@ def dw_fwd(x, weight, dil, bn, training, lazy=False):
 def dw_bwd(rec, bn, dout, dx_accumulate_into=None):
     """-> (dx, dweight, dgamma, dbeta); with dx_accumulate_into the input gradient is added into that tensor."""
     # second half of the BatchNorm backward in the loaders of the depthwise dgrad / wgrad (strip-walk kernels): no apply pass
-    dy, dgamma, dbeta, _ = ops.bn_backward(dout, None, rec.y, rec.coefs, bn.weight, 2, defer=FUSE_BN and ops.dw_lin_ok(rec.y.shape, rec.dil))
+    if hasattr(dout, "partials"):
+        dout.g = ops.f32(dout.g)
+    else:
+        dout = ops.f32(dout)
+    dy, dgamma, dbeta, _ = ops.bn_backward(dout, None, rec.y, rec.coefs, bn.weight, 2, defer=FUSE_BN and ops.dw_lin_ok(rec.y.shape, rec.dil),
+                                           grad32=True)
     dw = new_grad(rec.weight)
     if isinstance(rec.x, Lazy) and rec.x._out is None:
         ops.dwconv_wgrad(rec.x.y, dy, dw, rec.dil, side=True, aff=rec.x.coefs)

@@ -112,6 +112,39 @@ def pad4(c):
     return (c + 3) & ~3
 
 
+def pad8(c):
+    return (c + 7) & ~7
+
+
+def f32(t):
+    """fp32 view of a (gradient) tensor for the fp32-only kernels: the tensor itself, or a widened copy of a bf16 one."""
+    return t if t is None or t.dtype == torch.float32 else t.float()
+
+
+# bf16 COMPUTE mode (BASELINE configs[4]; include/seghiero_hip.h "bf16 COMPUTE mode", csrc/conv_b16.hip): inside `with compute_as(torch.bfloat16)`
+# every dense convolution whose geometry has an instantiation runs ONE bf16 MFMA product per tile on operands rounded once to bf16 in the
+# loader (fp32 accumulate, fp32 BatchNorm statistics, fp32 weight gradients) instead of the fp32-accurate six-product plan; the others
+# (the 4-channel stem, strided input gradients, channel counts that are not multiples of 8) stay on the fp32-accurate kernels.
+_B16 = False
+
+
+def b16():
+    return _B16
+
+
+class compute_as:
+    def __init__(self, dtype):
+        self.on = dtype == torch.bfloat16
+
+    def __enter__(self):
+        global _B16
+        self.prev, _B16 = _B16, self.on and CONV_IMPL == "x6"
+
+    def __exit__(self, *exc):
+        global _B16
+        _B16 = self.prev
+
+
 def pm(t):
     """(data_ptr, ld) of a logical-NCHW tensor with NHWC memory; raises if the strides are anything else.
 
@@ -223,6 +256,8 @@ def conv_fprop_aff(x, in_coefs, weight, bias, y, partials, stride, pad, dil):
     yp, ldy, yb = pmx(y)
     ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
     m = n * ho * wo
+    if _B16 and xb and _fprop_b16(x, in_coefs, weight, bias, y, partials, stride, pad, dil):
+        return True
     cost = (2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin + m * o + o * cin * kh * kw))
     ws, nb = _splitk_ws(0, n, h, w, cin, o, kh, kw, stride, pad, dil, 0, x.device)
     return _call_fused("sh_conv_fprop_x6_aff", xp, ldx, in_coefs[2].data_ptr(), in_coefs[3].data_ptr(), w_ohwi(weight).data_ptr(),
@@ -231,11 +266,33 @@ def conv_fprop_aff(x, in_coefs, weight, bias, y, partials, stride, pad, dil):
                        key=_ckey(n, h, w, cin, o, kh, stride, dil))
 
 
+def _bcost(n, h, w, cin, o, kh, kw, m, xbytes=2, ybytes=2):
+    return (2.0 * m * o * cin * kh * kw, float(xbytes * n * h * w * cin + ybytes * m * o + 2 * o * cin * kh * kw))
+
+
+def _fprop_b16(x, in_coefs, weight, bias, y, partials, stride, pad, dil):
+    """bf16 compute mode forward (x a bf16 tensor, read as is or through in_coefs); False = no instantiation (nothing launched)."""
+    n, cin, h, w = x.shape
+    o, _, kh, kw = weight.shape
+    xp, ldx, _ = pmx(x)
+    yp, ldy, yb = pmx(y)
+    ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
+    m = n * ho * wo
+    ws, nb = _splitk_ws(0, n, h, w, cin, o, kh, kw, stride, pad, dil, 0, x.device)
+    wb, _ = weights_bf16(weight)
+    return _call_fused("sh_conv_fprop_b16", xp, ldx, None if in_coefs is None else in_coefs[2].data_ptr(),
+                       None if in_coefs is None else in_coefs[3].data_ptr(), wb.data_ptr(), None if bias is None else bias.data_ptr(),
+                       yp, ldy, None if partials is None else partials.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, ws, nb,
+                       yb << 1, _st(), cost=_bcost(n, h, w, cin, o, kh, kw, m, 2, 2 if yb else 4), key=_ckey(n, h, w, cin, o, kh, stride, dil))
+
+
 def conv_fprop(x, weight, bias, y, partials, stride, pad, dil):
     n, cin, h, w = x.shape
     o, _, kh, kw = weight.shape
     xp, ldx, xb = pmx(x)
     yp, ldy, yb = pmx(y)
+    if _B16 and xb and _fprop_b16(x, None, weight, bias, y, partials, stride, pad, dil):
+        return
     ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
     m = n * ho * wo
     x6 = CONV_IMPL == "x6"
@@ -325,13 +382,106 @@ def prepare_dgrad_weights(weights, cache):
 
 
 def release_dgrad_weights():
-    global _WT_ACTIVE
+    global _WT_ACTIVE, _WB_ACTIVE
     _WT_ACTIVE = None
+    _WB_ACTIVE = None
+
+
+_WB_ACTIVE = None         # {id(weight): (weight, bf16 forward copy, bf16 transposed copy)} of the training step in flight, else None
+
+
+def _wb_buffers(w):
+    o, i, kh, kw = w.shape
+    return (torch.empty((o, kh * kw, i), device=w.device, dtype=torch.bfloat16),
+            torch.empty((kh * kw, i, pad8(o)), device=w.device, dtype=torch.bfloat16))
+
+
+def _wb_launch(items):
+    cap = 40                                                   # SH_WT_MAX
+    for a in range(0, len(items), cap):
+        chunk = items[a:a + cap]
+        k = len(chunk)
+        vp = ctypes.c_void_p
+        _call("sh_weights_to_bf16_multi", k, (vp * k)(*[w_ohwi(w).data_ptr() for w, _, _ in chunk]), (vp * k)(*[b.data_ptr() for _, b, _ in chunk]),
+              (vp * k)(*[t.data_ptr() for _, _, t in chunk]), (ctypes.c_int * k)(*[w.shape[0] for w, _, _ in chunk]),
+              (ctypes.c_int * k)(*[w.shape[2] * w.shape[3] for w, _, _ in chunk]), (ctypes.c_int * k)(*[w.shape[1] for w, _, _ in chunk]), _st())
+
+
+def prepare_bf16_weights(weights, cache):
+    """bf16 compute mode: the bf16 copies (forward operand and transposed input-gradient operand) of all dense conv `weights`, made
+    once per step in a few launches; handed out by weights_bf16() until release_dgrad_weights().  Contract as prepare_dgrad_weights."""
+    global _WB_ACTIVE
+    todo = []
+    for w in weights:
+        hit = cache.get(id(w))
+        if hit is None or hit[0] is not w or hit[1].device != w.device:
+            hit = (w,) + _wb_buffers(w)
+            cache[id(w)] = hit
+        todo.append(hit)
+    _wb_launch(todo)
+    _WB_ACTIVE = cache
+
+
+def weights_bf16(weight):
+    """-> (bf16 [O][taps][I] forward copy, bf16 [taps][I][pad8(O)] transposed copy) of a dense conv weight."""
+    if _WB_ACTIVE is not None:
+        hit = _WB_ACTIVE.get(id(weight))
+        if hit is not None and hit[0] is weight:
+            return hit[1], hit[2]
+    item = (weight,) + _wb_buffers(weight)
+    _wb_launch([item])
+    return item[1], item[2]
+
+
+def _dgrad_b16(dy, weight, dx, stride, pad, dil, addend=None, lin=None, bnb=None):
+    """bf16 compute mode input gradient.  dy: fp32 or bf16 tensor (lin = (y, lin coefficients): dy is the masked gradient g, bf16);
+    bnb = (y_prev, coefs, relu, partials, out_prev or None): BatchNorm-backward epilogue.  False = no instantiation."""
+    n, cin, h, w = dx.shape
+    o, _, kh, kw = weight.shape
+    dyp, lddy, dyb = pmx(dy)
+    if lddy < pad8(o) or stride != 1:
+        return False
+    dxp, lddx, dxb = pmx(dx)
+    ap, lda, ab = (None, 0, 0) if addend is None else pmx(addend)
+    flags = dyb | (dxb << 1) | (ab << 2)
+    ylp, ldyl, linp = None, 0, None
+    if lin is not None:
+        ylp, ldyl, ylb = pmx(lin[0])
+        if not (ylb and dyb):
+            return False
+        linp = lin[1].data_ptr()
+    bargs = (None, 0, None, 0, None, None, None, None, 0, None)
+    if bnb is not None:
+        y_prev, cf, relu, partials, out_prev = bnb
+        ypp, ldyp, ypb = pmx(y_prev)
+        flags |= ypb << 3
+        if out_prev is not None and out_prev.dtype == torch.uint8:
+            opp, ldop = out_prev.data_ptr(), cin // 4
+            flags |= 32
+        elif out_prev is not None:
+            opp, ldop, opb = pmx(out_prev)
+            flags |= opb << 4
+        else:
+            opp, ldop = None, 0
+        bargs = (ypp, ldyp, opp, ldop, cf[0].data_ptr(), cf[1].data_ptr(), cf[2].data_ptr(), cf[3].data_ptr(), int(bool(relu)), partials.data_ptr())
+    ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
+    m = n * ho * wo
+    ws, nb = _splitk_ws(1, n, h, w, cin, o, kh, kw, stride, pad, dil, 0, dx.device)
+    _, wtb = weights_bf16(weight)
+    cost = (2.0 * m * o * cin * kh * kw, float((2 if dxb else 4) * n * h * w * cin * (1 + (addend is not None)) + (2 if dyb else 4) * m * o * (2 if lin else 1)
+                                                + 2 * o * cin * kh * kw + (2 * n * h * w * cin if bnb else 0)))
+    return _call_fused("sh_conv_dgrad_b16", dyp, lddy, ylp, ldyl, linp, wtb.data_ptr(), ap, lda, dxp, lddx, *bargs, n, h, w, cin, o, kh, kw,
+                       stride, pad, dil, ws, nb, flags, _st(), cost=cost, key=_ckey(n, h, w, cin, o, kh, stride, dil))
 
 
 def conv_dgrad(dy, weight, dx, stride, pad, dil, addend=None, mode=0):
     n, cin, h, w = dx.shape
     o, _, kh, kw = weight.shape
+    if _B16 and mode == 0 and _dgrad_b16(dy, weight, dx, stride, pad, dil, addend=addend):
+        return
+    if dx.dtype != torch.float32:
+        raise SegHieroHipError("the fp32-accurate input-gradient kernels write fp32 tensors")
+    dy, addend = f32(dy), f32(addend)
     dyp, lddy = pm(dy)
     dxp, lddx = pm(dx)
     ap, lda = (None, 0) if addend is None else pm(addend)
@@ -355,6 +505,11 @@ def conv_dgrad_bnb(dy, weight, g, y_prev, coefs, relu, partials, stride, pad, di
         return False
     n, cin, h, w = g.shape
     o, _, kh, kw = weight.shape
+    if _B16 and _dgrad_b16(dy, weight, g, stride, pad, dil, addend=addend, bnb=(y_prev, coefs, relu, partials, out_prev)):
+        return True
+    if g.dtype != torch.float32:
+        return False
+    dy, addend = f32(dy), f32(addend)
     dyp, lddy = pm(dy)
     gp, ldg = pm(g)
     ypp, ldyp, ypb = pmx(y_prev)
@@ -383,6 +538,12 @@ def conv_dgrad_lin(dd, weight, dx, addend=None, bnb=None):
         return False
     n, cin, h, w = dx.shape
     o = weight.shape[0]
+    if _B16 and dd.g.dtype == torch.bfloat16:
+        return _dgrad_b16(dd.g, weight, dx, 1, 0, 1, addend=addend, lin=(dd.y, dd.lin),
+                          bnb=None if bnb is None else (bnb[0], bnb[1], True, bnb[2], None))
+    if dx.dtype != torch.float32 or dd.g.dtype != torch.float32:
+        return False
+    addend = f32(addend)
     gp, ldg = pm(dd.g)
     yp, ldy, yb = pmx(dd.y)
     dxp, lddx = pm(dx)
@@ -480,6 +641,12 @@ def conv_wgrad(x, dy, dweight, stride, pad, dil, side=False, aff=None):
     n, cin, h, w = x.shape
     o, _, kh, kw = dweight.shape
     dd = dy if isinstance(dy, DeferredDy) else None          # dy evaluated in the loader (check lin_ok before deferring)
+    if _B16 and x.dtype == torch.bfloat16 and _wgrad_b16(x, dy, dweight, stride, pad, dil, side, aff):
+        return
+    if dd is not None and dd.g.dtype != torch.float32:
+        dy, dd = dd.materialize(), None                      # the fp32-accurate lin loaders take an fp32 g
+    if dd is None:
+        dy = f32(dy)
     if (x.dtype == torch.bfloat16 or dd is not None) and not (CONV_IMPL == "x6" and _wgrad_pipelined_ok(x, o, kh, kw, stride, pad, dil)):
         # bf16-stored x / deferred dy where the pipelined wgrad has no instantiation (output width < 16: tiny test inputs; operands
         # of 2 GiB or more): widen / materialise once and run the plain kernel
@@ -532,6 +699,46 @@ def conv_wgrad(x, dy, dweight, stride, pad, dil, side=False, aff=None):
         launch("wgrad%d" % k)
     for t in (x, dy, dweight) + (() if dd is None else (dd.y, dd.lin)):
         t.record_stream(st)                                 # the allocator must not recycle them under the side stream
+
+
+def _wgrad_b16(x, dy, dweight, stride, pad, dil, side, aff):
+    """bf16 compute mode weight gradient (x bf16; dy fp32 / bf16 tensor, or a DeferredDy whose g and y are bf16).  False = no
+    instantiation (nothing launched, the caller runs the fp32-accurate kernel)."""
+    n, cin, h, w = x.shape
+    o, _, kh, kw = dweight.shape
+    dd = dy if isinstance(dy, DeferredDy) else None
+    g = dd.g if dd is not None else dy
+    if dd is not None and not (dd.g.dtype == torch.bfloat16 and dd.y.dtype == torch.bfloat16):
+        return False
+    if o % 8 or cin % 8 or not dweight.is_contiguous(memory_format=torch.channels_last if kh * kw > 1 and cin > 1 else torch.contiguous_format):
+        return False
+    need = LIB.raw("sh_conv_wgrad_x6_workspace")(n, h, w, cin, o, kh, kw, stride, pad, dil)
+    if need < 0:
+        return False
+    xp, ldx, _ = pmx(x)
+    gp, ldg, gb = pmx(g)
+    ylp, ldyl = (None, 0) if dd is None else pmx(dd.y)[:2]
+    ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
+    m = n * ho * wo
+    cost = (2.0 * m * o * cin * kh * kw, float(2 * n * h * w * cin + (2 if gb else 4) * m * o * (2 if dd is not None else 1) + 4 * o * cin * kh * kw))
+    ok = [True]
+
+    def launch(tag):
+        ws = workspace(need, x.device, tag)
+        ok[0] = _call_fused("sh_conv_wgrad_b16", xp, ldx, None if aff is None else aff[2].data_ptr(), None if aff is None else aff[3].data_ptr(),
+                            gp, ldg, ylp, ldyl, None if dd is None else dd.lin.data_ptr(), dweight.data_ptr(), ws.data_ptr(), n, h, w, cin, o,
+                            kh, kw, stride, pad, dil, gb, _st(), cost=cost, key=_ckey(n, h, w, cin, o, kh, stride, dil))
+
+    if not (side and WGRAD_ASYNC and x.is_cuda):
+        launch("wgrad")
+        return ok[0]
+    k, st = _wgrad_side(x.device).take()
+    st.wait_stream(torch.cuda.current_stream(x.device))
+    with torch.cuda.stream(st):
+        launch("wgrad%d" % k)
+    for t in (x, g, dweight) + (() if dd is None else (dd.y, dd.lin)):
+        t.record_stream(st)
+    return ok[0]
 
 
 def conv_partials(m, cout, device):
@@ -800,15 +1007,16 @@ class DeferredDy:
     def materialize(self):
         if self._dy is None:
             n, c, h, w = self.y.shape
-            ld = pad4(c)
-            dy = new_act(n, c, h, w, self.y.device, ld=ld, zero=ld != c)
-            gp, ldg = pm(self.g)
+            gdt = self.g.dtype
+            ld = pad8(c) if gdt == torch.bfloat16 else pad4(c)
+            dy = new_act(n, c, h, w, self.y.device, ld=ld, zero=ld != c, dtype=gdt)
+            gp, ldg, gb = pmx(self.g)
             yp, ldy, yb = pmx(self.y)
-            dyp, lddy = pm(dy)
+            dyp, lddy = pmx(dy)[:2]
             cf = self.coefs
             _call("sh_bn_bwd_apply", gp, ldg, None, 0, yp, ldy, cf[0].data_ptr(), cf[1].data_ptr(), cf[2].data_ptr(), cf[3].data_ptr(),
                   None if self.gamma is None else self.gamma.data_ptr(), self.red[2].data_ptr(), self.red[3].data_ptr(), dyp, lddy,
-                  None, 0, n * h * w, c, 0, yb, _st(), key=f"{n}x{h}x{w} C{c} (deferred)")
+                  None, 0, n * h * w, c, 0, yb | (gb << 2) | (gb << 3), _st(), key=f"{n}x{h}x{w} C{c} (deferred)")
             self._dy = dy
         return self._dy
 
@@ -819,6 +1027,16 @@ DEFER_APPLY = os.environ.get("SEGHIERO_DEFER_APPLY", "1") != "0"     # BatchNorm
 # when Cout * DEFER_RATIO >= Cin; measured (same-box A/B, ms per step): always 33.85, ratio 1 (also 512 -> 512) 33.7 / 34.0,
 # ratio 0.5 (Cout >= 2 Cin) 33.6 / 33.8 -- the two-stream loader costs the square pointwise convs what the apply pass saved.
 DEFER_RATIO = float(os.environ.get("SEGHIERO_DEFER_RATIO", "0.5"))
+# bf16 compute mode: a gradient w.r.t. an activation is stored like the activation itself -- bf16 where the forward tensor is bf16
+# (trunk and decoder), fp32 elsewhere -- except where its consumer only takes fp32 (depthwise / pooling / resampling kernels, the
+# fp32-accurate fallbacks): grad_dtype(like, fp32_consumer)
+GRAD_BF16 = os.environ.get("SEGHIERO_GRAD_BF16", "1") != "0"
+
+
+def grad_dtype(like, fp32_consumer=False):
+    if _B16 and GRAD_BF16 and not fp32_consumer and like is not None and like.dtype == torch.bfloat16:
+        return torch.bfloat16
+    return torch.float32
 
 
 def lin_ok(x_shape, weight, stride, pad, dil):
@@ -826,17 +1044,20 @@ def lin_ok(x_shape, weight, stride, pad, dil):
     counts, output width >= 16 for the pipelined wgrad, operands below the 2 GiB buffer-descriptor range)"""
     n, cin, h, w = x_shape
     o, _, kh, kw = weight.shape
+    if _B16 and not GRAD_BF16:
+        return False                   # bf16 compute mode: lin(g, y) takes a bf16 g (GRAD_BF16); with fp32 gradients dy is materialised
     return (DEFER_APPLY and CONV_IMPL == "x6" and kh == 1 and kw == 1 and stride == 1 and pad == 0 and o % 4 == 0 and cin % 4 == 0
             and o >= 32 and cin >= 64 and w >= 16 and n * h * w * max(pad4(o), pad4(cin)) * 4 < (1 << 31)
             and o * DEFER_RATIO >= cin)
 
 
-def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None, defer=False):
+def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None, defer=False, grad32=False):
     """-> (dy, dgamma, dbeta, dres).  relu: 0 none, 1 mask from `out` (residual blocks), 2 mask recomputed from y and
     the forward coefficients (out may be None).  dout may be a layers.GradPack: the ReLU mask is already applied and the
     (sum g, sum g*xhat) partials were produced by the consumer's dgrad epilogue, so the statistics pass is skipped.
     defer=True: dy is returned as a DeferredDy (no apply pass, no dy tensor) -- the statistics pass then also stores the masked
-    gradient g where a mask applies."""
+    gradient g where a mask applies.  grad32: the gradient tensors made here are fp32 whatever y's storage (their consumer takes
+    fp32 only); otherwise they are stored like y in bf16 compute mode (grad_dtype)."""
     relu = int(relu)
     if relu == 2:
         out = None
@@ -851,30 +1072,34 @@ def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None, d
     else:
         op, ldo, ob = (None, 0, 0) if out is None else pmx(out)
     af = yb | (ob << 1)
+    gdt = grad_dtype(y, grad32)                # storage of the gradient tensors made here (dy, g, dres): like y, or fp32
     packed = hasattr(dout, "partials")
     if packed:
         partials, dout, relu, op, ldo = dout.partials, dout.g, 0, None, 0
         p = partials.shape[0]
-        dop, lddo = pm(dout)
+        dop, lddo, dob = pmx(dout)
     else:
-        dop, lddo = pm(dout)
+        dop, lddo, dob = pmx(dout)
         p = LIB.raw("sh_stats_partials_count")(m)
         partials = torch.empty((p, 2, c), device=dev, dtype=torch.float32)
         gmask = None
         if defer and relu:
-            gmask = new_act(n, c, h, w, dev)
+            gmask = new_act(n, c, h, w, dev, dtype=gdt)
             if not _call_fused("sh_bn_bwd_reduce", dop, lddo, op, ldo, yp, ldy, coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(),
-                               coefs[3].data_ptr(), partials.data_ptr(), m, c, relu, gmask.data_ptr(), c, af, _st(), key=f"{n}x{h}x{w} C{c} +g"):
+                               coefs[3].data_ptr(), partials.data_ptr(), m, c, relu, gmask.data_ptr(), c, af | (dob << 2) | (int(gdt == torch.bfloat16) << 3),
+                               _st(), key=f"{n}x{h}x{w} C{c} +g"):
                 gmask, defer = None, False
         if gmask is None:
             _call("sh_bn_bwd_reduce", dop, lddo, op, ldo, yp, ldy, coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(),
-                  coefs[3].data_ptr(), partials.data_ptr(), m, c, relu, None, 0, af, _st(), key=f"{n}x{h}x{w} C{c}")
+                  coefs[3].data_ptr(), partials.data_ptr(), m, c, relu, None, 0, af | (dob << 2), _st(), key=f"{n}x{h}x{w} C{c}")
         else:
             dout, relu, op, ldo = gmask, 0, None, 0          # from here on as a packed gradient: mask applied
-            dop, lddo = pm(dout)
+            dop, lddo, dob = pmx(dout)
             packed = True
     if defer and (lddo % 4 or dop % 16 or c % 4):
         defer = False
+    if defer and _B16 and dout.dtype != y.dtype:
+        defer = False                  # the bf16 lin loaders take g and y in one element type
     red = torch.empty((4, c), device=dev, dtype=torch.float32)           # dgamma, dbeta, c1, c2
     lin = torch.empty((4, c), device=dev, dtype=torch.float32) if defer else None
     linp = None if lin is None else lin.data_ptr()
@@ -894,16 +1119,17 @@ def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None, d
     if defer:
         # relu == 0 here: dout is the masked gradient (packed, or stored by the statistics pass), or no mask applies
         return DeferredDy(dout, y, lin, coefs, gamma, red), red[0], red[1], (dout if want_dres else None)
-    ld = pad4(c) if dy_ld is None else dy_ld
-    dy = new_act(n, c, h, w, dev, ld=ld, zero=ld != c)
+    ld = (pad8(c) if gdt == torch.bfloat16 else pad4(c)) if dy_ld is None else dy_ld
+    dy = new_act(n, c, h, w, dev, ld=ld, zero=ld != c, dtype=gdt)
     dres = None
     if want_dres:
-        dres = dout if packed else new_act(n, c, h, w, dev)      # packed: g (mask applied) IS the identity path's gradient
-    dyp, lddy = pm(dy)
-    drp, lddr = (None, 0) if (dres is None or packed) else pm(dres)
+        dres = dout if packed else new_act(n, c, h, w, dev, dtype=gdt)      # packed: g (mask applied) IS the identity path's gradient
+    dyp, lddy = pmx(dy)[:2]
+    drp, lddr = (None, 0) if (dres is None or packed) else pmx(dres)[:2]
+    gb = int(gdt == torch.bfloat16)
     _call("sh_bn_bwd_apply", dop, lddo, op, ldo, yp, ldy, coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(),
           coefs[3].data_ptr(), None if gamma is None else gamma.data_ptr(), red[2].data_ptr(), red[3].data_ptr(), dyp, lddy,
-          drp, lddr, m, c, relu, af, _st(), key=f"{n}x{h}x{w} C{c}" + (" +dres" if drp else ""))
+          drp, lddr, m, c, relu, af | (dob << 2) | (gb << 3) | (gb << 4), _st(), key=f"{n}x{h}x{w} C{c}" + (" +dres" if drp else ""))
     return dy, red[0], red[1], dres
 
 

@@ -103,7 +103,7 @@ class SegHieroTrainer:
 
     def __init__(self, depth=50, n_fine=9, coarse_to_fine_map=((0, 3), (4, 6), (7,), (8,)), lr=0.01, fine_weight=1.0,
                  device="cuda:0", head_kw=None, grad_sync=None, super_coarse_to_coarse_map=None, rmi_radius=3,
-                 rmi_pool_way=0, rmi_pool_size=3, rmi_pool_stride=3, act_dtype=torch.float32):
+                 rmi_pool_way=0, rmi_pool_size=3, rmi_pool_stride=3, act_dtype=torch.float32, compute_dtype=torch.float32):
         """``super_coarse_to_coarse_map`` given -> 3-level model + RMIHieraTripletLoss (train.py:202-233), else the
         2-level HieraTripletLoss (train.py:176-200).  ``act_dtype=torch.bfloat16``: the trunk stores its activations as bf16
         (BASELINE configs[4]; ResNetBackbone.act_dtype)."""
@@ -113,7 +113,14 @@ class SegHieroTrainer:
         self.n_super = 0 if sup_map is None else len(sup_map)
         self.device = torch.device(device)
         self.backbone = ResNetBackbone(depth=depth, pretrained=False)
+        # compute_dtype = torch.bfloat16 (BASELINE configs[4] "bf16"): bf16 compute mode -- trunk and decoder store bf16 activations and
+        # their convolutions issue ONE bf16 MFMA product per tile on operands rounded once to bf16 (fp32 accumulate, fp32 BatchNorm
+        # statistics, fp32 weights / weight gradients / SGD); the default (float32) is the fp32-accurate six-product plan
+        self.compute_dtype = compute_dtype
+        if compute_dtype == torch.bfloat16:
+            act_dtype = torch.bfloat16
         self.backbone.act_dtype = act_dtype
+        self.backbone.compute_dtype = compute_dtype
         ch = self.backbone.out_channels
         kw = dict(in_channels=ch[3], c1_in_channels=ch[0], c1_channels=48, aspp_channels=512,
                   dilations=(1, 12, 24, 36), num_classes=n_fine + self.n_coarse + self.n_super, proj_dim=256,
@@ -122,6 +129,9 @@ class SegHieroTrainer:
         self.aspp_head = DepthwiseSeparableASPPContrastHead(**kw)
         # (the head's decoder can store bf16 too -- aspp_head.act_dtype -- but its depthwise kernels then move 128-byte segments and run
         # slower than they save: measured 49.0 vs 48.3 ms per step at the configs[4] shape, 8.9 vs 10.3 GiB; left to the caller)
+        if compute_dtype == torch.bfloat16:
+            self.aspp_head.act_dtype = torch.bfloat16
+            self.aspp_head.compute_dtype = torch.bfloat16
         self.aux_head = AuxHead(ch[2], n_fine)
         if sup_map is None:
             self.hiera_loss_fn = HieraTripletLoss(num_classes=n_fine, hiera_map=build_fine_to_coarse_map(cfg_map, n_fine).tolist(),
@@ -137,6 +147,7 @@ class SegHieroTrainer:
         self.params = list(self.backbone.parameters()) + list(self.aspp_head.parameters()) + list(self.aux_head.parameters())
         # dense conv weights whose backward runs a dgrad (everything but the depthwise convs and the stem)
         self._wt_cache = {}
+        self._wb_cache = {}
         self._dgrad_weights = [m.weight for mod in (self.backbone, self.aspp_head, self.aux_head) for m in mod.modules()
                                if isinstance(m, nn.Conv2d) and m.groups == 1 and m is not self.backbone.stem_conv]
         self.optimizer = FusedSGD(self.params, lr=lr, momentum=0.9, weight_decay=1e-4)
@@ -194,6 +205,8 @@ class SegHieroTrainer:
         self.optimizer.zero_grad(set_to_none=True)
         if ops.CONV_IMPL == "x6":
             ops.prepare_dgrad_weights(self._dgrad_weights, self._wt_cache)   # all dgrad operands in 2 launches; valid until SGD
+            if self.compute_dtype == torch.bfloat16:
+                ops.prepare_bf16_weights(self._dgrad_weights, self._wb_cache)    # bf16 operand copies of the fp32 master weights
         ops.STEP_SCOPE = self._step_scope            # the loss forward's per-pixel gradient buffers are reused from step to step
         try:
             loss, _, _, _ = self.forward_loss(img, fine_mask, epoch)

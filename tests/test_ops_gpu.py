@@ -746,3 +746,140 @@ def test_full_size_batchnorm_statistics(ops):
     v = out.double().var((0, 2, 3), unbiased=False).float()
     close(m, beta, 0, 2e-5)
     close(v, gamma * gamma, 1e-4, 1e-6)
+
+
+# ---------------------------------------------------------------------------------------------- bf16 compute mode (csrc/conv_b16.hip)
+def nhwc_bf16(t, ld=None):
+    """CPU NCHW tensor -> GPU logical-NCHW bf16 tensor with NHWC memory (optionally a channel slice of a wider buffer)."""
+    n, c, h, w = t.shape
+    ld = c if ld is None else ld
+    buf = torch.zeros((n, h, w, ld), device=DEV, dtype=torch.bfloat16)
+    out = buf.permute(0, 3, 1, 2)[:, :c]
+    out.copy_(t.to(DEV))
+    return out
+
+
+B16_CASES = [
+    # n, h, w, cin, cout, k, pad, dil
+    (2, 16, 16, 64, 64, 1, 0, 1),          # K = 64: one tile
+    (2, 16, 16, 64, 256, 1, 0, 1),
+    (2, 24, 16, 256, 64, 1, 0, 1),         # 128 x 64 tiles
+    (2, 16, 16, 560, 512, 1, 0, 1),        # K tail: 560 = 8.75 tiles of 64
+    (1, 17, 13, 128, 128, 3, 1, 1),        # 3 x 3, rows beyond M, odd sizes
+    (2, 12, 12, 64, 64, 3, 1, 1),          # 3 x 3 with Cin = 64: one tile per tap
+    (2, 12, 12, 256, 64, 3, 1, 1),         # long K, few tiles: K slices + reduce
+    (2, 12, 12, 64, 256, 3, 12, 12),       # dilated
+    (4, 16, 16, 2048, 512, 1, 0, 1),       # the ASPP pointwise shape
+    (1, 40, 40, 48, 32, 1, 0, 1),          # K = 48 < one tile, Cout = 32
+]
+
+
+@pytest.mark.parametrize("case", B16_CASES)
+def test_conv_bf16_compute_mode_matches_exact_products_of_the_rounded_operands(ops, case):
+    """bf16 compute mode (sh_conv_fprop_b16 / _dgrad_b16 / _wgrad_b16): operands rounded ONCE to bf16, one MFMA product, fp32 accumulate.
+    The reference is therefore exact: fp64 convolutions of the bf16-rounded operands; what remains is the fp32 summation order --
+    2e-5 of the result's scale (the fp32-accurate kernels are held to the same figure against fp32 torch).  Forward also through the
+    producer's BatchNorm + ReLU in the loader (rounded to bf16 AFTER the activation, evaluated in sh_bn_act's operation order), with
+    BatchNorm statistics from the fp32 accumulators and a bf16- or fp32-stored output; input gradient with fp32 and bf16 gradient
+    operands, addend, BatchNorm-backward epilogue; weight gradient plain and through the loader."""
+    n, h, w, cin, cout, k, p, d = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    bf = lambda t: t.to(torch.bfloat16)
+    x = bf(torch.randn(n, cin, h, w, generator=g))
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    wq = bf(wt).double()
+    scale, shift = torch.randn(cin, generator=g), 0.3 * torch.randn(cin, generator=g)
+    mean, invstd = 0.2 * torch.randn(cin, generator=g), 0.5 + torch.rand(cin, generator=g)
+    coefs = torch.stack([mean, invstd, scale, shift]).to(DEV).contiguous()
+    pre = x.float() * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)                  # fp32, mul then add: sh_bn_act's own order
+    act = bf(torch.relu(pre))
+    xg, wg = nhwc_bf16(x), wl(wt)
+    ref_plain = F.conv2d(x.double(), wq, None, 1, p, d)
+    ref_act = F.conv2d(act.double(), wq, None, 1, p, d)
+    ho, wo = ref_plain.shape[2:]
+    m = n * ho * wo
+    tol = lambda r: dict(rtol=2e-5, atol=2e-5 * float(r.abs().max()))
+    with ops.compute_as(torch.bfloat16):
+        assert ops.b16()
+        # ---- forward: plain and through the loader; fp32 output pins the accumulation, bf16 output is its rounding
+        for coef, ref in ((None, ref_plain), (coefs, ref_act)):
+            y = ops.new_act(n, cout, ho, wo, DEV, zero=True)
+            part = ops.conv_partials(m, cout, DEV)
+            assert ops._fprop_b16(xg, coef, wg, None, y, part, 1, p, d), "no bf16 instantiation for a model shape"
+            np.testing.assert_allclose(y.cpu().double().numpy(), ref.numpy(), **tol(ref))
+            st = ops.bn_finalize(part, m, None, None, 1e-5, 0.1, None, None, cout, DEV, rows=64)
+            close(st[0], ref.float().mean((0, 2, 3)), 1e-4, 1e-5, "BatchNorm mean from the fp32 accumulators")
+            close(st[1], 1.0 / torch.sqrt(ref.float().var((0, 2, 3), unbiased=False) + 1e-5), 1e-4, 1e-5, "invstd")
+            yb = ops.new_act(n, cout, ho, wo, DEV, zero=True, dtype=torch.bfloat16)
+            assert ops._fprop_b16(xg, coef, wg, None, yb, None, 1, p, d)
+            assert torch.equal(yb, y.to(torch.bfloat16)), "bf16 output = round-to-nearest-even of the fp32 result"
+        # ---- input gradient: fp32 and bf16 gradient operands
+        dy = torch.randn(n, cout, ho, wo, generator=g)
+        dyq = bf(dy)
+        ref_dx = torch.nn.grad.conv2d_input((n, cin, h, w), wq, dyq.double(), 1, p, d)
+        ldy = ops.pad8(cout)
+        dy32 = ops.new_act(n, cout, ho, wo, DEV, ld=ldy, zero=True)
+        dy32.copy_(dyq.float().to(DEV))                                                    # fp32 tensor holding bf16-representable values
+        dy16 = nhwc_bf16(dyq, ld=ldy)
+        for dyt in (dy32, dy16):
+            dx = ops.new_act(n, cin, h, w, DEV)
+            assert ops._dgrad_b16(dyt, wg, dx, 1, p, d)
+            np.testing.assert_allclose(dx.cpu().double().numpy(), ref_dx.numpy(), **tol(ref_dx))
+        add = bf(torch.randn(n, cin, h, w, generator=g))
+        dxb = ops.new_act(n, cin, h, w, DEV, dtype=torch.bfloat16)
+        assert ops._dgrad_b16(dy16, wg, dxb, 1, p, d, addend=nhwc_bf16(add))
+        want = (ref_dx + add.double()).float()
+        err = (dxb.cpu().double() - want.double()).abs().max() / want.abs().max()
+        assert float(err) < 2 ** -8, ("bf16 dx + bf16 addend", float(err))                 # one bf16 rounding of the sum
+        # BatchNorm-backward epilogue on a deferred input: g = relumask(y_prev * scale + shift) * dx, partial sums of g and g * xhat
+        gbuf = ops.new_act(n, cin, h, w, DEV)
+        bpart = torch.empty((-(-n * h * w // 64), 2, cin), device=DEV)
+        assert ops._dgrad_b16(dy16, wg, gbuf, 1, p, d, bnb=(xg, coefs, True, bpart, None))
+        g_ref = ref_dx * (pre > 0)
+        np.testing.assert_allclose(gbuf.cpu().double().numpy(), g_ref.numpy(), **tol(ref_dx))
+        xhat = ((x.double() - mean.double().view(1, -1, 1, 1)) * invstd.double().view(1, -1, 1, 1))
+        gk = gbuf.cpu().double()
+        sums = bpart.double().sum(0).cpu()
+        np.testing.assert_allclose(sums[0].numpy(), gk.sum((0, 2, 3)).numpy(), rtol=1e-5, atol=1e-5 * float(gk.abs().sum((0, 2, 3)).max()))
+        np.testing.assert_allclose(sums[1].numpy(), (gk * xhat).sum((0, 2, 3)).numpy(), rtol=1e-5,
+                                   atol=1e-5 * float((gk * xhat).abs().sum((0, 2, 3)).max()))
+        # ---- weight gradient: plain and with x through the loader, fp32 and bf16 gradient operands
+        if cout % 8 == 0:
+            for xin, coef in ((x, None), (act, coefs)):
+                ref_dw = torch.nn.grad.conv2d_weight(xin.double(), (cout, cin, k, k), dyq.double(), 1, p, d)
+                for dyt in (dy32, dy16):
+                    dw = torch.empty_like(wg)
+                    assert ops._wgrad_b16(xg, dyt, dw, 1, p, d, False, coef), "no bf16 weight-gradient instantiation for a model shape"
+                    np.testing.assert_allclose(dw.cpu().double().numpy(), ref_dw.numpy(), **tol(ref_dw))
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 256), (1, 24, 16, 128, 512), (4, 16, 16, 512, 2048), (2, 32, 32, 64, 128)])
+def test_conv_bf16_compute_mode_deferred_batchnorm_backward(ops, case):
+    """lin(g, y) in the bf16 loaders (1x1 input gradient and weight gradient; g and y bf16 tensors): the operand is
+    bf16(A*g + B*(y - mean) + D) evaluated in fp32 with two fused multiply-adds -- reference: the same expression in fp64 rounded to
+    bf16, exact products in fp64; an operand element may round to the neighbouring bf16 value where fp32 and fp64 evaluations differ,
+    so the bound is 2^-9 of the result's scale times a small factor (measured ~1e-4), not the 2e-5 of the plain kernels."""
+    n, h, w, cin, cout = case
+    g = torch.Generator().manual_seed(sum(case) + 3)
+    bf = lambda t: t.to(torch.bfloat16)
+    x = bf(torch.randn(n, cin, h, w, generator=g))
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    gq, yq = bf(torch.randn(n, cout, h, w, generator=g)), bf(torch.randn(n, cout, h, w, generator=g))
+    lin = torch.stack([0.5 + torch.rand(cout, generator=g), 0.1 * torch.randn(cout, generator=g), 0.2 * torch.randn(cout, generator=g),
+                       0.05 * torch.randn(cout, generator=g)])
+    v = lambda i: lin[i].double().view(1, -1, 1, 1)
+    dy = bf((v(0) * gq.double() + v(1) * (yq.double() - v(2)) + v(3)).float()).double()
+    wq = bf(wt).double()
+    ref_dx = torch.nn.grad.conv2d_input((n, cin, h, w), wq, dy, 1, 0, 1)
+    ref_dw = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 1, 1), dy, 1, 0, 1)
+    ling = lin.to(DEV).contiguous()
+    with ops.compute_as(torch.bfloat16):
+        dx = ops.new_act(n, cin, h, w, DEV)
+        assert ops._dgrad_b16(nhwc_bf16(gq), wl(wt), dx, 1, 0, 1, lin=(nhwc_bf16(yq), ling))
+        e = float((dx.cpu().double() - ref_dx).abs().max() / ref_dx.abs().max())
+        assert e < 1e-3, e
+        dd = ops.DeferredDy(nhwc_bf16(gq), nhwc_bf16(yq), ling, None, None, None)
+        dw = torch.empty_like(wl(wt))
+        assert ops._wgrad_b16(nhwc_bf16(x), dd, dw, 1, 0, 1, False, None)
+        e = float((dw.cpu().double() - ref_dw).abs().max() / ref_dw.abs().max())
+        assert e < 1e-3, e

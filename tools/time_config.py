@@ -24,6 +24,8 @@ def main():
         batch = int(sys.argv[2])
     if len(sys.argv) > 3 and sys.argv[3] == "bf16":          # trunk activations stored as bf16 (BASELINE configs[4])
         cfg["act_dtype"] = torch.bfloat16
+    if len(sys.argv) > 3 and sys.argv[3] == "b16":           # bf16 COMPUTE mode: bf16 storage + one MFMA product per tile
+        cfg["compute_dtype"] = torch.bfloat16
     torch.manual_seed(0)
     tr = SegHieroTrainer(lr=0.01, device="cuda:0", **cfg)
     tr.train()
@@ -43,8 +45,11 @@ def main():
     with ops.profile() as prof:
         tr.train_step(img, lab8, 0)
     torch.cuda.synchronize()
-    for k, v in sorted(prof.rows.items(), key=lambda kv: -kv[1]["ms"])[:16]:
-        print(f"   {k:28s} {v['ms']:8.2f} ms  {v['calls']:5d} calls")
+    tot = sum(v["ms"] for v in prof.rows.values())
+    print(f"   one-stream kernel time {tot:.2f} ms in {sum(v['calls'] for v in prof.rows.values())} launches")
+    for k, v in sorted(prof.rows.items(), key=lambda kv: -kv[1]["ms"])[:22]:
+        rate = f"{v['flops'] / v['ms'] / 1e9:7.1f} TF  {v['bytes'] / v['ms'] / 1e6:7.0f} GB/s(alg)" if v["flops"] else ""
+        print(f"   {k:28s} {v['ms']:8.2f} ms  {v['calls']:5d} calls  {rate}")
 
 
 if __name__ == "__main__":
