@@ -204,7 +204,8 @@ def main():
     if not args.no_units:
         try:
             from seghiero_amd import units
-            roof_units = {"aspp_ds_branch": units.measure(device=dev, batch=args.batch)}
+            roof_units = {"aspp_ds_branch": units.measure(device=dev, batch=args.batch),
+                          "aspp_ds_branch_bf16": units.measure(device=dev, batch=args.batch, bf16=True)}
         except Exception as e:                  # never lose the headline line to the side measurement
             roof_units = {"aspp_ds_branch": {"error": repr(e)}}
     breakdown = {k: round(v["ms"], 2) for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])[:16]}

@@ -77,7 +77,7 @@ class DepthwiseSeparableASPPModule(nn.Module):
 ASPP_GROUPED = __import__("os").environ.get("SEGHIERO_ASPP_GROUPED", "1") != "0"
 
 
-def _aspp_branches_grouped(aspp, c4, cat, A, training, R):
+def _aspp_branches_grouped(aspp, c4, cat, A, training, R, c4b=None):
     """The 1x1 branch and the depthwise-separable branches of the ASPP (``sep_aspp_contrast_head.py:100-131``) as ONE unit:
 
     * a branch whose dilation is >= the feature map (24 / 36 at 16 x 16) is ``w_centre * c4`` -- no depthwise kernel
@@ -87,6 +87,9 @@ def _aspp_branches_grouped(aspp, c4, cat, A, training, R):
     * all pointwise convs (+ the 1x1 branch) are one grouped launch (``ops.conv1x1_grouped_fprop``): a 512-tile GEMM instead of
       four under-filled ones with K slices and slab reduces; one BatchNorm + ReLU pass writes the four slices of the concat.
 
+    c4b (bf16 compute mode): the bf16 copy of c4 -- the grouped launch then reads bf16 sources (c4b as is / through the centre-tap
+    coefficients, a bf16 copy of the dilated depthwise output) with one MFMA product per tile; statistics, coefficient tables and the
+    raw outputs stay fp32.
     Fills R["b0"], R["pw<i>"] and R["dw<i>"] / R["dwc<i>"]; False = geometry not eligible (the caller runs the branches one by one)."""
     n, cin, h, w = c4.shape
     nbr = len(aspp.dilations)
@@ -95,7 +98,8 @@ def _aspp_branches_grouped(aspp, c4, cat, A, training, R):
         return False
     dev = c4.device
     m = n * h * w
-    sources, weights, bns = [(c4, None)], [aspp.branches[0][0].weight], [aspp.branches[0][1]]
+    src4 = c4 if c4b is None else c4b
+    sources, weights, bns = [(src4, None)], [aspp.branches[0][0].weight], [aspp.branches[0][1]]
     centre = [i for i, d in enumerate(aspp.dilations[1:], start=1) if d >= h and d >= w]      # only the centre tap touches the image
     if centre:                                           # y = w_centre * c4: statistics of c4 once, all such BatchNorms in one launch
         x_stats = ops.channel_stats(c4)
@@ -108,10 +112,11 @@ def _aspp_branches_grouped(aspp, c4, cat, A, training, R):
     for i, d in enumerate(aspp.dilations[1:], start=1):
         ds = aspp.branches[i][0]
         if i in centre:
-            sources.append((c4, R[f"dwc{i}"][0]))
+            sources.append((src4, R[f"dwc{i}"][0]))
         else:
-            t, R[f"dw{i}"] = L.dw_fwd(c4, ds.depthwise.weight, d, ds.bn_dw, training, lazy=True)
-            sources.append((t.y, t.coefs))
+            with ops.stored_as(torch.float32):          # (the dilated depthwise kernels are fp32)
+                t, R[f"dw{i}"] = L.dw_fwd(c4, ds.depthwise.weight, d, ds.bn_dw, training, lazy=True)
+            sources.append((t.y if c4b is None else t.y.to(torch.bfloat16), t.coefs))
         weights.append(ds.pointwise.weight)
         bns.append(ds.bn_pw)
     ycat = ops.new_act(n, nbr * A, h, w, dev)
@@ -125,7 +130,7 @@ def _aspp_branches_grouped(aspp, c4, cat, A, training, R):
     for g in range(nbr):
         rec = L.CBARec()
         src, cf = sources[g]
-        rec.x = src if cf is None else L.Lazy(src, cf)
+        rec.x = src if cf is None else L.Lazy(src, cf, grad32=True)      # (gradients into c4 / the depthwise branch are accumulated in fp32)
         rec.y, rec.out, rec.coefs = ycat[:, g * A:(g + 1) * A], None, coefs_cat[:, g * A:(g + 1) * A]
         rec.relu, rec.geom, rec.weight, rec.has_res, rec.mask = True, G1, weights[g], False, None
         R["b0" if g == 0 else f"pw{g}"] = rec
@@ -154,15 +159,20 @@ class _HeadFn(torch.autograd.Function):
         n, cin, h, w = c4.shape
         dev = c4.device
         R = {}
+        # bf16 compute mode: the 2048-channel consumers of c4 (projection head, ASPP pointwise convs) read a bf16 copy of it (8 M elements:
+        # the trunk hands its stage outputs on as fp32 tensors); pooling, statistics and the dilated depthwise conv keep the fp32 tensor
+        b16 = ops.b16() and training and L.FUSE_BN and mod.act_dtype == torch.bfloat16 and cin % 8 == 0
+        c4b = c4.to(torch.bfloat16) if b16 else None
         # ---- projection head -> l2-normalised embedding (:12-30)
         proj = mod.proj_head.proj
-        if isinstance(proj, nn.Sequential):
-            p1, R["p1"] = L.cba_fwd(c4, proj[0].weight, G1, proj[1], True, training, lazy=True)
-            e_raw = L.conv_fwd(p1, proj[3].weight, None, G1)
-            R["p1_out"] = p1
-        else:
-            e_raw = L.conv_fwd(c4, proj.weight, None, G1)
-            R["emb_in"] = c4
+        with ops.stored_as(torch.bfloat16 if b16 else torch.float32):
+            if isinstance(proj, nn.Sequential):
+                p1, R["p1"] = L.cba_fwd(c4b if b16 else c4, proj[0].weight, G1, proj[1], True, training, lazy=True)
+                e_raw = L.conv_fwd(p1, proj[3].weight, None, G1)
+                R["p1_out"] = p1
+            else:
+                e_raw = L.conv_fwd(c4b if b16 else c4, proj.weight, None, G1)
+                R["emb_in"] = c4b if b16 else c4
         if ops.pm(e_raw)[1] != e_raw.shape[1]:
             e_raw = ops.dense_copy(e_raw)
         emb, norm = ops.l2norm_fwd(e_raw)
@@ -171,11 +181,14 @@ class _HeadFn(torch.autograd.Function):
         aspp = mod.aspp
         A = aspp.image_pool_conv[0].out_channels
         nb = len(aspp.dilations) + 1
-        cat = ops.new_act(n, A * nb, h, w, dev)
+        cat = ops.new_act(n, A * nb, h, w, dev, dtype=torch.bfloat16 if b16 else torch.float32)
         pooled = ops.avgpool_fwd(c4)
         ip, R["ip"] = L.cba_fwd(pooled, aspp.image_pool_conv[0].weight, G1, aspp.image_pool_conv[1], True, training)
-        ops.broadcast_hw(ip, cat[:, 0:A])
-        if not _aspp_branches_grouped(aspp, c4, cat, A, training, R):
+        if b16:
+            cat[:, 0:A].copy_(ip.expand(n, A, h, w))       # (sh_broadcast_hw writes fp32; [N, A] values into a 16 x 16 bf16 slice)
+        else:
+            ops.broadcast_hw(ip, cat[:, 0:A])
+        if not _aspp_branches_grouped(aspp, c4, cat, A, training, R, c4b):
             _, R["b0"] = L.cba_fwd(c4, aspp.branches[0][0].weight, G1, aspp.branches[0][1], True, training, out=cat[:, A:2 * A])
             for i, d in enumerate(aspp.dilations[1:], start=1):
                 ds = aspp.branches[i][0]
@@ -253,7 +266,7 @@ class _HeadFn(torch.autograd.Function):
             put_cba(mod.bottleneck[0].weight, mod.bottleneck[1], res)
             dcat = res[0]
             # gradients into C4: 1x1 branch first (allocates), the rest accumulate into it
-            res = L.cba_bwd(R["b0"], aspp.branches[0][1], dcat[:, A:2 * A])
+            res = L.cba_bwd(R["b0"], aspp.branches[0][1], dcat[:, A:2 * A], dx32=True)      # dc4 is accumulated in fp32
             put_cba(aspp.branches[0][0].weight, aspp.branches[0][1], res)
             dc4 = res[0]
             for i in range(1, len(aspp.dilations)):
@@ -265,7 +278,7 @@ class _HeadFn(torch.autograd.Function):
                     # coefficients yields d/dc4 directly; the depthwise weight gradient is closed-form (sh_dw_center_wgrad)
                     coefs_x, isy = R[f"dwc{i}"]
                     xin = R[f"pw{i}"].x.y
-                    dxc, dg, db, _ = ops.bn_backward(res[0], None, xin, coefs_x, ds.bn_dw.weight, 2)
+                    dxc, dg, db, _ = ops.bn_backward(res[0], None, xin, coefs_x, ds.bn_dw.weight, 2, grad32=True)
                     ops._call("sh_axpy", dc4.data_ptr(), dxc.data_ptr(), 1.0, dc4.numel(), ops._st())
                     dww = L.new_grad(ds.depthwise.weight)
                     # (a centre tap that is exactly 0 leaves no trace in dgamma: those channels read the masked gradient itself)
@@ -274,7 +287,7 @@ class _HeadFn(torch.autograd.Function):
                 else:
                     _, dww, dg, db = L.dw_bwd(R[f"dw{i}"], ds.bn_dw, res[0], dx_accumulate_into=dc4)
                 gm.put(ds.depthwise.weight, dww); gm.put(ds.bn_dw.weight, dg); gm.put(ds.bn_dw.bias, db)
-            dip = ops.sum_hw(dcat[:, 0:A])
+            dip = ops.sum_hw(ops.f32(dcat[:, 0:A]))
             res = L.cba_bwd(R["ip"], aspp.image_pool_conv[1], dip)
             put_cba(aspp.image_pool_conv[0].weight, aspp.image_pool_conv[1], res)
             ops.avgpool_bwd(res[0], dc4, accumulate=True)
@@ -284,11 +297,11 @@ class _HeadFn(torch.autograd.Function):
             if isinstance(proj, nn.Sequential):
                 dp1, dw3 = L.conv_bwd(R["p1_out"], proj[3].weight, G1, L.grad_as_nhwc_padded(de, de.shape[1]))
                 gm.put(proj[3].weight, dw3)
-                res = L.cba_bwd(R["p1"], proj[1], dp1, addend=dc4)
+                res = L.cba_bwd(R["p1"], proj[1], dp1, addend=dc4, dx32=True)
                 put_cba(proj[0].weight, proj[1], res)
                 dc4 = res[0]
             else:
-                dc4n, dwp = L.conv_bwd(R["emb_in"], proj.weight, G1, L.grad_as_nhwc_padded(de, de.shape[1]), addend=dc4)
+                dc4n, dwp = L.conv_bwd(R["emb_in"], proj.weight, G1, L.grad_as_nhwc_padded(de, de.shape[1]), addend=dc4, dx32=True)
                 gm.put(proj.weight, dwp)
                 dc4 = dc4n
         ctx.R = None

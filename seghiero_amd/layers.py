@@ -338,14 +338,14 @@ def conv_fwd(x, weight, bias, geom):
     return y
 
 
-def conv_bwd(x, weight, geom, dy, need_dx=True, addend=None):
+def conv_bwd(x, weight, geom, dy, need_dx=True, addend=None, dx32=False):
     """dy must be NHWC with its padding lanes zeroed.  -> (dx (tensor, or GradPack for a deferred input), dweight)."""
     s, p, d = geom
     dw = new_grad(weight)
     _wgrad(x, dy, dw, s, p, d)
     dx = None
     if need_dx:
-        dx = _dgrad(x, dy, weight, s, p, d, addend=addend)
+        dx = _dgrad(x, dy, weight, s, p, d, addend=addend, grad32=dx32)
     return dx, dw
 
 

@@ -939,6 +939,18 @@ def conv1x1_grouped_fprop(sources, weights, y, partials):
     k = len(sources)
     n, cin, h, w = sources[0][0].shape
     a = weights[0].shape[0]
+    if _B16 and all(x.dtype == torch.bfloat16 for x, _ in sources):      # bf16 compute mode: every group's input is a bf16 tensor
+        xs, lds = zip(*[pmx(x)[:2] for x, _ in sources])
+        yp, ldy, yb = pmx(y)
+        vp = ctypes.c_void_p
+        arr = lambda vals: (vp * k)(*vals)
+        cost = (2.0 * n * h * w * cin * a * k, float(n * h * w * (2 * cin + (2 if yb else 4) * a) * k + 2 * a * cin * k))
+        wbs = [weights_bf16(wt)[0] for wt in weights]         # (held until the launch is enqueued: copies made on demand are fresh tensors)
+        return _call_fused("sh_conv1x1_grouped_fprop_b16", k, arr(xs), (ctypes.c_int * k)(*lds),
+                           arr([None if c is None else c[2].data_ptr() for _, c in sources]),
+                           arr([None if c is None else c[3].data_ptr() for _, c in sources]),
+                           arr([t.data_ptr() for t in wbs]), yp, ldy, partials.data_ptr(), n, h, w, cin, a, yb << 1, _st(),
+                           cost=cost, key=f"{k} x ({n}x{h}x{w} {cin}->{a} k1)")
     xs, lds = zip(*[pm(x) for x, _ in sources])
     yp, ldy = pm(y)
     vp = ctypes.c_void_p

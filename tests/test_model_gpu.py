@@ -910,3 +910,43 @@ def test_bf16_compute_mode_of_the_trunk(sa, depth, size):
     worst.sort(reverse=True)
     print("bf16 compute mode, per block vs fp32-accurate: worst", worst[:4], "median", worst[len(worst) // 2])
     assert worst[0][0] < 0.25 and worst[len(worst) // 2][0] < 0.12, (worst[:5], worst[len(worst) // 2])
+
+
+def test_bf16_compute_mode_of_the_head(sa):
+    """The contrast head in bf16 compute mode (DepthwiseSeparableASPPContrastHead.compute_dtype = act_dtype = bfloat16): the projection
+    head and the grouped ASPP launch read a bf16 copy of c4, the bottleneck and the decoder's pointwise convs bf16-stored tensors, all
+    with one MFMA product per tile; statistics, coefficient tables, depthwise / pooling / resampling kernels and the gradient sums
+    into c4 stay fp32.  Against the fp32-accurate HIP head on the same weights and inputs (stated tolerances of the mode; the
+    kernels are pinned exactly in tests/test_ops_gpu.py): logits within 3e-2 relative L2, embedding within 2e-2, every parameter
+    gradient within 0.4 and the median within 0.25, input gradients within 0.3 (ReLU flips of rounded pre-activations through four
+    BatchNorm + ReLU layers in a row, as test_bf16_activation_storage_of_the_decoder); the bf16 kernels really ran."""
+    import copy
+    from seghiero_amd import ops
+    from seghiero_amd.head import DepthwiseSeparableASPPContrastHead
+    torch.manual_seed(4)
+    kw = dict(in_channels=256, c1_in_channels=64, c1_channels=48, aspp_channels=128, dilations=(1, 12, 24, 36), num_classes=13,
+              proj_dim=64, proj_type="convmlp")
+    a = DepthwiseSeparableASPPContrastHead(**kw).to(DEV).train()
+    b = copy.deepcopy(a)
+    b.act_dtype = b.compute_dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(9)
+    c1 = torch.randn(2, 64, 64, 64, generator=g).relu().bfloat16().float().to(DEV)
+    c4 = torch.randn(2, 256, 16, 16, generator=g).relu().bfloat16().float().to(DEV)
+    gl = torch.randn(2, 13, 64, 64, generator=g).to(DEV)
+    ge = torch.randn(2, 64, 16, 16, generator=g).to(DEV)
+    res = {}
+    for name, mod in (("f32", a), ("b16", b)):
+        x1, x4 = c1.clone().requires_grad_(True), c4.clone().requires_grad_(True)
+        with ops.profile() as prof:
+            lo, em = mod([x1, None, None, x4])
+            ((lo * gl).sum() + (em * ge).sum()).backward()
+        res[name] = (lo.detach(), em.detach(), x1.grad, x4.grad, {k: p.grad for k, p in mod.named_parameters()}, prof.rows)
+    rows = res["b16"][5]
+    assert rows.get("sh_conv_fprop_b16", {}).get("calls", 0) >= 4 and "sh_conv1x1_grouped_fprop_b16" in rows and "sh_conv_dgrad_b16" in rows and \
+        "sh_conv_wgrad_b16" in rows, sorted(rows)
+    assert relerr(res["b16"][0], res["f32"][0]) < 3e-2, relerr(res["b16"][0], res["f32"][0])
+    assert relerr(res["b16"][1], res["f32"][1]) < 2e-2, relerr(res["b16"][1], res["f32"][1])
+    assert relerr(res["b16"][2], res["f32"][2]) < 0.3 and relerr(res["b16"][3], res["f32"][3]) < 0.3, (relerr(res["b16"][2], res["f32"][2]), relerr(res["b16"][3], res["f32"][3]))
+    errs = sorted(((relerr(res["b16"][4][k], v), k) for k, v in res["f32"][4].items() if not (k.endswith("bn_pw.weight") or k.endswith("bn_dw.weight") or k.endswith(".1.weight"))), reverse=True)
+    print("bf16 compute head: logits", relerr(res["b16"][0], res["f32"][0]), "emb", relerr(res["b16"][1], res["f32"][1]), "worst grads", errs[:4], "median", errs[len(errs) // 2])
+    assert errs[0][0] < 0.4 and errs[len(errs) // 2][0] < 0.25, (errs[:5], errs[len(errs) // 2])
