@@ -70,11 +70,16 @@ __device__ __forceinline__ F8 quad_mask_load8(const void* base, long long byte_i
 #define B16_OUT_BF 128
 #define B16_ADD_BF 256
 
-template <int MODE, int TN, int AFF, int EPI, int SK, int TAP, int GRP, int A32>
-__global__ __launch_bounds__(256, 2) void conv_b16_kernel(const ConvQ p) {
-    constexpr int TM = 2, NT = 256, BM = 128, BN = 64 * TN;
+// W8: the 128 x 128 tile on EIGHT waves (2 x 4, a wave owns 64 x 32) instead of four (2 x 2, 64 x 64): half the accumulators and staging
+// registers per wave (<= 128 VGPRs), so two blocks = 16 waves per CU, four per SIMD.  Measured on the 512 -> 512 pointwise conv at 128^2
+// (PMC, 4 waves): the matrix pipe busy 25 %, each wave spends 1,680 VALU instructions on its prologue / epilogue against 128 MFMAs, and
+// with two waves per SIMD nothing covers a wave that sits in its epilogue or waits for its first loads.
+template <int MODE, int TN, int AFF, int EPI, int SK, int TAP, int GRP, int A32, int W8 = 0>
+__global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void conv_b16_kernel(const ConvQ p) {
+    constexpr int TM = 2, WGN = W8 ? 4 : 2, TNW = W8 ? 1 : TN, NT = 128 * WGN, BM = 128, BN = 32 * TNW * WGN;
+    static_assert(!W8 || TN == 2, "the eight-wave form is the 128 x 128 tile");
     constexpr int A_BUF = BM * 128, B_BUF = BN * 128;                // bytes per LDS buffer
-    constexpr int RPP = 32, NA = BM / RPP, NB = BN / RPP;            // loader: 8 lanes x 16 bytes per row, 32 rows per pass
+    constexpr int RPP = NT / 8, NA = BM / RPP, NB = BN / RPP;        // loader: 8 lanes x 16 bytes per row, NT / 8 rows per pass
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const As = smem;
     unsigned char* const Bs = smem + 2 * A_BUF;
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void conv_b16_kernel(const ConvQ p) {
     static_assert(!A32 || (MODE == DGRAD && AFF == 0), "fp32 A streams are plain gradients (the lin loader takes a bf16 g)");
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WGN, wn = wave % WGN, l31 = lane & 31, h = lane >> 5;
     const unsigned nblk = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
     const unsigned bid = xcd_remap(blockIdx.x, nblk);
     const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
@@ -116,10 +121,14 @@ __global__ __launch_bounds__(256, 2) void conv_b16_kernel(const ConvQ p) {
     int b_row[NB];
     unsigned b_ok[NB];
     int cur_tap = -1;
+    // 1x1, stride 1, no padding (every pointwise conv of the model): pixel m of the output is row m of the operand -- no coordinate
+    // arithmetic (eight integer divisions per thread otherwise: ~300 VALU instructions of a kernel that issues 128 MFMAs per wave)
+    const bool direct = TAP == 0 && p.stride == 1 && p.pad == 0;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int m = m0 + r0 + RPP * i;
-        if (m < Mc) {
+        if (direct) { a_y[i] = m < Mc ? 0 : -(1 << 28); a_x[i] = 0; a_nb[i] = m < Mc ? m : 0; }
+        else if (m < Mc) {
             if constexpr (MODE == FPROP) {
                 const int ow = m % p.Wo, q = m / p.Wo, oh = q % p.Ho, n = q / p.Ho;
                 a_y[i] = oh * p.stride - p.pad; a_x[i] = ow * p.stride - p.pad; a_nb[i] = n * p.H * p.W;
@@ -139,6 +148,15 @@ __global__ __launch_bounds__(256, 2) void conv_b16_kernel(const ConvQ p) {
     [[maybe_unused]] int a_off2[NA];
     unsigned a_ok[NA];
     auto set_tap = [&](int tap) {
+        if (direct) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                a_ok[i] = a_y[i] == 0 ? ~0u : 0u;
+                a_off[i] = a_nb[i] * lda;
+                if constexpr (AFF == 2) a_off2[i] = a_nb[i] * (int)p.lda2;
+            }
+            return;
+        }
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
         const int dh = kh * p.dil, dw = kw * p.dil;
 #pragma unroll
@@ -241,12 +259,13 @@ __global__ __launch_bounds__(256, 2) void conv_b16_kernel(const ConvQ p) {
                         v[2 * e] = ok ? w0 : 0.f; v[2 * e + 1] = ok ? w1 : 0.f;
                     }
                 } else if constexpr (AFF) {
-                    // sh_bn_act's own operation order, so the ReLU mask the backward recomputes from y * scale + shift is this one
-                    const bool ok = (R.okm >> i) & 1u;
+                    // one fused multiply-add per element (the value is rounded to bf16 next; the fp32-accurate kernels keep sh_bn_act's
+                    // unfused order for bit-equality with the separate pass); rows beyond M / padded taps are zeroed AFTER the pack
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float w = fmaxf(v[e] * c0[e] + c1[e], aff_floor); v[e] = ok ? w : 0.f; }
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], c0[e], c1[e]), aff_floor);
                 }
-                const u32x4 o = {pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
+                u32x4 o = {pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
+                if constexpr (AFF == 1) { const unsigned okw = ((R.okm >> i) & 1u) ? ~0u : 0u; o[0] &= okw; o[1] &= okw; o[2] &= okw; o[3] &= okw; }
                 *reinterpret_cast<u32x4*>(ad + RPP * i * 128) = o;
             }
         }
@@ -255,15 +274,15 @@ __global__ __launch_bounds__(256, 2) void conv_b16_kernel(const ConvQ p) {
         for (int i = 0; i < NB; ++i) *reinterpret_cast<u32x4*>(bd + RPP * i * 128) = R.b[i];
     };
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[TM][TNW];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TNW; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int arow = wm * 64 + l31, brow = wn * 32 * TN + l31;
+    const int arow = wm * 64 + l31, brow = wn * 32 * TNW + l31;
     const int swz_r = swz8(l31);                                 // rows l31 + 32 k share (row >> 1) & 7
     auto compute_tile = [&](int buf) {
         const unsigned char* const ab = As + buf * A_BUF + arow * 128;
@@ -271,14 +290,14 @@ __global__ __launch_bounds__(256, 2) void conv_b16_kernel(const ConvQ p) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int rd = ((2 * ks + h) ^ swz_r) << 4;
-            bf16x8 bfr[TN];
+            bf16x8 bfr[TNW];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bb + 32 * j * 128 + rd));
+            for (int j = 0; j < TNW; ++j) bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bb + 32 * j * 128 + rd));
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const bf16x8 af = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ab + 32 * i * 128 + rd));
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(af, bfr[j], acc[i][j]);
+                for (int j = 0; j < TNW; ++j) acc[i][j] = mfma_bf16(af, bfr[j], acc[i][j]);
             }
         }
     };
@@ -314,8 +333,8 @@ __global__ __launch_bounds__(256, 2) void conv_b16_kernel(const ConvQ p) {
     if constexpr (SK) {
         float* slab = p.slab + (long long)blockIdx.y * p.M * p.ldslab;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * 32 * TN + 32 * j + l31;
+        for (int j = 0; j < TNW; ++j) {
+            const int n = n0 + wn * 32 * TNW + 32 * j + l31;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -334,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void conv_b16_kernel(const ConvQ p) {
     // private to the wave (LDS operations of one wave complete in order), the tile buffers it overlays were released by the main loop's
     // last barrier: no block-wide barrier in here, the four waves drain their tiles independently.
     {
-        constexpr int WC = 32 * TN, RS = WC + 4, LPR = WC / 8, RPI = 64 / LPR, NRD = 32 / RPI;
+        constexpr int WC = 32 * TNW, RS = WC + 4, LPR = WC / 8, RPI = 64 / LPR, NRD = 32 / RPI;
         float* const stage = reinterpret_cast<float*>(smem) + wave * (32 * RS);
         const int rr = lane / LPR, c8 = (lane % LPR) * 8;
         const int ncv = n0 + wn * WC + c8;
@@ -344,10 +363,105 @@ __global__ __launch_bounds__(256, 2) void conv_b16_kernel(const ConvQ p) {
         if constexpr (EPI == 2) { if (nokv) { v_mu = ld8(p.bnb_mean, ncv, 0); v_is = ld8(p.bnb_invstd, ncv, 0); v_sc = ld8(p.bnb_scale, ncv, 0); v_sh = ld8(p.bnb_shift, ncv, 0); } }
         [[maybe_unused]] F8 pend_gs = f8_zero(), pend_gq = f8_zero();
         const int out_bf = MODE == FPROP ? (p.act & 2) : (p.act & B16_OUT_BF);
+        // Input-gradient epilogues whose tensors are all bf16 (the bf16-gradient step): every load of the wave's 64 x 64 tile -- addend, the
+        // BatchNorm-backward y tile, the ReLU quad mask -- is issued up front into the registers the staging sets no longer need (16-byte
+        // raw words, widened when used): ONE memory round trip per wave instead of one per two row groups (measured on the 1024 -> 256
+        // layer-3 gradient with residual mask and identity addend: 80 us for a 25 us byte count, the four dependent trips of the chunked form)
+        bool fast = false;
+        if constexpr (MODE == DGRAD) {
+            fast = (p.act & B16_OUT_BF) && (p.extra == nullptr || (p.act & B16_ADD_BF)) &&
+                   (EPI != 2 || ((p.act & 4) && (p.bnb_out == nullptr || (p.act & 64))));
+        }
+        if (fast) {
+            if constexpr (MODE == DGRAD) {
+                constexpr int NL = TM * NRD;
+                u32x4 rad[NL];
+                [[maybe_unused]] u32x4 ryv[EPI == 2 ? NL : 1];
+                [[maybe_unused]] unsigned rmk[EPI == 2 ? NL : 1];
+                const bool has_add = p.extra != nullptr, has_mask = EPI == 2 && p.bnb_out != nullptr;
+#pragma unroll
+                for (int q = 0; q < NL; ++q) {
+                    const long long m = m0 + wm * 64 + 32 * (q / NRD) + (q % NRD) * RPI + rr;
+                    const bool ok = m < Mc && nokv;
+                    rad[q] = u32x4{0u, 0u, 0u, 0u};
+                    if (ok && has_add) rad[q] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(p.extra) + m * p.ldadd + ncv);
+                    if constexpr (EPI == 2) {
+                        ryv[q] = u32x4{0u, 0u, 0u, 0u}; rmk[q] = 0xffffu;
+                        if (ok) {
+                            ryv[q] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(p.bnb_y) + m * p.bnb_ldy + ncv);
+                            if (has_mask) rmk[q] = *reinterpret_cast<const unsigned short*>(reinterpret_cast<const unsigned char*>(p.bnb_out) + m * p.bnb_ldo + (ncv >> 2));
+                        }
+                    }
+                }
+                auto widen = [](const u32x4& v) {
+                    F8 r;
+                    r.lo = f32x4{__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u)};
+                    r.hi = f32x4{__uint_as_float(v[2] << 16), __uint_as_float(v[2] & 0xffff0000u), __uint_as_float(v[3] << 16), __uint_as_float(v[3] & 0xffff0000u)};
+                    return r;
+                };
+                [[maybe_unused]] F8 pgs = f8_zero(), pgq = f8_zero();
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int j = 0; j < TNW; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * RS + 32 * j + l31] = acc[i][j][r];
+                    [[maybe_unused]] F8 gs = f8_zero(), gq = f8_zero();
+#pragma unroll
+                    for (int k = 0; k < NRD; ++k) {
+                        const int q = i * NRD + k, row = k * RPI + rr;
+                        const long long m = m0 + wm * 64 + 32 * i + row;
+                        F8 o;
+                        o.lo = *reinterpret_cast<const f32x4*>(stage + row * RS + c8);
+                        o.hi = *reinterpret_cast<const f32x4*>(stage + row * RS + c8 + 4);
+                        if (m < Mc && nokv) {
+                            const F8 a8 = widen(rad[q]);
+                            o.lo += a8.lo; o.hi += a8.hi;
+                            if constexpr (EPI == 2) {
+                                const F8 y8 = widen(ryv[q]);
+                                if (p.bnb_relu) {
+                                    if (has_mask) {
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) { if (!((rmk[q] >> e) & 1u)) o.lo[e] = 0.f; if (!((rmk[q] >> (8 + e)) & 1u)) o.hi[e] = 0.f; }
+                                    } else {
+                                        const f32x4 al = y8.lo * v_sc.lo + v_sh.lo, ah = y8.hi * v_sc.hi + v_sh.hi;
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) { if (!(al[e] > 0.f)) o.lo[e] = 0.f; if (!(ah[e] > 0.f)) o.hi[e] = 0.f; }
+                                    }
+                                }
+                                gs.lo += o.lo; gs.hi += o.hi;
+                                gq.lo += o.lo * ((y8.lo - v_mu.lo) * v_is.lo); gq.hi += o.hi * ((y8.hi - v_mu.hi) * v_is.hi);
+                            }
+                            st8(p.c, m * p.ldc + ncv, o, 1);
+                        }
+                    }
+                    if constexpr (EPI == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                            for (int o2 = LPR; o2 < 64; o2 <<= 1) {
+                                gs.lo[e] += __shfl_xor(gs.lo[e], o2, 64); gs.hi[e] += __shfl_xor(gs.hi[e], o2, 64);
+                                gq.lo[e] += __shfl_xor(gq.lo[e], o2, 64); gq.hi[e] += __shfl_xor(gq.hi[e], o2, 64);
+                            }
+                        }
+                        if ((i & 1) == 0) { pgs = gs; pgq = gq; }
+                        else {
+                            const int pidx = tile_m * (BM / 64) + wm;
+                            if (lane < LPR && pidx < p.n_partials && nokv) {
+                                float* const ps = p.partials + ((long long)pidx * 2 + 0) * p.Nn + ncv;
+                                float* const pq = p.partials + ((long long)pidx * 2 + 1) * p.Nn + ncv;
+                                st4(ps, pgs.lo + gs.lo); st4(ps + 4, pgs.hi + gs.hi);
+                                st4(pq, pgq.lo + gq.lo); st4(pq + 4, pgq.hi + gq.hi);
+                            }
+                        }
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TNW; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * RS + 32 * j + l31] = acc[i][j][r];
             constexpr int CH = NRD > 2 ? 2 : NRD;
@@ -426,7 +540,7 @@ __global__ __launch_bounds__(256, 2) void conv_b16_kernel(const ConvQ p) {
             const int npr = max(0, min(64, p.M - wrow0));
             const int pidx = tile_m * (BM / 64) + wm;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
+            for (int j = 0; j < TNW; ++j) {
                 float ss = 0.f;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -444,7 +558,7 @@ __global__ __launch_bounds__(256, 2) void conv_b16_kernel(const ConvQ p) {
                         qq += (npr == 64 || row < p.M) ? dv * dv : 0.f;
                     }
                 qq += __shfl_xor(qq, 32, 64);
-                const int n = n0 + wn * 32 * TN + 32 * j + l31;
+                const int n = n0 + wn * 32 * TNW + 32 * j + l31;
                 if (h == 0 && pidx < p.n_partials && n < p.Nn) {
                     p.partials[((long long)pidx * 2 + 0) * p.Nn + n] = ss;
                     p.partials[((long long)pidx * 2 + 1) * p.Nn + n] = qq;
@@ -455,8 +569,11 @@ __global__ __launch_bounds__(256, 2) void conv_b16_kernel(const ConvQ p) {
 }
 
 // ---------------------------------------------------------------------------------------- host side
-template <int MODE, int TN, int AFF, int EPI, int SK, int TAP, int GRP, int A32>
+static int b16_w8() { static int v = -2; if (v == -2) { const char* e = getenv("SEGHIERO_B16_W8"); v = e ? atoi(e) : 1; } return v; }
+template <int MODE, int TN, int AFF, int EPI, int SK, int TAP, int GRP, int A32, int W8 = 0>
 static int launch_b16(ConvQ& p, hipStream_t st) {
+    // (the BatchNorm-backward epilogue and the lin loader need more than the 128 registers of the eight-wave form: 106-132 spills)
+    if constexpr (TN == 2 && !W8 && !A32 && EPI != 2 && AFF != 2) { if (b16_w8()) return launch_b16<MODE, TN, AFF, EPI, SK, TAP, GRP, A32, 1>(p, st); }
     constexpr int BM = 128, BN = 64 * TN;
     const size_t lds = 2 * (size_t)(BM + BN) * 128 + (AFF == 2 ? 16 : AFF ? 8 : 0) * (size_t)p.Kc;
     // 64 KB of tiles + the coefficient table: two blocks per CU up to Kc = 1024 (lin loader) / 2048 (BatchNorm + ReLU loader); beyond
@@ -464,14 +581,14 @@ static int launch_b16(ConvQ& p, hipStream_t st) {
     if (lds > 160 * 1024) return SH_X6P_NO;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b16_kernel<MODE, TN, AFF, EPI, SK, TAP, GRP, A32>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b16_kernel<MODE, TN, AFF, EPI, SK, TAP, GRP, A32, W8>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         attr_done = true;
     }
     p.tiles_m = (int)sh_cdiv(p.M, BM);
     p.tiles_n = (int)sh_cdiv(p.Nn, BN);
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), SK ? (unsigned)p.ksplit : 1u);
-    conv_b16_kernel<MODE, TN, AFF, EPI, SK, TAP, GRP, A32><<<grid, 256, lds, st>>>(p);
+    conv_b16_kernel<MODE, TN, AFF, EPI, SK, TAP, GRP, A32, W8><<<grid, W8 ? 512 : 256, lds, st>>>(p);
     return sh_launch_status();
 }
 template <int MODE, int AFF, int EPI, int A32>
@@ -699,8 +816,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_b16_kernel(const
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(R.b[i][e] << 16); v[2 * e + 1] = __uint_as_float(R.b[i][e] & 0xffff0000u); }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float w = fmaxf(v[e] * sc[e] + sh[e], 0.f); v[e] = ok ? w : 0.f; }
-            *reinterpret_cast<u32x4*>(dst) = u32x4{pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);      // (as conv_b16_kernel's loader: fused, masked after the pack)
+            const unsigned okw = ok ? ~0u : 0u;
+            *reinterpret_cast<u32x4*>(dst) = u32x4{pk_bf16(v[0], v[1]) & okw, pk_bf16(v[2], v[3]) & okw, pk_bf16(v[4], v[5]) & okw, pk_bf16(v[6], v[7]) & okw};
         }
     };
     f32x16 acc[2][2];

@@ -1200,7 +1200,7 @@ extern "C" int sh_conv_dgrad_x6_lin(const float* g, int ldg, const float* y, int
 }
 
 struct WgX6Plan { int wgm, wgn, splits, kchunk, per_xcd; };
-static WgX6Plan wgrad_plan_x6(int Cout, long long Nn, long long npix) {
+static WgX6Plan wgrad_plan_x6(int Cout, long long Nn, long long npix, double rate = 0.29e12) {      // rate: flop/s of the main loop (bf16 compute: 1.2e12)
     WgX6Plan g;
     // measured (tools/bench_conv.py): 128x256 helps the narrow-Cout shapes, 256x256 on 1024 threads does not help wgrad
     g.wgm = Cout <= 64 ? 1 : 2;
@@ -1215,7 +1215,7 @@ static WgX6Plan wgrad_plan_x6(int Cout, long long Nn, long long npix) {
     // and each slice writes + re-reads one fp32 copy of dW, which prices many short slices out for the small layers.
     //   cost(r) = r * (npix / s_r) * t_pixel + s_r * dW_bytes * 2 / HBM,   s_r = floor(512 r / tiles)
     const long long maxs = sh_cdiv(npix, 256);
-    const double t_pixel = 2.0 * (64 * g.wgm) * (64 * g.wgn) / 0.29e12, dwb = 4.0 * Cout * (double)Nn;
+    const double t_pixel = 2.0 * (64 * g.wgm) * (64 * g.wgn) / rate, dwb = 4.0 * Cout * (double)Nn;
     // resident blocks per CU: the kernels are bounded to 2 waves per SIMD (8 waves per CU) and their [k][row] planes take
     // 96 * ((128 wgm + 64) + (128 wgn + 64)) bytes of the 160 KB LDS -- 2 for the 256-thread tiles, 1 for 128 x 256 on 512 threads
     const long long lds_b = 96ll * ((128 * g.wgm + 64) + (128 * g.wgn + 64));
@@ -1507,7 +1507,10 @@ extern "C" int sh_conv_wgrad_b16(const void* x, int ldx, const float* in_scale, 
         if (a2 * 2 >= (1ll << 31)) return SH_EUNSUPPORTED;
         p.a2 = (const float*)y_lin; p.lda2 = ldyl; p.a2_bytes = (unsigned)(a2 * 2); p.lin = lin;
     }
-    const WgX6Plan g = wgrad_plan_x6(Cout, p.Nn, p.K);
+    // K slices priced at the bf16 loop's rate: a slice costs its fp32 slab (written, then read by the reduce) whatever the loop's speed,
+    // so the one-product loop takes fewer, longer slices than the six-product one (never more: the fp32-accurate workspace size covers it)
+    WgX6Plan g = wgrad_plan_x6(Cout, p.Nn, p.K, 1.2e12);
+    { const WgX6Plan g6 = wgrad_plan_x6(Cout, p.Nn, p.K); if (g.splits > g6.splits) g = g6; }
     p.kchunk = g.kchunk;
     p.scatter = g.per_xcd;
     hipStream_t st = (hipStream_t)stream;

@@ -779,7 +779,7 @@ def test_conv_bf16_compute_mode_matches_exact_products_of_the_rounded_operands(o
     """bf16 compute mode (sh_conv_fprop_b16 / _dgrad_b16 / _wgrad_b16): operands rounded ONCE to bf16, one MFMA product, fp32 accumulate.
     The reference is therefore exact: fp64 convolutions of the bf16-rounded operands; what remains is the fp32 summation order --
     2e-5 of the result's scale (the fp32-accurate kernels are held to the same figure against fp32 torch).  Forward also through the
-    producer's BatchNorm + ReLU in the loader (rounded to bf16 AFTER the activation, evaluated in sh_bn_act's operation order), with
+    producer's BatchNorm + ReLU in the loader (one fused multiply-add, ReLU, then rounded to bf16), with
     BatchNorm statistics from the fp32 accumulators and a bf16- or fp32-stored output; input gradient with fp32 and bf16 gradient
     operands, addend, BatchNorm-backward epilogue; weight gradient plain and through the loader."""
     n, h, w, cin, cout, k, p, d = case
@@ -791,7 +791,9 @@ def test_conv_bf16_compute_mode_matches_exact_products_of_the_rounded_operands(o
     scale, shift = torch.randn(cin, generator=g), 0.3 * torch.randn(cin, generator=g)
     mean, invstd = 0.2 * torch.randn(cin, generator=g), 0.5 + torch.rand(cin, generator=g)
     coefs = torch.stack([mean, invstd, scale, shift]).to(DEV).contiguous()
-    pre = x.float() * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)                  # fp32, mul then add: sh_bn_act's own order
+    # the loader's arithmetic: ONE fused multiply-add in fp32 (x is bf16, so the product is exact in fp64 and rounding the fp64 sum to fp32
+    # is the fused result)
+    pre = (x.double() * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)).float()
     act = bf(torch.relu(pre))
     xg, wg = nhwc_bf16(x), wl(wt)
     ref_plain = F.conv2d(x.double(), wq, None, 1, p, d)
@@ -843,6 +845,23 @@ def test_conv_bf16_compute_mode_matches_exact_products_of_the_rounded_operands(o
         np.testing.assert_allclose(sums[0].numpy(), gk.sum((0, 2, 3)).numpy(), rtol=1e-5, atol=1e-5 * float(gk.abs().sum((0, 2, 3)).max()))
         np.testing.assert_allclose(sums[1].numpy(), (gk * xhat).sum((0, 2, 3)).numpy(), rtol=1e-5,
                                    atol=1e-5 * float((gk * xhat).abs().sum((0, 2, 3)).max()))
+        # ... the same with every tensor of the epilogue in bf16 (the bf16-gradient step: all loads of the tile issued up front), mask
+        # recomputed from y, and taken from a ReLU quad mask with a bf16 addend
+        gb16 = ops.new_act(n, cin, h, w, DEV, dtype=torch.bfloat16)
+        bp16 = torch.empty_like(bpart)
+        assert ops._dgrad_b16(dy16, wg, gb16, 1, p, d, bnb=(xg, coefs, True, bp16, None))
+        e = float((gb16.cpu().double() - g_ref).abs().max() / ref_dx.abs().max())
+        assert e < 2 ** -8, ("bf16 g", e)
+        np.testing.assert_allclose(bp16.double().sum(0).cpu().numpy(), sums.numpy(), rtol=1e-4, atol=1e-4 * float(gk.abs().sum((0, 2, 3)).max()))
+        outp = torch.randn(n, cin, h, w, generator=g)
+        bits = (outp > 0).permute(0, 2, 3, 1).reshape(n, h, w, cin // 4, 4).to(torch.uint8)
+        qm = (bits[..., 0] | (bits[..., 1] << 1) | (bits[..., 2] << 2) | (bits[..., 3] << 3)).contiguous().to(DEV)
+        assert ops._dgrad_b16(dy16, wg, gb16, 1, p, d, addend=nhwc_bf16(add), bnb=(xg, coefs, True, bp16, qm))
+        g3 = (ref_dx + add.double()) * (outp > 0)
+        e = float((gb16.cpu().double() - g3).abs().max() / g3.abs().max())
+        assert e < 2 ** -8, ("bf16 g, quad mask + addend", e)
+        s3 = bp16.double().sum(0).cpu()
+        np.testing.assert_allclose(s3[1].numpy(), (g3 * xhat).sum((0, 2, 3)).numpy(), rtol=2e-4, atol=2e-4 * float((g3 * xhat).abs().sum((0, 2, 3)).max()))
         # ---- weight gradient: plain and with x through the loader, fp32 and bf16 gradient operands
         if cout % 8 == 0:
             for xin, coef in ((x, None), (act, coefs)):
