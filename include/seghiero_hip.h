@@ -333,11 +333,17 @@ int sh_l2norm_bwd(const float* dy, const float* y, const float* norm, float* dx,
  *   grad_out (optional; sh_loss_bwd_workspace(N,H,W,ldg) bytes, 16-byte aligned, ldg % 4 == 0, upsampling only): the same pass
  *   also writes every full-resolution pixel's d(loss_out)/d(interpolated logits) [N*H*W][ldg] -- its normalisers are label counts,
  *   taken by a small pre-pass -- so the backward is only the adjoint of the resize (sh_hiera2_loss_bwd, workspace_has_grad = 1)
- *   and the per-pixel sigmoid / softmax arithmetic (VALU-bound, ~0.3 ms at 16x512x512) runs once per step instead of twice. */
+ *   and the per-pixel sigmoid / softmax arithmetic (VALU-bound, ~0.3 ms at 16x512x512) runs once per step instead of twice.
+ *   norm_counts (optional, device int64[3], EXACT data-parallel mode): the all-reduced sh_label_counts vector {valid fine, valid coarse,
+ *   pixels} of ALL shards -- the local numerators are then divided by these global denominators (loss_out, the emitted gradient and the
+ *   counts left in `sums`), so the per-rank losses SUM to the full-batch loss and the summed gradients are the full-batch gradients. */
 int sh_hiera2_partials(int N, int H, int W);
+int sh_label_counts(const uint8_t* labels, const int* buckets_host, int n_fine, int n_coarse, int64_t total, int64_t* counts,
+                    void* stream);
 int sh_hiera2_loss_fwd(const float* logits, int ldl, const uint8_t* labels, const int* buckets_host, int n_fine,
                        int n_coarse, double* sums, float* loss_out, float* partials, uint8_t* coarse_out,
-                       int N, int h, int w, int H, int W, float* grad_out, int64_t grad_out_bytes, int ldg, void* stream);
+                       int N, int h, int w, int H, int W, float* grad_out, int64_t grad_out_bytes, int ldg,
+                       const int64_t* norm_counts, void* stream);
 /* d(loss_out)/d(logits) * gscale * gscale_dev[0] into dlogits [N,h,w,lddl] (gather form, deterministic; lanes
  * >= C of each row are zeroed).  Uses the counts left in `sums` by the forward.  workspace (optional, sh_loss_bwd_workspace
  * bytes, 16-byte aligned; needs lddl % 4 == 0): two streaming passes -- every full-resolution pixel's gradient once into the
@@ -351,9 +357,11 @@ int sh_hiera2_loss_bwd(const float* logits, int ldl, const uint8_t* labels, cons
                        int lddl, int N, int h, int w, int H, int W, float* workspace, int64_t workspace_bytes,
                        int workspace_has_grad, void* stream);
 /* Fused bilinear resize + nn.CrossEntropyLoss(ignore_index=255) (valid-pixel mean) of the aux head
- * (train.py:309-313).  sums double[2] = {ce_sum, n_valid}; loss_out = ce_sum / n_valid. */
+ * (train.py:309-313).  sums double[2] = {ce_sum, n_valid}; loss_out = ce_sum / n_valid.  norm_count (optional, device int64[1]):
+ * the global valid-pixel count of the exact data-parallel mode (sh_label_counts counts[0], all-reduced). */
 int sh_ce_loss_fwd(const float* logits, int ldl, const uint8_t* labels, int C, double* sums, float* loss_out,
-                   float* partials, int N, int h, int w, int H, int W, float* grad_out, int64_t grad_out_bytes, int ldg, void* stream);
+                   float* partials, int N, int h, int w, int H, int W, float* grad_out, int64_t grad_out_bytes, int ldg,
+                   const int64_t* norm_count, void* stream);
 int sh_ce_loss_bwd(const float* logits, int ldl, const uint8_t* labels, int C, const double* sums,
                    const float* gscale_dev, float gscale, float* dlogits, int lddl, int N, int h, int w, int H,
                    int W, float* workspace, int64_t workspace_bytes, int workspace_has_grad,

@@ -149,16 +149,18 @@ template <int MAXC, bool GRAD>
 __global__ __launch_bounds__(256) void hiera2_fwd_kernel(const float* __restrict__ logits, long long ldl, const uint8_t* __restrict__ labels,
                                                          const H2Tab T, float* __restrict__ partials, uint8_t* __restrict__ coarse_out,
                                                          int h, int w, int H, int W, float sy, float sx, long long total,
-                                                         const unsigned long long* __restrict__ cnt, float* __restrict__ gfull, int L) {
+                                                         const unsigned long long* __restrict__ cnt, float* __restrict__ gfull, int L,
+                                                         const long long* __restrict__ norm) {
     const bool identity = (h == H && w == W);
     const int C = T.nf + T.nc;
     float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float af = 0.f, ac = 0.f, b = 0.f;
-    if (GRAD) {       // the coefficients of loss_grad_fullres_kernel at unit upstream gradient
-        const double nvf = cnt[0] < 1 ? 1.0 : (double)cnt[0], nvc = cnt[1] < 1 ? 1.0 : (double)cnt[1];
+    if (GRAD) {       // the coefficients of loss_grad_fullres_kernel at unit upstream gradient (norm: the all-reduced counts, see the entry point)
+        const double c0 = norm ? (double)norm[0] : (double)cnt[0], c1 = norm ? (double)norm[1] : (double)cnt[1];
+        const double nvf = c0 < 1 ? 1.0 : c0, nvc = c1 < 1 ? 1.0 : c1;
         af = (float)(5.0 / (nvf * T.nf));
         ac = T.nc > 0 ? (float)(5.0 / (nvc * T.nc)) : 0.f;
-        b = (float)(1.0 / (double)total);
+        b = (float)(1.0 / (norm ? (double)norm[2] : (double)total));
     }
     const long long base = (long long)blockIdx.x * LOSS_PIX_PER_BLOCK;
 #pragma unroll 1
@@ -196,7 +198,8 @@ __global__ __launch_bounds__(256) void hiera2_fwd_kernel(const float* __restrict
 }
 // sums[0..3] = the four sums, sums[4] = n_valid_fine, sums[5] = n_valid_coarse, sums[6] = n_pixels; loss_out = scalar loss
 __global__ __launch_bounds__(256) void hiera2_finalize_kernel(const float* __restrict__ partials, int nblk, double npix, int nf, int nc,
-                                                              double* __restrict__ sums, float* __restrict__ loss_out) {
+                                                              double* __restrict__ sums, float* __restrict__ loss_out,
+                                                              const long long* __restrict__ norm) {
     __shared__ double red[8][4];
     const int t = threadIdx.x;
     double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -213,6 +216,7 @@ __global__ __launch_bounds__(256) void hiera2_finalize_kernel(const float* __res
         double s[8];
         for (int j = 0; j < 8; ++j) s[j] = (red[j][0] + red[j][1]) + (red[j][2] + red[j][3]);
         s[6] = npix;
+        if (norm) { s[4] = (double)norm[0]; s[5] = (double)norm[1]; s[6] = npix = (double)norm[2]; }      // global denominators, local numerators
         for (int j = 0; j < 8; ++j) sums[j] = s[j];
         const double nvf = s[4] < 1.0 ? 1.0 : s[4], nvc = s[5] < 1.0 ? 1.0 : s[5];
         const double lf = s[0] / (nvf * nf), lc = nc > 0 ? s[1] / (nvc * nc) : 0.0;
@@ -551,6 +555,22 @@ static bool make_tab(H2Tab& T, const int* buckets, int nf, int nc) {
     return true;
 }
 
+// The loss normalisers of one shard as integers -- counts[0] = pixels with a valid fine label (hiera_triplet_loss.py:41-107 num_valid, also
+// nn.CrossEntropyLoss's denominator), counts[1] = pixels whose coarse label is valid, counts[2] = all pixels (the all-pixel mean of
+// models/loss/utils.py:20-21) -- for the EXACT data-parallel mode: the ranks all-reduce (sum) this 24-byte vector and hand the result to
+// sh_hiera2_loss_fwd / sh_ce_loss_fwd (norm_counts), which then divide their LOCAL numerators by the GLOBAL denominators: the per-rank
+// losses sum to the full-batch loss and the summed gradients are the full-batch gradients.
+__global__ void label_counts_finish_kernel(long long* counts, long long total) { counts[2] = total; }
+extern "C" int sh_label_counts(const uint8_t* labels, const int* buckets_host, int n_fine, int n_coarse, int64_t total, int64_t* counts,
+                               void* stream) {
+    H2Tab T;
+    if (!labels || !counts || total <= 0 || !make_tab(T, buckets_host, n_fine, n_coarse)) return SH_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(counts, 0, 3 * sizeof(int64_t), st) != hipSuccess) return SH_ELAUNCH;
+    label_counts_kernel<<<256, 256, 0, st>>>(labels, T, 1, total, reinterpret_cast<unsigned long long*>(counts));
+    label_counts_finish_kernel<<<1, 1, 0, st>>>(reinterpret_cast<long long*>(counts), (long long)total);
+    return sh_launch_status();
+}
 // grad_out usable? (forward that also emits the per-pixel gradient for the gather-only backward)
 static bool grad_out_ok(const float* grad_out, int64_t bytes, int ldg, int C, int N, int h, int w, int H, int W) {
     return grad_out && ldg >= C && ldg <= 32 && (ldg & 3) == 0 && ((uintptr_t)grad_out & 15) == 0 && bytes >= sh_loss_bwd_workspace(N, H, W, ldg) &&
@@ -558,10 +578,12 @@ static bool grad_out_ok(const float* grad_out, int64_t bytes, int ldg, int C, in
 }
 extern "C" int sh_hiera2_loss_fwd(const float* logits, int ldl, const uint8_t* labels, const int* buckets_host, int n_fine,
                                   int n_coarse, double* sums, float* loss_out, float* partials, uint8_t* coarse_out,
-                                  int N, int h, int w, int H, int W, float* grad_out, int64_t grad_out_bytes, int ldg, void* stream) {
+                                  int N, int h, int w, int H, int W, float* grad_out, int64_t grad_out_bytes, int ldg,
+                                  const int64_t* norm_counts, void* stream) {
     H2Tab T;
     if (!logits || !labels || !sums || !loss_out || !partials || N <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SH_EINVAL;
     if (!make_tab(T, buckets_host, n_fine, n_coarse) || ldl < n_fine + n_coarse) return SH_EINVAL;
+    const long long* norm = reinterpret_cast<const long long*>(norm_counts);
     const long long total = (long long)N * H * W;
     const int nblk = (int)sh_cdiv(total, LOSS_PIX_PER_BLOCK);
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
@@ -571,17 +593,19 @@ extern "C" int sh_hiera2_loss_fwd(const float* logits, int ldl, const uint8_t* l
         if (!grad_out_ok(grad_out, grad_out_bytes, ldg, C, N, h, w, H, W)) return SH_EINVAL;
         // the gradient's normalisers are label counts: taken first, parked (as integers) where the finalize kernel later writes the same counts
         unsigned long long* cnt = reinterpret_cast<unsigned long long*>(sums + 4);
-        if (hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned long long), st) != hipSuccess) return SH_ELAUNCH;
-        label_counts_kernel<<<256, 256, 0, st>>>(labels, T, 1, total, cnt);
-        if (C <= 8 && ldg <= 8) hiera2_fwd_kernel<8, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total, cnt, grad_out, ldg);
-        else if (C <= 16 && ldg <= 16) hiera2_fwd_kernel<16, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total, cnt, grad_out, ldg);
-        else hiera2_fwd_kernel<32, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total, cnt, grad_out, ldg);
-    } else if (C <= 8) hiera2_fwd_kernel<8, false><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total, nullptr, nullptr, 0);
-    else if (C <= 16) hiera2_fwd_kernel<16, false><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total, nullptr, nullptr, 0);
-    else hiera2_fwd_kernel<32, false><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total, nullptr, nullptr, 0);
+        if (norm == nullptr) {
+            if (hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned long long), st) != hipSuccess) return SH_ELAUNCH;
+            label_counts_kernel<<<256, 256, 0, st>>>(labels, T, 1, total, cnt);
+        }
+        if (C <= 8 && ldg <= 8) hiera2_fwd_kernel<8, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total, cnt, grad_out, ldg, norm);
+        else if (C <= 16 && ldg <= 16) hiera2_fwd_kernel<16, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total, cnt, grad_out, ldg, norm);
+        else hiera2_fwd_kernel<32, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total, cnt, grad_out, ldg, norm);
+    } else if (C <= 8) hiera2_fwd_kernel<8, false><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total, nullptr, nullptr, 0, norm);
+    else if (C <= 16) hiera2_fwd_kernel<16, false><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total, nullptr, nullptr, 0, norm);
+    else hiera2_fwd_kernel<32, false><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, coarse_out, h, w, H, W, sy, sx, total, nullptr, nullptr, 0, norm);
     int rc = sh_launch_status();
     if (rc != SH_OK) return rc;
-    hiera2_finalize_kernel<<<1, 256, 0, st>>>(partials, nblk, (double)total, n_fine, n_coarse, sums, loss_out);
+    hiera2_finalize_kernel<<<1, 256, 0, st>>>(partials, nblk, (double)total, n_fine, n_coarse, sums, loss_out, norm);
     return sh_launch_status();
 }
 
@@ -628,10 +652,11 @@ extern "C" int sh_hiera2_loss_bwd(const float* logits, int ldl, const uint8_t* l
 template <int MAXC, bool GRAD>      // GRAD: as hiera2_fwd_kernel (cnt[0] = number of valid pixels)
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, long long ldl, const uint8_t* __restrict__ labels, int C,
                                                      float* __restrict__ partials, int h, int w, int H, int W, float sy, float sx, long long total,
-                                                     const unsigned long long* __restrict__ cnt, float* __restrict__ gfull, int L) {
+                                                     const unsigned long long* __restrict__ cnt, float* __restrict__ gfull, int L,
+                                                     const long long* __restrict__ norm) {
     const bool identity = (h == H && w == W);
     float v[2] = {0.f, 0.f};
-    const float b = GRAD ? (float)(1.0 / (double)cnt[0]) : 0.f;          // no valid pixel: inf -> NaN gradient, as the separate backward
+    const float b = GRAD ? (float)(1.0 / (norm ? (double)norm[0] : (double)cnt[0])) : 0.f;          // no valid pixel: inf -> NaN gradient, as the separate backward
     const long long base = (long long)blockIdx.x * LOSS_PIX_PER_BLOCK;
 #pragma unroll 1
     for (int it = 0; it < LOSS_PIX_PER_BLOCK / 256; ++it) {
@@ -663,7 +688,8 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
     }
     block_reduce_store<2>(v, partials);
 }
-__global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restrict__ partials, int nblk, double* __restrict__ sums, float* __restrict__ loss_out) {
+__global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restrict__ partials, int nblk, double* __restrict__ sums, float* __restrict__ loss_out,
+                                                          const long long* __restrict__ norm) {
     __shared__ double red[2][4];
     const int t = threadIdx.x;
     double a0 = 0, a1 = 0;
@@ -672,7 +698,8 @@ __global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restric
     if ((t & 63) == 0) { red[0][t >> 6] = a0; red[1][t >> 6] = a1; }
     __syncthreads();
     if (t == 0) {
-        const double s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), c = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        const double s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        const double c = norm ? (double)norm[0] : (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);          // global valid count, local numerator
         sums[0] = s; sums[1] = c;
         loss_out[0] = (float)(s / c);      // 0/0 -> NaN like nn.CrossEntropyLoss on an all-ignored batch
     }
@@ -726,8 +753,10 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
     }
 }
 extern "C" int sh_ce_loss_fwd(const float* logits, int ldl, const uint8_t* labels, int C, double* sums, float* loss_out,
-                              float* partials, int N, int h, int w, int H, int W, float* grad_out, int64_t grad_out_bytes, int ldg, void* stream) {
+                              float* partials, int N, int h, int w, int H, int W, float* grad_out, int64_t grad_out_bytes, int ldg,
+                              const int64_t* norm_count, void* stream) {
     if (!logits || !labels || !sums || !loss_out || !partials || C <= 0 || C > 32 || ldl < C || N <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SH_EINVAL;
+    const long long* norm = reinterpret_cast<const long long*>(norm_count);
     const long long total = (long long)N * H * W;
     const int nblk = (int)sh_cdiv(total, LOSS_PIX_PER_BLOCK);
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
@@ -735,17 +764,19 @@ extern "C" int sh_ce_loss_fwd(const float* logits, int ldl, const uint8_t* label
     if (grad_out != nullptr) {
         if (!grad_out_ok(grad_out, grad_out_bytes, ldg, C, N, h, w, H, W)) return SH_EINVAL;
         unsigned long long* cnt = reinterpret_cast<unsigned long long*>(sums + 1);       // see sh_hiera2_loss_fwd
-        if (hipMemsetAsync(cnt, 0, sizeof(unsigned long long), st) != hipSuccess) return SH_ELAUNCH;
-        label_counts_kernel<<<256, 256, 0, st>>>(labels, H2Tab{}, 0, total, cnt);
-        if (ldg <= 8) ce_fwd_kernel<8, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total, cnt, grad_out, ldg);
-        else if (ldg <= 16) ce_fwd_kernel<16, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total, cnt, grad_out, ldg);
-        else ce_fwd_kernel<32, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total, cnt, grad_out, ldg);
-    } else if (C <= 8) ce_fwd_kernel<8, false><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total, nullptr, nullptr, 0);
-    else if (C <= 16) ce_fwd_kernel<16, false><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total, nullptr, nullptr, 0);
-    else ce_fwd_kernel<32, false><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total, nullptr, nullptr, 0);
+        if (norm == nullptr) {
+            if (hipMemsetAsync(cnt, 0, sizeof(unsigned long long), st) != hipSuccess) return SH_ELAUNCH;
+            label_counts_kernel<<<256, 256, 0, st>>>(labels, H2Tab{}, 0, total, cnt);
+        }
+        if (ldg <= 8) ce_fwd_kernel<8, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total, cnt, grad_out, ldg, norm);
+        else if (ldg <= 16) ce_fwd_kernel<16, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total, cnt, grad_out, ldg, norm);
+        else ce_fwd_kernel<32, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total, cnt, grad_out, ldg, norm);
+    } else if (C <= 8) ce_fwd_kernel<8, false><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total, nullptr, nullptr, 0, norm);
+    else if (C <= 16) ce_fwd_kernel<16, false><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total, nullptr, nullptr, 0, norm);
+    else ce_fwd_kernel<32, false><<<nblk, 256, 0, st>>>(logits, ldl, labels, C, partials, h, w, H, W, sy, sx, total, nullptr, nullptr, 0, norm);
     int rc = sh_launch_status();
     if (rc != SH_OK) return rc;
-    ce_finalize_kernel<<<1, 256, 0, st>>>(partials, nblk, sums, loss_out);
+    ce_finalize_kernel<<<1, 256, 0, st>>>(partials, nblk, sums, loss_out, norm);
     return sh_launch_status();
 }
 extern "C" int sh_ce_loss_bwd(const float* logits, int ldl, const uint8_t* labels, int C, const double* sums, const float* gscale_dev,

@@ -118,6 +118,39 @@ def broadcast_module_state(modules, src=0):
                 dist.broadcast(t.data, src=src)
 
 
+# EXACT data-parallel mode (SURVEY 8e "optional exact mode"): the loss normalisers -- valid-pixel counts of the hierarchical BCE terms
+# (hiera_triplet_loss.py:41-107), the all-pixel count of the CE wrapper (utils.py:20-21), the aux CE's valid count -- are all-reduced
+# (ONE 24-byte message per step) and every rank divides its LOCAL numerators by the GLOBAL denominators: the per-rank losses then SUM to the
+# full-batch loss, gradients are summed (not averaged) over the ranks, and with SyncBN on a sharded step equals the single-process
+# step on the whole batch (strong scaling: global batch 16 as 8 x 2).  The triplet term stays per rank as the reference's DDP code
+# intended (tree_triplet_loss.py:23-46 selects inside the local shard) and enters with weight 1 / world.  2-level loss + aux CE; the
+# 3-level RMI loss keeps local normalisers.
+EXACT = False
+_COUNTS = None          # the all-reduced normalisers of the step in flight (device int64[3]), set by exact_counts()
+
+
+def exact_counts(labels8, n_fine, hiera_index):
+    """Exact mode: all-reduce this step's loss normalisers; the loss modules pick them up (current_counts) until end_step()."""
+    global _COUNTS
+    if not (EXACT and collectives_on()):
+        _COUNTS = None
+        return None
+    from . import ops
+    c = ops.label_counts(labels8, n_fine, hiera_index)
+    all_reduce_small(c)
+    _COUNTS = c
+    return c
+
+
+def current_counts():
+    return _COUNTS
+
+
+def end_step():
+    global _COUNTS
+    _COUNTS = None
+
+
 _ACTIVE = None          # the GradSync that is collecting gradients of the backward pass in flight (set by begin())
 
 
@@ -257,4 +290,4 @@ class GradSync:
                 o, n = self.views[id(p)]
                 p.grad = self.flat[o:o + n].as_strided(p.shape, p.stride())
         self._works = []
-        return 1.0 / self.world
+        return 1.0 if EXACT else 1.0 / self.world      # exact mode: every rank's loss already carries the global denominators -- gradients are summed

@@ -143,16 +143,19 @@ class _Hiera2Fn(torch.autograd.Function):
         logits = ops.to_nhwc(cls_score)
         emb = _dense_nhwc(embedding)
         nf, hidx = mod.num_classes, mod.hiera_index
-        main, sums, _, gw = ops.hiera2_fwd(logits, label8, nf, hidx, want_grad=ctx.needs_input_grad[0])
+        from . import ddp
+        norm = ddp.current_counts()              # exact data-parallel mode: global normalisers (ddp.exact_counts), else None
+        main, sums, _, gw = ops.hiera2_fwd(logits, label8, nf, hidx, want_grad=ctx.needs_input_grad[0], norm=norm)
         masks, ok = mod.triplet_loss_fn.tables(logits.device)
         trip, ws = ops.triplet_fwd(emb, label8, masks, ok, 200, 0.6)
         ready = None
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             # hiera_triplet_loss.py:193-198: the term counts only if EVERY rank produced triplets
-            from . import ddp
             ready = trip[1:2].clone()
             ddp.all_reduce_small(ready, op=torch.distributed.ReduceOp.MIN)
         factor = triplet_factor(step, 80000)
+        if norm is not None:
+            factor = factor / ddp.world_size()   # per-rank triplets (tree_triplet_loss.py:23-46), mean over the ranks; the rest sums
         total = ops.combine_loss(main, trip, ready, factor, mod.loss_weight)
         ctx.save_for_backward(logits, emb, label8, sums, trip, ws)
         ctx.grad_ws = gw            # per-pixel gradient left by the forward (None: the backward recomputes it)

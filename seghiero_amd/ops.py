@@ -1296,9 +1296,18 @@ def _loss_grad_out(want_grad, n, c, h, w, H, W, device, tag="lossgrad"):
     return torch.empty((need // 4,), device=device, dtype=torch.float32), need, ldg
 
 
-def hiera2_fwd(logits, labels8, n_fine, hiera_index, want_coarse=False, want_grad=False):
+def label_counts(labels8, n_fine, hiera_index):
+    """-> device int64[3] = {pixels with a valid fine label, with a valid coarse label, all pixels} of this shard: the loss normalisers
+    that the exact data-parallel mode all-reduces (ddp.exact_counts)."""
+    counts = torch.empty((3,), device=labels8.device, dtype=torch.int64)
+    _call("sh_label_counts", labels8.data_ptr(), _buckets(hiera_index), n_fine, len(hiera_index), labels8.numel(), counts.data_ptr(), _st())
+    return counts
+
+
+def hiera2_fwd(logits, labels8, n_fine, hiera_index, want_coarse=False, want_grad=False, norm=None):
     """-> (loss[1] f32, sums[8] f64, coarse u8 or None, grad workspace or None).  want_grad: the same pass leaves the per-pixel
-    gradient for hiera2_bwd(grad_ws=...), which is then only the adjoint of the resize."""
+    gradient for hiera2_bwd(grad_ws=...), which is then only the adjoint of the resize.  norm: device int64[3] global normalisers
+    (label_counts summed over the ranks): local numerators over global denominators."""
     n, c, h, w = logits.shape
     _, H, W = labels8.shape
     lp, ldl = pm(logits)
@@ -1311,7 +1320,7 @@ def hiera2_fwd(logits, labels8, n_fine, hiera_index, want_coarse=False, want_gra
     gw, gbytes, ldg = _loss_grad_out(want_grad, n, c, h, w, H, W, dev)
     _call("sh_hiera2_loss_fwd", lp, ldl, labels8.data_ptr(), _buckets(hiera_index), n_fine, len(hiera_index),
           sums.data_ptr(), loss.data_ptr(), partials.data_ptr(), None if coarse is None else coarse.data_ptr(),
-          n, h, w, H, W, None if gw is None else gw.data_ptr(), gbytes, ldg, _st())
+          n, h, w, H, W, None if gw is None else gw.data_ptr(), gbytes, ldg, None if norm is None else norm.data_ptr(), _st())
     return loss, sums, coarse, gw
 
 
@@ -1343,8 +1352,8 @@ def hiera2_bwd(logits, labels8, n_fine, hiera_index, sums, gscale_dev, gscale, g
     return d
 
 
-def ce_fwd(logits, labels8, want_grad=False):
-    """-> (loss[1], sums[2] f64, grad workspace or None); want_grad as hiera2_fwd."""
+def ce_fwd(logits, labels8, want_grad=False, norm=None):
+    """-> (loss[1], sums[2] f64, grad workspace or None); want_grad as hiera2_fwd; norm: device int64[>=1], [0] = global valid count."""
     n, c, h, w = logits.shape
     _, H, W = labels8.shape
     lp, ldl = pm(logits)
@@ -1355,7 +1364,7 @@ def ce_fwd(logits, labels8, want_grad=False):
     loss = torch.empty((1,), device=dev, dtype=torch.float32)
     gw, gbytes, ldg = _loss_grad_out(want_grad, n, c, h, w, H, W, dev, tag="lossgrad_ce")
     _call("sh_ce_loss_fwd", lp, ldl, labels8.data_ptr(), c, sums.data_ptr(), loss.data_ptr(), partials.data_ptr(),
-          n, h, w, H, W, None if gw is None else gw.data_ptr(), gbytes, ldg, _st())
+          n, h, w, H, W, None if gw is None else gw.data_ptr(), gbytes, ldg, None if norm is None else norm.data_ptr(), _st())
     return loss, sums, gw
 
 

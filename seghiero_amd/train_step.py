@@ -32,7 +32,8 @@ class _AuxCEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, label8):
         lg = ops.to_nhwc(logits)
-        loss, sums, gw = ops.ce_fwd(lg, label8, want_grad=ctx.needs_input_grad[0])
+        from . import ddp
+        loss, sums, gw = ops.ce_fwd(lg, label8, want_grad=ctx.needs_input_grad[0], norm=ddp.current_counts())
         ctx.save_for_backward(lg, label8, sums)
         ctx.grad_ws = gw
         return loss.reshape(())
@@ -209,6 +210,9 @@ class SegHieroTrainer:
                 ops.prepare_bf16_weights(self._dgrad_weights, self._wb_cache)    # bf16 operand copies of the fp32 master weights
         ops.STEP_SCOPE = self._step_scope            # the loss forward's per-pixel gradient buffers are reused from step to step
         try:
+            if self.grad_sync is not None and self.n_super == 0:
+                from . import ddp
+                ddp.exact_counts(ops.labels_u8(fine_mask), self.n_fine, self.hiera_loss_fn.hiera_index)      # (no-op unless ddp.EXACT)
             loss, _, _, _ = self.forward_loss(img, fine_mask, epoch)
             if self.grad_sync is not None:
                 self.grad_sync.begin()                   # buckets are exchanged as the backward nodes finish them
@@ -216,6 +220,9 @@ class SegHieroTrainer:
         finally:
             ops.release_dgrad_weights()
             ops.STEP_SCOPE = None
+            if self.grad_sync is not None:
+                from . import ddp
+                ddp.end_step()
         gscale = 1.0
         if self.grad_sync is not None:
             gscale = self.grad_sync.reduce(self.params)

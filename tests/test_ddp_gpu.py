@@ -430,3 +430,78 @@ def test_ddp_sharded_step_with_syncbn_matches_oracle_ddp_statement(cuts):
     for k, v in want.items():
         np.testing.assert_array_equal(res[0]["rstat"][k], res[1]["rstat"][k])
         np.testing.assert_allclose(res[0]["rstat"][k], v, rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+# ---------------------------------------------------------------- exact data-parallel mode: sharded == full batch
+def _exact_step(cuts, rank, world):
+    from seghiero_amd import ddp, ops
+    from seghiero_amd.synthetic import make_batch
+    from seghiero_amd.train_step import SegHieroTrainer
+    torch.manual_seed(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ops.SYNC_BN = world > 1
+    ddp.EXACT = world > 1
+    tr = SegHieroTrainer(device=dev, **TR_KW)
+    if world > 1:
+        ddp.broadcast_module_state(list(tr.modules().values()))
+        tr.grad_sync = ddp.GradSync(tr.params, bucket_mb=4.0)
+    tr.train()
+    img, lab = make_batch(4, 128, 4, seed=5)
+    a, b = cuts[rank], cuts[rank + 1]
+    loss = float(tr.train_step(img[a:b].to(dev), lab[a:b].to(dev), 0))          # epoch 0: the (per-rank by design) triplet term has weight 0
+    torch.cuda.synchronize()
+    ddp.EXACT = False
+    named = [(f"{mk}.{k}", p) for mk, m in tr.modules().items() for k, p in m.named_parameters()]
+    return dict(loss=loss, grads={k: p.grad.detach().cpu().numpy().copy() for k, p in named},
+                after={k: p.detach().cpu().numpy().copy() for k, p in named})
+
+
+def _exact_worker(rank, world, port, q, cuts):
+    _env(rank, world, port, "gloo")
+    import torch.distributed as dist
+    from seghiero_amd import ddp
+    ddp.init_from_env(backend="gloo")
+    try:
+        out = _exact_step(cuts, rank, world)
+    except Exception as e:
+        import traceback
+        out = "rank %d failed: %s\n%s" % (rank, e, traceback.format_exc())
+    q.put((rank, out))
+    if not isinstance(out, str):
+        dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cuts", [[0, 2, 4], [0, 1, 4]])
+def test_ddp_exact_normalisers_sharded_equals_full_batch(cuts):
+    """Exact data-parallel mode (ddp.EXACT): the ranks all-reduce the 24-byte vector of loss normalisers (sh_label_counts:
+    valid fine / valid coarse / all pixels -- hiera_triplet_loss.py:41-107 num_valid, utils.py:20-21, nn.CrossEntropyLoss) and divide
+    their LOCAL numerators by the GLOBAL denominators; with SyncBN on, two ranks holding 2 + 2 or 1 + 3 images then reproduce the
+    single-process step on the whole batch: the per-rank losses SUM to the full-batch loss (1e-5 relative), the summed gradients and
+    the parameters after the SGD step equal the single-process ones (the gradient vector 5e-4, any one tensor 5e-3: fp32 sums in
+    another order, as test_syncbn_two_ranks_equals_full_batch)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 28900 + os.getpid() % 150 + cuts[1]
+    procs = [ctx.Process(target=_exact_worker, args=(r, 2, port, q, cuts)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+    for r in res.values():
+        assert not isinstance(r, str), r
+    full = _exact_step([0, 4], 0, 1)
+    total = res[0]["loss"] + res[1]["loss"]
+    assert abs(total - full["loss"]) < 1e-5 * abs(full["loss"]), (res[0]["loss"], res[1]["loss"], full["loss"])
+    ks = list(full["grads"])
+    for k in ks:
+        np.testing.assert_array_equal(res[0]["grads"][k], res[1]["grads"][k])          # summed by the all-reduce, not averaged
+    tot = _rel(np.concatenate([res[0]["grads"][k].ravel() for k in ks]), np.concatenate([full["grads"][k].ravel() for k in ks]))
+    worst = max((_rel(res[0]["grads"][k], full["grads"][k]), k) for k in ks)
+    assert tot < 5e-4 and worst[0] < 5e-3, (tot, worst)
+    upd = _rel(np.concatenate([res[0]["after"][k].ravel() for k in ks]), np.concatenate([full["after"][k].ravel() for k in ks]))
+    assert upd < 1e-6, upd

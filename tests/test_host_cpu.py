@@ -45,7 +45,7 @@ def test_abi_rejects_bad_arguments_without_launching(built):
     assert LIB.raw("sh_dwconv_dgrad")(None, 64, None, 0, None, None, None, 64, 1, 8, 8, 64, 1, 0, 0, None) == -1
     assert LIB.raw("sh_bn_bwd_reduce")(None, 64, None, 0, None, 64, None, None, None, None, None, 64, 64, 0, None, 0, 0, None) == -1
     assert LIB.raw("sh_bilinear_bwd")(None, 64, None, 64, 1, 4, 4, 8, 8, 64, None, 0, None) == -1
-    assert LIB.raw("sh_hiera2_loss_fwd")(None, 16, None, None, 9, 4, None, None, None, None, 1, 8, 8, 32, 32, None, 0, 0, None) == -1
+    assert LIB.raw("sh_hiera2_loss_fwd")(None, 16, None, None, 9, 4, None, None, None, None, 1, 8, 8, 32, 32, None, 0, 0, None, None) == -1
     assert LIB.raw("sh_bn_fold_partials")(None, 4096, 64, 262144.0, 64, 64, None, None) == -1
     assert LIB.raw("sh_bilinear_bwd_workspace")(0, 4, 4, 64) == -1 and LIB.raw("sh_bilinear_bwd_workspace")(2, 4, 4, 64) == 2 * 2 * 16 * 64 * 4
     assert LIB.raw("sh_resize_bilinear_coeffs")(0, 8, None, None, 0) < 0
