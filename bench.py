@@ -83,6 +83,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-units", action="store_true", help="skip the separate north-star unit measurement (profiling runs)")
     ap.add_argument("--batch", type=int, default=CFG["batch"])
+    ap.add_argument("--exact", action="store_true",
+                    help="N > 1: exact data-parallel mode (ddp.EXACT: all-reduced loss normalisers, summed gradients; with --syncbn a sharded "
+                         "step equals the single-process step on the global batch)")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the secondary bf16-compute-mode measurement of the same workload")
     ap.add_argument("--syncbn", action="store_true",
                     help="N > 1: BatchNorm statistics over all ranks (BASELINE configs[2] variant; default = per-rank statistics, "
                          "the weak-scaling setting of SURVEY 8d)")
@@ -103,6 +107,7 @@ def main():
         ddp.broadcast_module_state(list(tr.modules().values()))
         tr.grad_sync = ddp.GradSync(tr.params)
         ops.SYNC_BN = bool(args.syncbn)
+        ddp.EXACT = bool(args.exact)
     tr.train()
     img, lab = make_inputs(args.batch, rank, dev)
     lab8 = ops.labels_u8(lab)                       # the loader contract is i64 labels; convert once, outside the loop
@@ -208,6 +213,31 @@ def main():
                           "aspp_ds_branch_bf16": units.measure(device=dev, batch=args.batch, bf16=True)}
         except Exception as e:                  # never lose the headline line to the side measurement
             roof_units = {"aspp_ds_branch": {"error": repr(e)}}
+    # the same workload in bf16 COMPUTE mode (BASELINE configs[4]'s arithmetic: operands rounded once to bf16, one MFMA product, fp32
+    # accumulate / statistics / weights) -- a secondary figure; the headline `value` above is the fp32-accurate path
+    bf16_mode = None
+    if world == 1 and not args.no_bf16:
+        try:
+            from seghiero_amd.train_step import SegHieroTrainer
+            torch.manual_seed(0)
+            tb = SegHieroTrainer(depth=CFG["depth"], n_fine=CFG["n_fine"], coarse_to_fine_map=CFG["coarse_to_fine_map"], lr=0.01, device=dev,
+                                 compute_dtype=torch.bfloat16)
+            tb.train()
+            l0 = float(tb.train_step(img, lab8, 0))
+            for _ in range(4):
+                tb.train_step(img, lab8, 0)
+            barrier()
+            b0 = time.perf_counter()
+            for _ in range(40):
+                tb.train_step(img, lab8, 0)
+            barrier()
+            bdt = (time.perf_counter() - b0) / 40
+            bf16_mode = {"images_per_s": round(args.batch / bdt, 1), "ms_per_step": round(1e3 * bdt, 2), "loss_step0": round(l0, 5),
+                         "dtype": "bf16 operands (rounded once in the loaders), one MFMA product per tile, f32 accumulate / BatchNorm statistics / "
+                                  "weights / SGD; bf16-stored activations and activation gradients", "steps": 40}
+            del tb
+        except Exception as e:
+            bf16_mode = {"error": repr(e)}
     breakdown = {k: round(v["ms"], 2) for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])[:16]}
     out = {
         "metric": "images/sec at 512x512 (ResNet-50 2-level), full train step", "value": round(args.batch * world * args.steps / dt, 2),
@@ -218,9 +248,10 @@ def main():
         "config": {"workload": "BASELINE configs[1]: ResNet-50 + DepthwiseSeparableASPPContrastHead + 2-level HieraTripletLoss "
                                "+ aux head, 9 fine / 4 coarse, 512x512 synthetic, fwd+loss+bwd+SGD",
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                   "parallelism": f"dp{world}" + ("" if world == 1 else (" + SyncBN" if args.syncbn else " (per-rank BatchNorm statistics)"))},
+                   "parallelism": f"dp{world}" + ("" if world == 1 else (" + SyncBN" if args.syncbn else " (per-rank BatchNorm statistics)")) +
+                                  (" + exact normalisers" if args.exact and world > 1 else "")},
         "loss": round(loss_val, 5), "loss_step0": None if loss0 is None else round(float(loss0), 6),
-        "host_ms_per_step": round(sorted(host_ms)[1], 2), "roofline": roof, "roofline_units": roof_units, "kernel_ms_per_step": breakdown,
+        "host_ms_per_step": round(sorted(host_ms)[1], 2), "bf16_compute_mode": bf16_mode, "roofline": roof, "roofline_units": roof_units, "kernel_ms_per_step": breakdown,
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

@@ -3,6 +3,7 @@
 // wave-shuffle -> LDS -> per-block partials, and f64 for every cross-block combine (deterministic two-stage
 // reductions, no float atomics).
 #include "common.h"
+#include <stdlib.h>
 
 static inline unsigned grid_for(long long work_items, int block = 256, int cap = 4096) {
     long long g = sh_cdiv(work_items, block);
@@ -665,7 +666,22 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y
         const int r = e / cv;
         const long long m = m0 + r;
         const int c = (e - r * cv) * V;
-        if (V == 4) {
+        if (V == 8) {          // 16-byte accesses of bf16 tensors (two 4-channel halves, each in the 4-channel form's own arithmetic)
+            const sh_f8 yv = lda8(y, m * ldy + c, af & 1);
+            sh_f8 v;
+            v.lo = yv.lo * ld4(scale + c) + ld4(shift + c); v.hi = yv.hi * ld4(scale + c + 4) + ld4(shift + c + 4);
+            if (res) {
+                sh_f8 r = lda8(res, m * ldr + c, af & 2);
+                if (rscale) { r.lo = r.lo * ld4(rscale + c) + ld4(rshift + c); r.hi = r.hi * ld4(rscale + c + 4) + ld4(rshift + c + 4); }
+                v.lo += r.lo; v.hi += r.hi;
+            }
+            if (relu) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v.lo[j] = fmaxf(v.lo[j], 0.f); v.hi[j] = fmaxf(v.hi[j], 0.f); }
+            }
+            sta8(out, m * ldo + c, v, af & 4);
+            if (qmask) *reinterpret_cast<unsigned short*>(qmask + m * (C / 4) + (c >> 2)) = (unsigned short)(quad_mask_bits(v.lo) | (quad_mask_bits(v.hi) << 8));
+        } else if (V == 4) {
             f32x4 v = lda4(y, m * ldy + c, af & 1) * ld4(scale + c) + ld4(shift + c);        // af: bit 0 y, 1 residual, 2 out stored as bf16
             if (res) {
                 f32x4 r = lda4(res, m * ldr + c, af & 2);
@@ -693,6 +709,8 @@ static inline bool vec4_ok(int C, long long a, long long b = 0, long long c = 0,
     return (C & 3) == 0 && ((a | b | c | d | e) & 3) == 0;
 }
 static inline bool ptr16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+// SEGHIERO_EW8=0: the 4-channel form also for bf16 tensors (A/B and the bit-equality test of the 8-channel form)
+static inline bool ew8_on() { const char* e = getenv("SEGHIERO_EW8"); return !(e && e[0] == '0'); }
 
 extern "C" int sh_bn_act(const float* y, int ldy, const float* scale, const float* shift, const float* residual, int ldr,
                          const float* res_scale, const float* res_shift, float* out, int ldo, int64_t M, int C, int relu, uint8_t* relu_mask,
@@ -704,7 +722,10 @@ extern "C" int sh_bn_act(const float* y, int ldy, const float* scale, const floa
     const bool v4 = vec4_ok(C, ldy, ldo, residual ? ldr : 0) && ptr16(y) && ptr16(out) && ptr16(scale) && ptr16(shift) && (!residual || ptr16(residual)) &&
                     (!res_scale || (ptr16(res_scale) && ptr16(res_shift)));
     if ((act_flags || relu_mask) && !v4) return SH_EUNSUPPORTED;
-    if (v4) bn_act_kernel<4><<<rows_grid(M, C / 4), 256, 0, (hipStream_t)stream>>>(y, ldy, scale, shift, residual, ldr, out, ldo, M, C, relu, res_scale, res_shift, act_flags, relu_mask);
+    // bf16 tensors with 16-byte rows: eight channels per lane (one 16-byte access per tensor instead of 8 bytes)
+    const bool v8 = v4 && ew8_on() && (act_flags & 1) && (C & 7) == 0 && ((ldy | ldo | (residual ? ldr : 0)) & 7) == 0 && (!relu_mask || ((uintptr_t)relu_mask & 1) == 0);
+    if (v8) bn_act_kernel<8><<<rows_grid(M, C / 8), 256, 0, (hipStream_t)stream>>>(y, ldy, scale, shift, residual, ldr, out, ldo, M, C, relu, res_scale, res_shift, act_flags, relu_mask);
+    else if (v4) bn_act_kernel<4><<<rows_grid(M, C / 4), 256, 0, (hipStream_t)stream>>>(y, ldy, scale, shift, residual, ldr, out, ldo, M, C, relu, res_scale, res_shift, act_flags, relu_mask);
     else bn_act_kernel<1><<<rows_grid(M, C), 256, 0, (hipStream_t)stream>>>(y, ldy, scale, shift, residual, ldr, out, ldo, M, C, relu, res_scale, res_shift, 0, nullptr);
     return sh_launch_status();
 }
@@ -724,7 +745,33 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const int r = e / cv;
         const long long m = m0 + r;
         const int c = (e - r * cv) * V;
-        if (V == 4) {
+        if (V == 8) {          // 16-byte accesses of bf16 tensors: the 4-channel arithmetic on two halves
+            sh_f8 g8 = lda8(dout, m * lddo + c, af & 4);
+            const sh_f8 y8 = lda8(y, m * ldy + c, af & 1);
+            sh_f8 o8 = sh_f8{f32x4{1.f, 1.f, 1.f, 1.f}, f32x4{1.f, 1.f, 1.f, 1.f}};
+            if (relu == 1) o8 = lda8(out, m * ldo + c, af & 2);
+            else if (relu == 2) { o8.lo = y8.lo * ld4(scale + c) + ld4(shift + c); o8.hi = y8.hi * ld4(scale + c + 4) + ld4(shift + c + 4); }
+            else if (relu == 3) { o8.lo = quad_mask_load(out, m * ldo + (c >> 2)); o8.hi = quad_mask_load(out, m * ldo + (c >> 2) + 1); }
+            if (relu) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { if (!(o8.lo[j] > 0.f)) g8.lo[j] = 0.f; if (!(o8.hi[j] > 0.f)) g8.hi[j] = 0.f; }
+            }
+            sh_f8 r8;
+            {
+                const f32x4 is = ld4(invstd + c), xh = (y8.lo - ld4(mean + c)) * is;
+                f32x4 ga = {1.f, 1.f, 1.f, 1.f};
+                if (gamma) ga = ld4(gamma + c);
+                r8.lo = ga * is * (g8.lo - ld4(c1 + c) - xh * ld4(c2 + c));
+            }
+            {
+                const f32x4 is = ld4(invstd + c + 4), xh = (y8.hi - ld4(mean + c + 4)) * is;
+                f32x4 ga = {1.f, 1.f, 1.f, 1.f};
+                if (gamma) ga = ld4(gamma + c + 4);
+                r8.hi = ga * is * (g8.hi - ld4(c1 + c + 4) - xh * ld4(c2 + c + 4));
+            }
+            sta8(dy, m * lddy + c, r8, af & 8);
+            if (dres) sta8(dres, m * lddres + c, g8, af & 16);
+        } else if (V == 4) {
             f32x4 g = lda4(dout, m * lddo + c, af & 4);                     // af: bit 0 y, 1 out, 2 dout, 3 dy, 4 dres stored as bf16
             const f32x4 yv = lda4(y, m * ldy + c, af & 1);
             if (relu == 1) {
@@ -770,7 +817,9 @@ extern "C" int sh_bn_bwd_apply(const float* dout, int lddo, const float* out, in
                     ptr16(mean) && ptr16(invstd) && ptr16(c1) && ptr16(c2) && (!gamma || ptr16(gamma)) && (relu != 1 || ptr16(out)) &&
                     (relu != 2 || (ptr16(scale) && ptr16(shift))) && (!dres || ptr16(dres));
     if ((act_flags || relu == 3) && !v4) return SH_EUNSUPPORTED;
-    if (v4) bn_bwd_apply_kernel<4><<<rows_grid(M, C / 4), 256, 0, (hipStream_t)stream>>>(dout, lddo, out, ldo, y, ldy, mean, invstd, scale, shift, gamma, c1, c2, dy, lddy, dres, lddres, M, C, relu, act_flags);
+    const bool v8 = v4 && ew8_on() && (act_flags & 1) && (C & 7) == 0 && ((lddo | ldy | lddy | (relu == 1 ? ldo : 0) | (dres ? lddres : 0)) & 7) == 0 && (relu != 3 || (ldo & 1) == 0);
+    if (v8) bn_bwd_apply_kernel<8><<<rows_grid(M, C / 8), 256, 0, (hipStream_t)stream>>>(dout, lddo, out, ldo, y, ldy, mean, invstd, scale, shift, gamma, c1, c2, dy, lddy, dres, lddres, M, C, relu, act_flags);
+    else if (v4) bn_bwd_apply_kernel<4><<<rows_grid(M, C / 4), 256, 0, (hipStream_t)stream>>>(dout, lddo, out, ldo, y, ldy, mean, invstd, scale, shift, gamma, c1, c2, dy, lddy, dres, lddres, M, C, relu, act_flags);
     else bn_bwd_apply_kernel<1><<<rows_grid(M, C), 256, 0, (hipStream_t)stream>>>(dout, lddo, out, ldo, y, ldy, mean, invstd, scale, shift, gamma, c1, c2, dy, lddy, dres, lddres, M, C, relu, 0);
     return sh_launch_status();
 }

@@ -70,3 +70,22 @@ __device__ __forceinline__ void sta4(float* base, long long idx, f32x4 v, int bf
     if (bf) *reinterpret_cast<sh_u32x2*>(reinterpret_cast<unsigned short*>(base) + idx) = f32_to_bf16x4(v);
     else st4(base + idx, v);
 }
+
+// eight consecutive channels of one pixel: ONE 16-byte access of a bf16 tensor, two of an fp32 one (idx = element index, multiple of 8).  The
+// streaming kernels take this form where their tensors are bf16 (bf16 compute mode): the 4-channel form moves 8 bytes per lane there.
+struct sh_f8 { f32x4 lo, hi; };
+typedef unsigned int sh_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ sh_f8 lda8(const float* base, long long idx, int bf) {
+    sh_f8 r;
+    if (bf) {
+        const sh_u32x4 v = *reinterpret_cast<const sh_u32x4*>(reinterpret_cast<const unsigned short*>(base) + idx);
+        r.lo = bf16x4_to_f32(sh_u32x2{v[0], v[1]}); r.hi = bf16x4_to_f32(sh_u32x2{v[2], v[3]});
+    } else { r.lo = ld4(base + idx); r.hi = ld4(base + idx + 4); }
+    return r;
+}
+__device__ __forceinline__ void sta8(float* base, long long idx, const sh_f8& v, int bf) {
+    if (bf) {
+        const sh_u32x2 a = f32_to_bf16x4(v.lo), b = f32_to_bf16x4(v.hi);
+        *reinterpret_cast<sh_u32x4*>(reinterpret_cast<unsigned short*>(base) + idx) = sh_u32x4{a[0], a[1], b[0], b[1]};
+    } else { st4(base + idx, v.lo); st4(base + idx + 4, v.hi); }
+}

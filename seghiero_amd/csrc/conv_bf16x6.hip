@@ -881,11 +881,19 @@ int sh_x6_splitk_reduce(const ConvQ& p, int mode, hipStream_t st) {
     return sh_launch_status();
 }
 // K slices for an under-filled grid: the mid-network shapes (M*N small, K long) give < 2 blocks per CU with 128x128 tiles.
-static int splitk_plan(long long M, long long N, long long K, int parity, int scatter) {
+static int splitk_plan(long long M, long long N, long long K, int parity, int scatter, int b16 = 0) {
     if (parity || scatter || (N & 3)) return 1;
     const long long tiles = sh_cdiv(M, 128) * sh_cdiv(N, 128), nkt = sh_cdiv(K, 32);
-    static int target = 0, minkt = 0;
-    if (!target) { const char* e = getenv("SEGHIERO_SK_TARGET"); target = e ? atoi(e) : 512; e = getenv("SEGHIERO_SK_MINKT"); minkt = e ? atoi(e) : 16; }
+    static int target6 = 0, minkt6 = 0, target1 = 0, minkt1 = 0;
+    if (!target6) {
+        const char* e = getenv("SEGHIERO_SK_TARGET"); target6 = e ? atoi(e) : 512; e = getenv("SEGHIERO_SK_MINKT"); minkt6 = e ? atoi(e) : 16;
+        // bf16 compute kernels (one MFMA product: the loop is 3-6x shorter, the fp32 slabs and their reduce cost the same)
+        // -- measured on the configs[4] shape and on the headline shape in bf16 mode (same box, alternating): without K slices the
+        // under-filled mid-network grids leave CUs to the weight gradients on the side stream, with them 2 ms of slab reduces per step:
+        // 26.6-28.7 vs 27.7 ms and 19.06 vs 19.27 ms -- off by default (SEGHIERO_B16_SK_TARGET=512 restores the fp32-accurate plan)
+        e = getenv("SEGHIERO_B16_SK_TARGET"); target1 = e ? atoi(e) : 1; e = getenv("SEGHIERO_B16_SK_MINKT"); minkt1 = e ? atoi(e) : 16;
+    }
+    const int target = b16 ? target1 : target6, minkt = b16 ? minkt1 : minkt6;
     if (tiles >= (target * 3) / 4 || nkt < 2 * minkt) return 1;
     long long S = sh_cdiv(target, tiles);
     if (S > nkt / minkt) S = nkt / minkt;    // >= minkt K tiles per slice
@@ -1007,9 +1015,9 @@ extern "C" int64_t sh_conv_x6_workspace(int which, int N, int H, int W, int Cin,
     const int S = splitk_plan(M, Nn, K, parity, 0);
     return S > 1 ? (int64_t)S * M * Nn * 4 : 0;
 }
-static void use_splitk(ConvQ& p, float* workspace, int64_t workspace_bytes) {
+static void use_splitk(ConvQ& p, float* workspace, int64_t workspace_bytes, int b16 = 0) {
     if (x6_variant() == 7 && workspace && workspace_bytes >= (1 << 20)) { p.slab = workspace; return; }      // phase-timing buffer
-    const int S = splitk_plan(p.M, p.Nn, p.K, p.parity, p.scatter);
+    const int S = splitk_plan(p.M, p.Nn, p.K, p.parity, p.scatter, b16);
     if (S > 1 && workspace && workspace_bytes >= (int64_t)S * p.M * p.Nn * 4) { p.ksplit = S; p.slab = workspace; p.ldslab = p.Nn; }
 }
 // byte extents of the operands for the buffer descriptors of the pipelined kernels; false = too large for 32-bit offsets
@@ -1410,7 +1418,7 @@ extern "C" int sh_conv_fprop_b16(const void* x, int ldx, const float* in_scale, 
     p.M = N * p.Ho * p.Wo; p.Nn = Cout; p.K = KH * KW * Cin; p.Kc = Cin;
     p.n_partials = (int)sh_cdiv(p.M, 64);
     p.aff_scale = in_scale; p.aff_shift = in_shift;
-    if ((ldy & 3) == 0 && ((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0)) use_splitk(p, workspace, workspace_bytes);
+    if ((ldy & 3) == 0 && ((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0)) use_splitk(p, workspace, workspace_bytes, 1);
     const long long a = ((long long)N * H * W - 1) * ldx + Cin, b = (long long)Cout * p.K;
     if (a * 2 >= (1ll << 31) || b * 2 >= (1ll << 31)) return SH_EUNSUPPORTED;
     p.a_bytes = (unsigned)(a * 2); p.b_bytes = (unsigned)(b * 2);
@@ -1474,7 +1482,7 @@ extern "C" int sh_conv_dgrad_b16(const void* dy, int lddy, const void* y_lin, in
         al = al && (ldyp & 3) == 0 && (((uintptr_t)y_prev | (uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0 &&
              (!out_prev || qmask || ((ldop & 3) == 0 && ((uintptr_t)out_prev & 15) == 0));
     }
-    if (al) use_splitk(p, workspace, workspace_bytes);
+    if (al) use_splitk(p, workspace, workspace_bytes, 1);
     const long long a = ((long long)N * p.Ho * p.Wo - 1) * lddy + CoutP, b = (long long)KH * KW * Cin * CoutP;
     if (a * 4 >= (1ll << 31) || b * 2 >= (1ll << 31)) return SH_EUNSUPPORTED;
     p.a_bytes = (unsigned)(a * (dy_bf ? 2 : 4)); p.b_bytes = (unsigned)(b * 2);

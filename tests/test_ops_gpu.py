@@ -902,3 +902,37 @@ def test_conv_bf16_compute_mode_deferred_batchnorm_backward(ops, case):
         assert ops._wgrad_b16(nhwc_bf16(x), dd, dw, 1, 0, 1, False, None)
         e = float((dw.cpu().double() - ref_dw).abs().max() / ref_dw.abs().max())
         assert e < 1e-3, e
+
+
+def test_batchnorm_streaming_kernels_eight_channel_form_is_bit_identical(ops, monkeypatch):
+    """sh_bn_act and sh_bn_bwd_apply on bf16 tensors move eight channels (one 16-byte access per tensor) per lane in bf16 compute mode;
+    the arithmetic per element is the 4-channel form's: outputs, the ReLU quad mask, dy and dres are bit-identical (SEGHIERO_EW8=0
+    selects the 4-channel form)."""
+    g = torch.Generator().manual_seed(11)
+    n, c, h, w = 2, 136, 12, 10
+    bf = torch.bfloat16
+    y = nhwc_bf16(torch.randn(n, c, h, w, generator=g))
+    res = nhwc_bf16(torch.randn(n, c, h, w, generator=g))
+    dout = nhwc_bf16(torch.randn(n, c, h, w, generator=g))
+    coefs = torch.stack([0.2 * torch.randn(c, generator=g), 0.5 + torch.rand(c, generator=g), torch.randn(c, generator=g), 0.3 * torch.randn(c, generator=g)]).to(DEV).contiguous()
+    gamma = (0.5 + torch.rand(c, generator=g)).to(DEV)
+    got = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("SEGHIERO_EW8", form)
+        out = ops.new_act(n, c, h, w, DEV, dtype=bf)
+        mask = ops.new_relu_mask(n, c, h, w, DEV)
+        ops.bn_act(y, coefs, out, True, res, mask=mask)
+        r = [out.clone(), mask.clone()]
+        for relu, o in ((1, out), (2, None), (1, mask), (0, None)):
+            dy, dg, db, dres = ops.bn_backward(dout, o, y, coefs, gamma, relu, want_dres=True)
+            r += [dy.clone(), dg.clone(), db.clone(), dres.clone()]
+        got[form] = r
+    for a, b in zip(got["1"], got["0"]):
+        assert a.dtype == b.dtype and torch.equal(a, b)
+    assert got["1"][2].dtype == torch.float32           # (outside compute_as: gradients made by bn_backward stay fp32 -- both forms read bf16 y / dout)
+    with ops.compute_as(torch.bfloat16):
+        for form in ("1", "0"):
+            monkeypatch.setenv("SEGHIERO_EW8", form)
+            dy, dg, db, dres = ops.bn_backward(dout, mask, y, coefs, gamma, 1, want_dres=True)
+            got[form] = [dy.clone(), dres.clone()]
+        assert got["1"][0].dtype == bf and torch.equal(got["1"][0], got["0"][0]) and torch.equal(got["1"][1], got["0"][1])

@@ -15,3 +15,9 @@ echo "pmc done"
 echo "aspp unit done"
 python bench.py --steps 400 --warmup 10 --no-cpu-baseline > gpurun_out/sustained_$TAG.json 2> gpurun_out/sustained_$TAG.err
 echo "sustained done"; cat gpurun_out/sustained_$TAG.json | cut -c1-400
+# condense on the box (the raw traces are too large to merge back) and leave the summaries under gpurun_out/profiles_out/
+mkdir -p gpurun_out/profiles_out profiles_tmp
+python tools/summarize_profile.py $TAG gpurun_out/profiles_out > gpurun_out/summarize_$TAG.log 2>&1
+python tools/summarize_pmc.py gpurun_out/pmc_$TAG "conv_x6p_kernel|conv_wgrad_x6p" gpurun_out/profiles_out/${TAG}_pmc_sep1pw.json >> gpurun_out/summarize_$TAG.log 2>&1
+cp gpurun_out/sustained_$TAG.json gpurun_out/profiles_out/${TAG}_sustained_bench.json
+rm -rf gpurun_out/prof_$TAG gpurun_out/pmc_$TAG

@@ -35,7 +35,7 @@ def main():
         tr.train_step(img, lab8, 0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = 10
+    n = 30
     for _ in range(n):
         loss = tr.train_step(img, lab8, 0)
     torch.cuda.synchronize()
