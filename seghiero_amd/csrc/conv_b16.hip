@@ -367,8 +367,11 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void conv_b16_kernel(co
         // BatchNorm-backward y tile, the ReLU quad mask -- is issued up front into the registers the staging sets no longer need (16-byte
         // raw words, widened when used): ONE memory round trip per wave instead of one per two row groups (measured on the 1024 -> 256
         // layer-3 gradient with residual mask and identity addend: 80 us for a 25 us byte count, the four dependent trips of the chunked form)
-        bool fast = false;
-        if constexpr (MODE == DGRAD) {
+        // (the eight-wave form of the input gradient is launched for all-bf16 epilogues only -- sh_b16_launch checks -- and compiles just
+        // this path: the generic one needs more than its 128 registers)
+        constexpr bool FAST_ONLY = W8 && MODE == DGRAD;
+        bool fast = FAST_ONLY;
+        if constexpr (MODE == DGRAD && !FAST_ONLY) {
             fast = (p.act & B16_OUT_BF) && (p.extra == nullptr || (p.act & B16_ADD_BF)) &&
                    (EPI != 2 || ((p.act & 4) && (p.bnb_out == nullptr || (p.act & 64))));
         }
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void conv_b16_kernel(co
                     }
                 }
             }
-        } else
+        } else if constexpr (!FAST_ONLY)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -572,8 +575,18 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void conv_b16_kernel(co
 static int b16_w8() { static int v = -2; if (v == -2) { const char* e = getenv("SEGHIERO_B16_W8"); v = e ? atoi(e) : 1; } return v; }
 template <int MODE, int TN, int AFF, int EPI, int SK, int TAP, int GRP, int A32, int W8 = 0>
 static int launch_b16(ConvQ& p, hipStream_t st) {
-    // (the BatchNorm-backward epilogue and the lin loader need more than the 128 registers of the eight-wave form: 106-132 spills)
-    if constexpr (TN == 2 && !W8 && !A32 && EPI != 2 && AFF != 2) { if (b16_w8()) return launch_b16<MODE, TN, AFF, EPI, SK, TAP, GRP, A32, 1>(p, st); }
+    // (the lin loader needs more than the 128 registers of the eight-wave form; the input gradient's eight-wave form has the all-bf16
+    // epilogue only)
+    if constexpr (TN == 2 && !W8 && !A32 && AFF != 2) {
+        bool ok8 = b16_w8() != 0;
+        // input gradients: opt-in (SEGHIERO_B16_W8=2).  Measured on the configs[4] step, same box, alternating rounds of 20 steps: the
+        // four-wave form 27.16 / 27.06 / 27.39 / 27.13 ms, the eight-wave form 27.64 / 35.07 / 29.03 / 26.80 ms -- sixteen 128-register waves
+        // per CU leave the concurrent weight-gradient stream nothing, and the step time becomes erratic
+        if constexpr (MODE == DGRAD)
+            ok8 = b16_w8() == 2 && (p.act & B16_OUT_BF) && (p.extra == nullptr || (p.act & B16_ADD_BF)) &&
+                  (EPI != 2 || ((p.act & 4) && (p.bnb_out == nullptr || (p.act & 64))));
+        if (ok8) return launch_b16<MODE, TN, AFF, EPI, SK, TAP, GRP, A32, 1>(p, st);
+    }
     constexpr int BM = 128, BN = 64 * TN;
     const size_t lds = 2 * (size_t)(BM + BN) * 128 + (AFF == 2 ? 16 : AFF ? 8 : 0) * (size_t)p.Kc;
     // 64 KB of tiles + the coefficient table: two blocks per CU up to Kc = 1024 (lin loader) / 2048 (BatchNorm + ReLU loader); beyond

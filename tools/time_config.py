@@ -16,8 +16,39 @@ CFGS = {
 }
 
 
+def ab(name, batch):
+    """fp32-accurate vs bf16 compute mode of one configuration in ONE process, alternating (the ratio without box-to-box and clock-ramp noise)."""
+    cfg = dict(CFGS[name])
+    size, b0 = cfg.pop("size"), cfg.pop("batch")
+    batch = batch or b0
+    img, lab = make_batch(batch, size, cfg["n_fine"], seed=0, device="cuda:0")
+    lab8 = ops.labels_u8(lab)
+    trs = {}
+    for mode, dt in (("f32", torch.float32), ("b16", torch.bfloat16)):
+        torch.manual_seed(0)
+        trs[mode] = SegHieroTrainer(lr=0.01, device="cuda:0", compute_dtype=dt, **cfg)
+        trs[mode].train()
+        for _ in range(3):
+            trs[mode].train_step(img, lab8, 0)
+    res = {"f32": [], "b16": []}
+    for rnd in range(4):
+        for mode in ("f32", "b16"):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                trs[mode].train_step(img, lab8, 0)
+            torch.cuda.synchronize()
+            res[mode].append((time.perf_counter() - t0) / 20 * 1e3)
+    med = {m: sorted(v)[len(v) // 2] for m, v in res.items()}
+    print(f"{name} batch {batch} @ {size}^2, 4 alternating rounds of 20 steps: fp32-accurate {[round(x, 2) for x in res['f32']]} ms, "
+          f"bf16 compute {[round(x, 2) for x in res['b16']]} ms; medians {med['f32']:.2f} / {med['b16']:.2f} ms = {med['f32'] / med['b16']:.2f}x "
+          f"({batch / med['f32'] * 1e3:.1f} -> {batch / med['b16'] * 1e3:.1f} images/s)")
+
+
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "C4"
+    if len(sys.argv) > 3 and sys.argv[3] == "ab":
+        return ab(name, int(sys.argv[2]))
     cfg = dict(CFGS[name])
     size, batch = cfg.pop("size"), cfg.pop("batch")
     if len(sys.argv) > 2:
