@@ -64,11 +64,20 @@ int sh_x6p_wgrad_l1b0(ConvQ& p, bool aff, int wgm, int wgn, int splits, hipStrea
 int sh_x6p_wgrad_l0b1(ConvQ& p, bool aff, int wgm, int wgn, int splits, hipStream_t st);
 int sh_x6p_wgrad_l1b1(ConvQ& p, bool aff, int wgm, int wgn, int splits, hipStream_t st);
 static int x6p_mode() { static int v = -2; if (v == -2) { const char* e = getenv("SEGHIERO_X6P"); v = e ? atoi(e) : 1; } return v; }
+[[maybe_unused]] static int x6p_ws() { static int v = -2; if (v == -2) { const char* e = getenv("SEGHIERO_X6P_WS"); v = e ? atoi(e) : 0; } return v; }
 static int x6p_tile() { static int v = -2; if (v == -2) { const char* e = getenv("SEGHIERO_X6P_TILE"); v = e ? atoi(e) : 0; } return v; }
-#if SH_PART(1) || SH_PART(2)
-template <int MODE, int TM, int TN, int WGM, int WGN, int WPS, int AFF, int EPI, int SK, int TAP, int GRP = 0, int ABF = 0>
-__global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const ConvQ p) {
-    constexpr int NT = 64 * WGM * WGN;
+#if SH_PART(1) || SH_PART(2) || defined(SH_X6P_EXP)
+// WS (r3): wave-specialised form.  The block carries a second set of WGM * WGN waves; waves 0 .. WGM*WGN-1 ("consumers") only read
+// fragments and issue MFMAs, the others ("producers") only load, apply the BatchNorm hooks, split and store -- one consumer and one
+// producer of the block on every SIMD, so the matrix pipe and the vector ALU are fed from two instruction streams the hardware arbitrates
+// cycle by cycle instead of from one in-order stream whose interleave is the compiler's (which clusters the MFMAs at the end of a phase
+// whatever the sched_group_barrier pattern asks for -- see DESIGN.md section 7).  Same LDS image, same phases, same barrier count.
+// MEASURED (r3, same box, alternating processes): bit-identical results, 126 VGPRs, no spills -- and no faster: fprop 165.0 -> 163.9 TF,
+// dgrad 91.6 -> 88.6 TF over the step's shapes, step 32.0 -> 32.5 ms.  Co-issue is therefore not what limits the loop (the vector
+// port needs ~150 VALU x 4 cycles per 768 MFMA cycles of a phase); instantiated only in experiment builds (-DSH_X6P_WS).
+template <int MODE, int TM, int TN, int WGM, int WGN, int WPS, int AFF, int EPI, int SK, int TAP, int GRP = 0, int ABF = 0, int WS = 0>
+__global__ __launch_bounds__(64 * WGM * WGN * (WS ? 2 : 1), WPS) void conv_x6p_kernel(const ConvQ p) {
+    constexpr int NT = 64 * WGM * WGN;                           // loader threads = consumer threads
     constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
     constexpr int A_PLANE = BM * ROWB, B_PLANE = BN * ROWB;      // bytes
     constexpr int RPP = NT / 4;                                  // rows covered per loader pass (4 lanes x 16 B per half-tile row)
@@ -99,7 +108,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
         return bf ? bf16x4_to_f32(sh_u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])}) : v;
     };
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t_all = threadIdx.x, t = WS ? (t_all & (NT - 1)) : t_all, lane = t & 63, wave = t >> 6;
+    [[maybe_unused]] const bool producer = WS && t_all >= NT;    // wave-uniform
+    static_assert(!WS || (NT & (NT - 1)) == 0, "wave-specialised form: power-of-two wave count");
     const int wm = wave / WGN, wn = wave % WGN, l31 = lane & 31, h = lane >> 5;
     const unsigned nblk = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
     const unsigned bid = xcd_remap(blockIdx.x, nblk);
@@ -148,10 +159,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
     int b_row[NB];                                               // element offset of the B row (< 2^29)
     unsigned b_ok[NB];                                           // validity as all-ones / zero masks: offsets are formed with
     int cur_tap = -1;                                            // AND / OR only, nothing the compiler can turn into a branch
+    // (r3) 1x1, stride 1, no padding: output pixel m is row m of the operand -- no integer divisions in the prologue (measured on the bf16
+    // kernels: ~300 of a wave's 1 300 prologue / epilogue VALU instructions)
+    const bool direct = TAP == 0 && p.stride == 1 && p.pad == 0 && !(MODE == DGRAD && (p.parity || p.scatter));
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int m = m0 + r0 + RPP * i;
-        if (m < Mc) {
+        if (direct) { a_y[i] = m < Mc ? 0 : -(1 << 28); a_x[i] = 0; a_nb[i] = m < Mc ? m : 0; }
+        else if (m < Mc) {
             if constexpr (MODE == FPROP) {
                 const int ow = m % p.Wo, q = m / p.Wo, oh = q % p.Ho, n = q / p.Ho;
                 a_y[i] = oh * p.stride - p.pad; a_x[i] = ow * p.stride - p.pad; a_nb[i] = n * p.H * p.W;
@@ -172,6 +187,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
     [[maybe_unused]] int a_off2[NA];                             // ... and of the y row (AFF == 2: its own pixel stride)
     unsigned a_ok[NA];
     auto set_tap = [&](int tap) {
+        if (direct) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                a_ok[i] = a_y[i] == 0 ? ~0u : 0u;
+                a_off[i] = a_nb[i] * lda;
+                if constexpr (AFF == 2) a_off2[i] = a_nb[i] * (int)p.lda2;
+            }
+            return;
+        }
         int kh, kw;
         if (MODE == DGRAD && p.parity) { const int ty = tap / ntw; kh = cy + 2 * ty; kw = cx + 2 * (tap - ty * ntw); }
         else { kh = tap / p.KW; kw = tap - kh * p.KW; }
@@ -337,12 +361,42 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
     };
     // ------------------------------------------------------------------ prologue
     if constexpr (AFF == 2) {
-        for (int c = t; c < 4 * p.Kc; c += NT) coef[c] = p.lin[c];
+        for (int c = t_all; c < 4 * p.Kc; c += NT * (WS ? 2 : 1)) coef[c] = p.lin[c];
         __syncthreads();
     } else if constexpr (AFF) {
-        for (int c = t; c < p.Kc; c += NT) { coef[c] = sc_ptr ? sc_ptr[c] : 1.f; coef[p.Kc + c] = sh_ptr ? sh_ptr[c] : 0.f; }
+        for (int c = t_all; c < p.Kc; c += NT * (WS ? 2 : 1)) { coef[c] = sc_ptr ? sc_ptr[c] : 1.f; coef[p.Kc + c] = sh_ptr ? sh_ptr[c] : 0.f; }
         __syncthreads();
     }
+    if constexpr (WS) {
+        // every wave executes the same number of barriers (the branch is wave-uniform); producers leave after the loop -- a finished
+        // wave no longer counts towards the block's barrier, and the epilogue has none
+        if (producer) {
+            Regs R0, R1;
+            prepare_tap(q_begin);     load_half(q_begin, R0);
+            prepare_tap(q_begin + 1); load_half(q_begin + 1, R1);
+            store_half(R0, 0);
+            prepare_tap(q_begin + 2); load_half(q_begin + 2, R0);
+            __syncthreads();
+            for (int j = 0; j < nq; j += 2) {
+                prepare_tap(q_begin + j + 3);
+                store_half(R1, 1);
+                load_half(q_begin + j + 3, R1);
+                __syncthreads();
+                prepare_tap(q_begin + j + 4);
+                store_half(R0, 0);
+                load_half(q_begin + j + 4, R0);
+                __syncthreads();
+            }
+            return;
+        }
+        __syncthreads();
+        for (int j = 0; j < nq; j += 2) {
+            compute_half(0);
+            __syncthreads();
+            compute_half(1);
+            __syncthreads();
+        }
+    } else {
     Regs R0, R1;
     prepare_tap(q_begin);     load_half(q_begin, R0);
     prepare_tap(q_begin + 1); load_half(q_begin + 1, R1);
@@ -363,6 +417,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
         compute_half(1);                         // half-tile j+1
         phase_schedule();
         __syncthreads();
+    }
     }
 
     if constexpr (SK) {          // split-K: raw partial sums; bias / addend / BN statistics are applied by the reduce kernel
@@ -418,7 +473,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * RS + 32 * j + l31] = acc[i][j][r];
-            __syncthreads();
+            // (r3) no block-wide barrier: the strip is private to the wave (LDS operations of one wave complete in order) and the planes it
+            // overlays were released by the main loop's last barrier
             // the strip's NRD row groups in chunks: the BatchNorm-backward epilogue holds four tiles per row group (accumulator strip,
             // addend, y, out) next to the 64 accumulator registers -- all 8 groups at once spilled 85 registers
             constexpr int CH = (EPI == 2 && NRD > 4) ? 4 : NRD;
@@ -481,7 +537,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
                     }
                 }
             }
-            __syncthreads();
         }
     } else if constexpr (EPI != 2) {
     [[maybe_unused]] float pend_s[TN], pend_q[TN];          // EPI == 2: sums of the even tile of a 64-row group
@@ -595,14 +650,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, WPS) void conv_x6p_kernel(const Con
 }
 
 // ---------------------------------------------------------------------------------------- host side
-template <int MODE, int TM, int TN, int WGM, int WGN, int WPS, int AFF, int EPI, int SK, int TAP, int GRP = 0, int ABF = 0>
+template <int MODE, int TM, int TN, int WGM, int WGN, int WPS, int AFF, int EPI, int SK, int TAP, int GRP = 0, int ABF = 0, int WS = 0>
 static int launch_x6p(ConvQ& p, hipStream_t st) {
     constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
     const size_t lds = 3 * (size_t)(BM + BN) * ROWB + (AFF == 2 ? 16 : AFF ? 8 : 0) * (size_t)p.Kc;
     if (lds > 160 * 1024) return SH_X6P_NO;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6p_kernel<MODE, TM, TN, WGM, WGN, WPS, AFF, EPI, SK, TAP, GRP, ABF>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6p_kernel<MODE, TM, TN, WGM, WGN, WPS, AFF, EPI, SK, TAP, GRP, ABF, WS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         attr_lds = 160 * 1024;
     }
@@ -611,7 +666,7 @@ static int launch_x6p(ConvQ& p, hipStream_t st) {
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), p.parity ? 4u : (SK ? (unsigned)p.ksplit : 1u));
     // (Wave quantisation -- 1024 or 2048 blocks on 768 resident slots -- was tried against TWO blocks per CU, enforced by a larger dynamic-LDS
     // request, so that those grids run 2 or 4 full rounds: slower for every grid-size threshold, step 31.15 -> 31.16 / 31.3 / 31.4 ms.)
-    conv_x6p_kernel<MODE, TM, TN, WGM, WGN, WPS, AFF, EPI, SK, TAP, GRP, ABF><<<grid, 64 * WGM * WGN, lds, st>>>(p);
+    conv_x6p_kernel<MODE, TM, TN, WGM, WGN, WPS, AFF, EPI, SK, TAP, GRP, ABF, WS><<<grid, 64 * WGM * WGN * (WS ? 2 : 1), lds, st>>>(p);
     return sh_launch_status();
 }
 
@@ -627,6 +682,9 @@ static int pick_tile_x6p(ConvQ& p, hipStream_t st, int force) {
     // The BatchNorm-backward epilogue (EPI == 2) spilled 85 registers until its row groups were processed in chunks; 128 x 64 tiles with
     // it still need 3 instead of 4 blocks per CU (18 spills at 128 VGPRs).
     constexpr int W1 = SH_W1(AFF, EPI), W2 = SH_W2(AFF, EPI);
+#ifdef SH_X6P_WS       // experiment builds only (-DSH_X6P_WS, then SEGHIERO_X6P_WS=1): 4 consumer + 4 producer waves, 2 blocks per CU
+    if (p.Nn > 64 && x6p_ws()) return launch_x6p<MODE, 2, 2, 2, 2, 2, AFF, EPI, 0, TAP, 0, ABF, 1>(p, st);
+#endif
     if (p.Nn > 64) return launch_x6p<MODE, 2, 2, 2, 2, W1, AFF, EPI, 0, TAP, 0, ABF>(p, st);     // 128 x 128, 4 waves of 64 x 64, 3 blocks per CU
     return launch_x6p<MODE, 2, 1, 2, 2, W2, AFF, EPI, 0, TAP, 0, ABF>(p, st);                    // 128 x 64, 4 blocks per CU
 }
@@ -975,4 +1033,8 @@ int sh_x6p_wgrad_l1b1(ConvQ& p, bool aff, int wgm, int wgn, int splits, hipStrea
     return aff ? pick_wgrad_x6p<1, 1, 1>(p, wgm, wgn, splits, st) : pick_wgrad_x6p<0, 1, 1>(p, wgm, wgn, splits, st);
 }
 #endif
+#endif
+
+#ifdef SH_X6P_EXP      // schedule experiments: ONE instantiation, device assembly only (hipcc -S --cuda-device-only -DSH_X6P_PART=-1 -DSH_X6P_EXP=...)
+template __global__ void conv_x6p_kernel<SH_X6P_EXP>(const ConvQ);
 #endif
