@@ -43,11 +43,14 @@ class _Block(nn.Module):
             self.conv3, self.bn3 = _conv(width, width * 4, 1), nn.BatchNorm2d(width * 4)
             self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
+        # the hand-scheduled forward / backward walk these per step: plain instance attributes (nn.Module resolves `self.conv1` through
+        # __getattr__ and three dict probes -- ~1 us each, ~1 000 of them per ResNet-101 step); the module tree itself is unchanged
+        m = self._modules
+        self.__dict__["_chain"] = [(m["conv1"], m["bn1"]), (m["conv2"], m["bn2"])] + ([] if kind == "basic" else [(m["conv3"], m["bn3"])])
+        self.__dict__["_ds"] = None if downsample is None else (downsample[0], downsample[1])
 
     def chain(self):
-        if self.kind == "basic":
-            return [(self.conv1, self.bn1), (self.conv2, self.bn2)]
-        return [(self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)]
+        return self._chain
 
     def forward(self, x):
         raise SegHieroHipError("blocks run inside ResNetBackbone.forward (hand-scheduled HIP path)")
@@ -78,15 +81,15 @@ def _block_fwd(blk, x, training):
     chain = blk.chain()
     recs = []
     idt, ds_rec = x, None
-    if blk.downsample is not None:
-        dconv, dbn = blk.downsample[0], blk.downsample[1]
+    if blk._ds is not None:
+        dconv, dbn = blk._ds
         # the downsample BatchNorm is applied inside the block's final BatchNorm + add + ReLU pass (LazyAffine)
-        idt, ds_rec = L.cba_fwd(x, dconv.weight, L.conv_geom(dconv), dbn, False, training, lazy=True)
+        idt, ds_rec = L.cba_fwd(x, L.W(dconv), L.conv_geom(dconv), dbn, False, training, lazy=True)
     h = x
     for i, (conv, bn) in enumerate(chain):
         last = i == len(chain) - 1
         # inner convs hand their BatchNorm + ReLU to the next conv's loader (Lazy); the block output (+ identity) is materialised
-        h, rec = L.cba_fwd(h, conv.weight, L.conv_geom(conv), bn, True, training, residual=idt if last else None, lazy=not last)
+        h, rec = L.cba_fwd(h, L.W(conv), L.conv_geom(conv), bn, True, training, residual=idt if last else None, lazy=not last)
         recs.append(rec)
     return h, (recs, ds_rec)
 
@@ -101,25 +104,25 @@ def _block_bwd(blk, saved, dout, gm, prev_rec=None, extra=None, in32=False):
     recs, ds_rec = saved
     chain = blk.chain()
     # a strided downsample branch scatters into the input gradient with the fp32-accurate kernel: that tensor is fp32 then
-    in32 = in32 or (ds_rec is not None and blk.downsample[0].stride[0] > 1)
+    in32 = in32 or (ds_rec is not None and blk._ds[0].stride[0] > 1)
     # last conv: g = dout * relu-mask feeds BN backward AND (as dres) the identity / downsample path
     conv, bn = chain[-1]
     d, dw, dg, db, dres = L.cba_bwd(recs[-1], bn, dout, need_dx=True, want_dres=True)
-    gm.put(conv.weight, dw); gm.put(bn.weight, dg); gm.put(bn.bias, db)
+    gm.put(L.W(conv), dw); gm.put(L.W(bn), dg); gm.put(L.Bi(bn), db)
     for i in range(len(chain) - 2, -1, -1):
         conv, bn = chain[i]
         first = i == 0
         addend = dres if (first and ds_rec is None) else (extra if first else None)      # identity path summed in the dgrad epilogue
         d, dw, dg, db, _ = L.cba_bwd(recs[i], bn, d, need_dx=True, addend=addend,
                                      pack_for=prev_rec if (first and ds_rec is None) else None, dx32=first and in32)
-        gm.put(conv.weight, dw); gm.put(bn.weight, dg); gm.put(bn.bias, db)
+        gm.put(L.W(conv), dw); gm.put(L.W(bn), dg); gm.put(L.Bi(bn), db)
     if ds_rec is not None:
-        dconv, dbn = blk.downsample[0], blk.downsample[1]
+        dconv, dbn = blk._ds
         if dconv.stride[0] > 1:
             _, dw, dg, db, _ = L.cba_bwd(ds_rec, dbn, dres, scatter_into=d)          # accumulate at strided pixels
         else:
             d, dw, dg, db, _ = L.cba_bwd(ds_rec, dbn, dres, need_dx=True, addend=d, dx32=in32)
-        gm.put(dconv.weight, dw); gm.put(dbn.weight, dg); gm.put(dbn.bias, db)
+        gm.put(L.W(dconv), dw); gm.put(L.W(dbn), dg); gm.put(L.Bi(dbn), db)
     return d
 
 

@@ -18,6 +18,15 @@ def conv_geom(conv):
     return conv.stride[0], conv.padding[0], conv.dilation[0]
 
 
+def W(m):
+    """m.weight / m.bias (Bi) without nn.Module.__getattr__ (~1 us per access, several per layer and step); always the live Parameter."""
+    return m._parameters["weight"]
+
+
+def Bi(m):
+    return m._parameters["bias"]
+
+
 def to_native_layout(module):
     """Put every dense KxK conv weight of `module` into channels_last (OHWI) memory, in place.  1x1 / depthwise /
     the 3-channel stem weight are layout-neutral or handled separately.  Idempotent; call after .to(device) or
@@ -105,7 +114,8 @@ class CBARec:
 def _bn_coefs(bn, partials, count, training, c, device):
     if training:
         mom = 0.1 if bn.momentum is None else bn.momentum
-        return ops.bn_finalize(partials, count, bn.weight, bn.bias, bn.eps, mom, bn.running_mean, bn.running_var, c, device)
+        pr, bf = bn._parameters, bn._buffers
+        return ops.bn_finalize(partials, count, pr["weight"], pr["bias"], bn.eps, mom, bf["running_mean"], bf["running_var"], c, device)
     return ops.bn_eval_coefs(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
 
 
@@ -252,7 +262,7 @@ def cba_bwd(rec, bn, dout, need_dx=True, addend=None, want_dres=False, scatter_i
     # second half of the BatchNorm backward in the loaders of this conv's dgrad / wgrad (1x1 convs): no apply pass, no dy tensor
     defer = FUSE_BN and scatter_into is None and pack_for is None and ops.lin_ok(rec.x.shape, rec.weight, s, p, d)
     dy, dgamma, dbeta, dres = ops.bn_backward(dout, (rec.out if rec.mask is None else rec.mask) if mode == 1 else None, rec.y, rec.coefs,
-                                              bn.weight, mode, want_dres, defer=defer, grad32=dy32)
+                                              W(bn), mode, want_dres, defer=defer, grad32=dy32)
     dw = new_grad(rec.weight)
     if not ops.WGRAD_AFTER_DGRAD:
         _wgrad(rec.x, dy, dw, s, p, d)
@@ -303,7 +313,7 @@ def dw_bwd(rec, bn, dout, dx_accumulate_into=None):
         dout.g = ops.f32(dout.g)
     else:
         dout = ops.f32(dout)
-    dy, dgamma, dbeta, _ = ops.bn_backward(dout, None, rec.y, rec.coefs, bn.weight, 2, defer=FUSE_BN and ops.dw_lin_ok(rec.y.shape, rec.dil),
+    dy, dgamma, dbeta, _ = ops.bn_backward(dout, None, rec.y, rec.coefs, W(bn), 2, defer=FUSE_BN and ops.dw_lin_ok(rec.y.shape, rec.dil),
                                            grad32=True)
     dw = new_grad(rec.weight)
     if isinstance(rec.x, Lazy) and rec.x._out is None:

@@ -65,9 +65,19 @@ class profile:
         return False
 
 
+_STREAM = None        # explicit launch stream (raw hipStream_t) while the weight-gradient side stream is the target: see conv_wgrad
+
+
 def _st():
     # raw hipStream_t of torch's current stream on the current device (the C call: no Stream object is built per launch)
-    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+    if _STREAM is not None:
+        return _STREAM
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
+def _rp(t, k):
+    """Pointer of row k of a dense 2-D tensor (coefficient tables): `t[k].data_ptr()` without building a view per launch argument."""
+    return t.data_ptr() + k * t.stride(0) * t.element_size()
 
 
 def _require_gpu(t):
@@ -157,25 +167,29 @@ def pmx(t):
     return _pm(t, True)
 
 
+_F32, _BF16 = torch.float32, torch.bfloat16
+
+
 def _pm(t, allow_bf16):
-    _require_gpu(t)
-    if t.dim() != 4 or not (t.dtype == torch.float32 or (allow_bf16 and t.dtype == torch.bfloat16)):
+    # (hot: ~1 800 calls per ResNet-101 step -- one pass over shape / strides, no helper calls)
+    dt = t.dtype
+    if not t.is_cuda:
+        _require_gpu(t)
+    if t.dim() != 4 or not (dt is _F32 or (allow_bf16 and dt is _BF16)):
         raise SegHieroHipError(f"expected a 4-D fp32 tensor, got {tuple(t.shape)} {t.dtype}")
     n, c, h, w = t.shape
-    s = t.stride()
+    s0, s1, s2, s3 = t.stride()
     if w > 1:
-        ld = s[3]
+        ld = s3
     elif h > 1:
-        ld = s[2]
+        ld = s2
     elif n > 1:
-        ld = s[0]
+        ld = s0
     else:
         ld = c
-    ok = (c == 1 or s[1] == 1) and (w == 1 or s[3] == ld) and (h == 1 or s[2] == w * ld) and \
-        (n == 1 or s[0] == h * w * ld) and ld >= c
-    if not ok:
-        raise SegHieroHipError(f"tensor is not NHWC-strided: shape {tuple(t.shape)} strides {s}")
-    return t.data_ptr(), ld, int(t.dtype == torch.bfloat16)
+    if not ((c == 1 or s1 == 1) and (w == 1 or s3 == ld) and (h == 1 or s2 == w * ld) and (n == 1 or s0 == h * w * ld) and ld >= c):
+        raise SegHieroHipError(f"tensor is not NHWC-strided: shape {tuple(t.shape)} strides {t.stride()}")
+    return t.data_ptr(), ld, 1 if dt is _BF16 else 0
 
 
 def is_nhwc(t):
@@ -205,6 +219,8 @@ def to_nhwc(t, cpad=None):
 
 # ----------------------------------------------------------------------------- conv
 def _ckey(n, h, w, cin, o, kh, stride, dil):
+    if _PROF is None:
+        return None
     return f"{n}x{h}x{w} {cin}->{o} k{kh}" + (f" s{stride}" if stride != 1 else "") + (f" d{dil}" if dil != 1 else "")
 
 
@@ -260,7 +276,7 @@ def conv_fprop_aff(x, in_coefs, weight, bias, y, partials, stride, pad, dil):
         return True
     cost = (2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin + m * o + o * cin * kh * kw))
     ws, nb = _splitk_ws(0, n, h, w, cin, o, kh, kw, stride, pad, dil, 0, x.device)
-    return _call_fused("sh_conv_fprop_x6_aff", xp, ldx, in_coefs[2].data_ptr(), in_coefs[3].data_ptr(), w_ohwi(weight).data_ptr(),
+    return _call_fused("sh_conv_fprop_x6_aff", xp, ldx, _rp(in_coefs, 2), _rp(in_coefs, 3), w_ohwi(weight).data_ptr(),
                        None if bias is None else bias.data_ptr(), yp, ldy, None if partials is None else partials.data_ptr(),
                        n, h, w, cin, o, kh, kw, stride, pad, dil, ws, nb, xb | (yb << 1), _st(), cost=cost,
                        key=_ckey(n, h, w, cin, o, kh, stride, dil))
@@ -280,8 +296,8 @@ def _fprop_b16(x, in_coefs, weight, bias, y, partials, stride, pad, dil):
     m = n * ho * wo
     ws, nb = _splitk_ws(0, n, h, w, cin, o, kh, kw, stride, pad, dil, 0, x.device)
     wb, _ = weights_bf16(weight)
-    return _call_fused("sh_conv_fprop_b16", xp, ldx, None if in_coefs is None else in_coefs[2].data_ptr(),
-                       None if in_coefs is None else in_coefs[3].data_ptr(), wb.data_ptr(), None if bias is None else bias.data_ptr(),
+    return _call_fused("sh_conv_fprop_b16", xp, ldx, None if in_coefs is None else _rp(in_coefs, 2),
+                       None if in_coefs is None else _rp(in_coefs, 3), wb.data_ptr(), None if bias is None else bias.data_ptr(),
                        yp, ldy, None if partials is None else partials.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, ws, nb,
                        yb << 1, _st(), cost=_bcost(n, h, w, cin, o, kh, kw, m, 2, 2 if yb else 4), key=_ckey(n, h, w, cin, o, kh, stride, dil))
 
@@ -324,7 +340,7 @@ def conv_fprop_act(x, weight, coefs, out, relu, residual, stride, pad, dil):
     rp, ldr = (None, 0) if residual is None else pm(residual)
     ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
     m = n * ho * wo
-    _call("sh_conv_fprop_x6_act", xp, ldx, w_ohwi(weight).data_ptr(), coefs[2].data_ptr(), coefs[3].data_ptr(), rp, ldr,
+    _call("sh_conv_fprop_x6_act", xp, ldx, w_ohwi(weight).data_ptr(), _rp(coefs, 2), _rp(coefs, 3), rp, ldr,
           int(bool(relu)), op, ldo, n, h, w, cin, o, kh, kw, stride, pad, dil, _st(),
           cost=(2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin + m * o + o * cin * kh * kw)))
 
@@ -463,7 +479,7 @@ def _dgrad_b16(dy, weight, dx, stride, pad, dil, addend=None, lin=None, bnb=None
             flags |= opb << 4
         else:
             opp, ldop = None, 0
-        bargs = (ypp, ldyp, opp, ldop, cf[0].data_ptr(), cf[1].data_ptr(), cf[2].data_ptr(), cf[3].data_ptr(), int(bool(relu)), partials.data_ptr())
+        bargs = (ypp, ldyp, opp, ldop, _rp(cf, 0), _rp(cf, 1), _rp(cf, 2), _rp(cf, 3), int(bool(relu)), partials.data_ptr())
     ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
     m = n * ho * wo
     ws, nb = _splitk_ws(1, n, h, w, cin, o, kh, kw, stride, pad, dil, 0, dx.device)
@@ -525,7 +541,7 @@ def conv_dgrad_bnb(dy, weight, g, y_prev, coefs, relu, partials, stride, pad, di
     cost = (2.0 * m * o * cin * kh * kw, 4.0 * (n * h * w * cin * (3 if addend is not None else 2) + m * o + o * cin * kh * kw))
     ws, nb = _splitk_ws(1, n, h, w, cin, o, kh, kw, stride, pad, dil, 0, g.device)
     return _call_fused("sh_conv_dgrad_x6_bnb", dyp, lddy, weight_transpose(weight).data_ptr(), ap, lda, gp, ldg, ypp, ldyp, opp, ldop,
-                       coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(), coefs[3].data_ptr(), int(bool(relu)),
+                       _rp(coefs, 0), _rp(coefs, 1), _rp(coefs, 2), _rp(coefs, 3), int(bool(relu)),
                        partials.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, ws, nb, ypb | (opb << 1), _st(), cost=cost,
                        key=_ckey(n, h, w, cin, o, kh, stride, dil))
 
@@ -554,7 +570,7 @@ def conv_dgrad_lin(dd, weight, dx, addend=None, bnb=None):
     else:
         y_prev, cf, partials = bnb
         ypp, ldyp, ypb = pmx(y_prev)
-        bargs = (ypp, ldyp, cf[0].data_ptr(), cf[1].data_ptr(), cf[2].data_ptr(), cf[3].data_ptr(), 1, partials.data_ptr())
+        bargs = (ypp, ldyp, _rp(cf, 0), _rp(cf, 1), _rp(cf, 2), _rp(cf, 3), 1, partials.data_ptr())
     m = n * h * w
     cost = (2.0 * m * o * cin, 4.0 * (m * cin * (1 + (addend is not None) + (bnb is not None)) + 2 * m * o + o * cin))
     ws, nb = _splitk_ws(1, n, h, w, cin, o, 1, 1, 1, 0, 1, 0, dx.device)
@@ -606,6 +622,23 @@ def _wgrad_side(device):
         ent = _WgEnt(device)
         _WG_STREAMS[device.index] = ent
     return ent
+
+
+def _launch_on_side(device, launch, tagfmt, tensors):
+    """launch(tag) with the weight-gradient side stream as the launch stream of its C-ABI calls (ops._STREAM: the kernels take their
+    stream as an argument, so torch's current stream is not switched -- a `with torch.cuda.stream(...)` costs more host time than the
+    launch itself); the side stream first waits for what the compute stream has queued, and the allocator is told about the tensors."""
+    global _STREAM
+    k, st = _wgrad_side(device).take()
+    st.wait_stream(torch.cuda.current_stream(device))     # dy / x were produced on the compute stream
+    prev, _STREAM = _STREAM, st.cuda_stream
+    try:
+        launch(tagfmt % k)
+    finally:
+        _STREAM = prev
+    for t in tensors:
+        t.record_stream(st)                                 # the allocator must not recycle them under the side stream
+
 
 
 def join_wgrad():
@@ -676,13 +709,13 @@ def conv_wgrad(x, dy, dweight, stride, pad, dil, side=False, aff=None):
         ws = workspace(need, x.device, tag)              # one workspace per stream: its kernels stay in that stream's order
         if dd is not None:
             y2p, ldy2, y2b = pmx(dd.y)
-            if not _call_fused("sh_conv_wgrad_x6_lin", xp, ldx, None if aff is None else aff[2].data_ptr(), None if aff is None else aff[3].data_ptr(),
+            if not _call_fused("sh_conv_wgrad_x6_lin", xp, ldx, None if aff is None else _rp(aff, 2), None if aff is None else _rp(aff, 3),
                                dyp, lddy, y2p, ldy2, dd.lin.data_ptr(), dweight.data_ptr(), ws.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil,
                                xb | (y2b << 1), _st(), cost=cost, key=_ckey(n, h, w, cin, o, kh, stride, dil)):
                 raise SegHieroHipError("sh_conv_wgrad_x6_lin: unsupported geometry (check lin_ok before deferring the BatchNorm-backward apply)")
             return
         if aff is not None:
-            if not _call_fused("sh_conv_wgrad_x6_aff", xp, ldx, aff[2].data_ptr(), aff[3].data_ptr(), dyp, lddy, dweight.data_ptr(),
+            if not _call_fused("sh_conv_wgrad_x6_aff", xp, ldx, _rp(aff, 2), _rp(aff, 3), dyp, lddy, dweight.data_ptr(),
                                ws.data_ptr(), n, h, w, cin, o, kh, kw, stride, pad, dil, xb, _st(), cost=cost,
                                key=_ckey(n, h, w, cin, o, kh, stride, dil)):
                 raise SegHieroHipError("sh_conv_wgrad_x6_aff: unsupported geometry (check wgrad_aff_ok before deferring the activation)")
@@ -693,12 +726,7 @@ def conv_wgrad(x, dy, dweight, stride, pad, dil, side=False, aff=None):
     if not (side and WGRAD_ASYNC and x.is_cuda):
         launch()
         return
-    k, st = _wgrad_side(x.device).take()
-    st.wait_stream(torch.cuda.current_stream(x.device))     # dy / x were produced on the compute stream
-    with torch.cuda.stream(st):
-        launch("wgrad%d" % k)
-    for t in (x, dy, dweight) + (() if dd is None else (dd.y, dd.lin)):
-        t.record_stream(st)                                 # the allocator must not recycle them under the side stream
+    _launch_on_side(x.device, launch, "wgrad%d", (x, dy, dweight) + (() if dd is None else (dd.y, dd.lin)))
 
 
 def _wgrad_b16(x, dy, dweight, stride, pad, dil, side, aff):
@@ -725,19 +753,14 @@ def _wgrad_b16(x, dy, dweight, stride, pad, dil, side, aff):
 
     def launch(tag):
         ws = workspace(need, x.device, tag)
-        ok[0] = _call_fused("sh_conv_wgrad_b16", xp, ldx, None if aff is None else aff[2].data_ptr(), None if aff is None else aff[3].data_ptr(),
+        ok[0] = _call_fused("sh_conv_wgrad_b16", xp, ldx, None if aff is None else _rp(aff, 2), None if aff is None else _rp(aff, 3),
                             gp, ldg, ylp, ldyl, None if dd is None else dd.lin.data_ptr(), dweight.data_ptr(), ws.data_ptr(), n, h, w, cin, o,
                             kh, kw, stride, pad, dil, gb, _st(), cost=cost, key=_ckey(n, h, w, cin, o, kh, stride, dil))
 
     if not (side and WGRAD_ASYNC and x.is_cuda):
         launch("wgrad")
         return ok[0]
-    k, st = _wgrad_side(x.device).take()
-    st.wait_stream(torch.cuda.current_stream(x.device))
-    with torch.cuda.stream(st):
-        launch("wgrad%d" % k)
-    for t in (x, g, dweight) + (() if dd is None else (dd.y, dd.lin)):
-        t.record_stream(st)
+    _launch_on_side(x.device, launch, "wgrad%d", (x, g, dweight) + (() if dd is None else (dd.y, dd.lin)))
     return ok[0]
 
 
@@ -755,9 +778,9 @@ def dwconv_fprop(x, weight, y, partials, dil, aff=None):
     n, c, h, w = x.shape
     xp, ldx, xb = pmx(x)
     yp, ldy, yb = pmx(y)
-    _call("sh_dwconv_fprop", xp, ldx, None if aff is None else aff[2].data_ptr(), None if aff is None else aff[3].data_ptr(),
+    _call("sh_dwconv_fprop", xp, ldx, None if aff is None else _rp(aff, 2), None if aff is None else _rp(aff, 3),
           weight.data_ptr(), yp, ldy, None if partials is None else partials.data_ptr(), n, h, w, c, dil, xb | (yb << 1), _st(),
-          key=f"{n}x{h}x{w} C{c} d{dil}")
+          key=(None if _PROF is None else f"{n}x{h}x{w} C{c} d{dil}"))
 
 
 def dw_lin_ok(shape, dil):
@@ -779,7 +802,7 @@ def dwconv_dgrad(dy, weight, dx, dil, accumulate=False):
     n, c, h, w = dx.shape
     dxp, lddx = pm(dx)
     largs, yb = _lin_args(dy)
-    _call("sh_dwconv_dgrad", *largs, weight.data_ptr(), dxp, lddx, n, h, w, c, dil, int(accumulate), yb, _st(), key=f"{n}x{h}x{w} C{c} d{dil}")
+    _call("sh_dwconv_dgrad", *largs, weight.data_ptr(), dxp, lddx, n, h, w, c, dil, int(accumulate), yb, _st(), key=(None if _PROF is None else f"{n}x{h}x{w} C{c} d{dil}"))
 
 
 def dwconv_dgrad_bnb(dy, weight, g, y_prev, coefs, partials, dil):
@@ -788,8 +811,8 @@ def dwconv_dgrad_bnb(dy, weight, g, y_prev, coefs, partials, dil):
     gp, ldg = pm(g)
     ypp, ldyp, ypb = pmx(y_prev)
     largs, yb = _lin_args(dy)
-    _call("sh_dwconv_dgrad_bnb", *largs, weight.data_ptr(), gp, ldg, ypp, ldyp, coefs[0].data_ptr(), coefs[1].data_ptr(),
-          coefs[2].data_ptr(), coefs[3].data_ptr(), partials.data_ptr(), n, h, w, c, dil, yb | (ypb << 1), _st(), key=f"{n}x{h}x{w} C{c} d{dil}")
+    _call("sh_dwconv_dgrad_bnb", *largs, weight.data_ptr(), gp, ldg, ypp, ldyp, _rp(coefs, 0), _rp(coefs, 1),
+          _rp(coefs, 2), _rp(coefs, 3), partials.data_ptr(), n, h, w, c, dil, yb | (ypb << 1), _st(), key=(None if _PROF is None else f"{n}x{h}x{w} C{c} d{dil}"))
 
 
 def dwconv_wgrad(x, dy, dweight, dil, side=False, aff=None):
@@ -805,18 +828,13 @@ def dwconv_wgrad(x, dy, dweight, dil, side=False, aff=None):
 
     def launch(tag="dwwgrad"):
         ws = workspace(p * 9 * c * 4, x.device, tag)
-        _call("sh_dwconv_wgrad", xp, ldx, None if aff is None else aff[2].data_ptr(), None if aff is None else aff[3].data_ptr(),
-              *largs, ws.data_ptr(), dweight.data_ptr(), n, h, w, c, dil, xb | (yb << 1), _st(), key=f"{n}x{h}x{w} C{c} d{dil}")
+        _call("sh_dwconv_wgrad", xp, ldx, None if aff is None else _rp(aff, 2), None if aff is None else _rp(aff, 3),
+              *largs, ws.data_ptr(), dweight.data_ptr(), n, h, w, c, dil, xb | (yb << 1), _st(), key=(None if _PROF is None else f"{n}x{h}x{w} C{c} d{dil}"))
 
     if not (side and WGRAD_ASYNC and x.is_cuda):
         launch()
         return
-    k, st = _wgrad_side(x.device).take()
-    st.wait_stream(torch.cuda.current_stream(x.device))
-    with torch.cuda.stream(st):
-        launch("dwwgrad%d" % k)
-    for t in (x, dy, dweight) + (() if dd is None else (dd.y, dd.lin)):
-        t.record_stream(st)
+    _launch_on_side(x.device, launch, "dwwgrad%d", (x, dy, dweight) + (() if dd is None else (dd.y, dd.lin)))
 
 
 # ----------------------------------------------------------------------------- batch norm
@@ -847,7 +865,7 @@ def _fold_partials(partials, c, count, rows):
     if p < FOLD_MIN or partials.shape[-1] != c or not partials.is_contiguous():
         return partials, rows
     out = torch.empty((-(-p // FOLD_CHUNK), 2, c), device=partials.device, dtype=torch.float32)
-    if not _call_fused("sh_bn_fold_partials", partials.data_ptr(), p, c, float(count), rows, FOLD_CHUNK, out.data_ptr(), _st(), key=f"P{p} C{c}"):
+    if not _call_fused("sh_bn_fold_partials", partials.data_ptr(), p, c, float(count), rows, FOLD_CHUNK, out.data_ptr(), _st(), key=(None if _PROF is None else f"P{p} C{c}")):
         return partials, rows
     return out, rows * FOLD_CHUNK
 
@@ -871,7 +889,7 @@ def bn_finalize(partials, count, gamma, beta, eps, momentum, running_mean, runni
               None if beta is None else beta.data_ptr(), eps, momentum,
               None if running_mean is None else running_mean.data_ptr(),
               None if running_var is None else running_var.data_ptr(),
-              coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(), coefs[3].data_ptr(), _st())
+              _rp(coefs, 0), _rp(coefs, 1), _rp(coefs, 2), _rp(coefs, 3), _st())
         return coefs
     if not partials_ld and not partials_col:
         partials, rows = _fold_partials(partials, c, count, rows)
@@ -880,8 +898,8 @@ def bn_finalize(partials, count, gamma, beta, eps, momentum, running_mean, runni
           None if gamma is None else gamma.data_ptr(), None if beta is None else beta.data_ptr(), eps, momentum,
           None if running_mean is None else running_mean.data_ptr(),
           None if running_var is None else running_var.data_ptr(),
-          coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(), coefs[3].data_ptr(), rows, int(partials_ld), _st(),
-          key=f"P{partials.shape[0]} C{c}")
+          _rp(coefs, 0), _rp(coefs, 1), _rp(coefs, 2), _rp(coefs, 3), rows, int(partials_ld), _st(),
+          key=(None if _PROF is None else f"P{partials.shape[0]} C{c}"))
     return coefs
 
 
@@ -892,8 +910,8 @@ def bn_finalize_scaled(partials, count, dw_weight, gamma, beta, eps, momentum, r
     isy = torch.empty((c,), device=device, dtype=torch.float32)
     _call("sh_bn_finalize_scaled", partials.data_ptr(), partials.shape[0], c, float(count), dw_weight.data_ptr() + 16, 9,
           gamma.data_ptr(), beta.data_ptr(), eps, momentum, None if running_mean is None else running_mean.data_ptr(),
-          None if running_var is None else running_var.data_ptr(), coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(),
-          coefs[3].data_ptr(), isy.data_ptr(), rows, _st())
+          None if running_var is None else running_var.data_ptr(), _rp(coefs, 0), _rp(coefs, 1), _rp(coefs, 2),
+          _rp(coefs, 3), isy.data_ptr(), rows, _st())
     return coefs, isy
 
 
@@ -915,8 +933,8 @@ def bn_finalize_multi(partials, count, rows, bns, coefs_list, partials_ld=0, col
     _call("sh_bn_finalize_multi", k, partials.data_ptr(), partials.shape[0], c, float(count), rows, int(partials_ld),
           (ctypes.c_int * k)(*cols), arr([b.weight.data_ptr() for b in bns]), arr([b.bias.data_ptr() for b in bns]),
           arr([ptr(b.running_mean) for b in bns]), arr([ptr(b.running_var) for b in bns]),
-          arr([cf[0].data_ptr() for cf in coefs_list]), arr([cf[1].data_ptr() for cf in coefs_list]),
-          arr([cf[2].data_ptr() for cf in coefs_list]), arr([cf[3].data_ptr() for cf in coefs_list]),
+          arr([_rp(cf, 0) for cf in coefs_list]), arr([_rp(cf, 1) for cf in coefs_list]),
+          arr([_rp(cf, 2) for cf in coefs_list]), arr([_rp(cf, 3) for cf in coefs_list]),
           arr([None if w is None else w.data_ptr() + 16 for w in dw_weights]), 9, arr([ptr(t) for t in isy_list]),
           float(eps), float(mom), _st())
 
@@ -947,20 +965,20 @@ def conv1x1_grouped_fprop(sources, weights, y, partials):
         cost = (2.0 * n * h * w * cin * a * k, float(n * h * w * (2 * cin + (2 if yb else 4) * a) * k + 2 * a * cin * k))
         wbs = [weights_bf16(wt)[0] for wt in weights]         # (held until the launch is enqueued: copies made on demand are fresh tensors)
         return _call_fused("sh_conv1x1_grouped_fprop_b16", k, arr(xs), (ctypes.c_int * k)(*lds),
-                           arr([None if c is None else c[2].data_ptr() for _, c in sources]),
-                           arr([None if c is None else c[3].data_ptr() for _, c in sources]),
+                           arr([None if c is None else _rp(c, 2) for _, c in sources]),
+                           arr([None if c is None else _rp(c, 3) for _, c in sources]),
                            arr([t.data_ptr() for t in wbs]), yp, ldy, partials.data_ptr(), n, h, w, cin, a, yb << 1, _st(),
-                           cost=cost, key=f"{k} x ({n}x{h}x{w} {cin}->{a} k1)")
+                           cost=cost, key=(None if _PROF is None else f"{k} x ({n}x{h}x{w} {cin}->{a} k1)"))
     xs, lds = zip(*[pm(x) for x, _ in sources])
     yp, ldy = pm(y)
     vp = ctypes.c_void_p
     arr = lambda vals: (vp * k)(*vals)
     cost = (2.0 * n * h * w * cin * a * k, 4.0 * (n * h * w * (cin + a) * k + a * cin * k))
     return _call_fused("sh_conv1x1_grouped_fprop_x6", k, arr(xs), (ctypes.c_int * k)(*lds),
-                       arr([None if c is None else c[2].data_ptr() for _, c in sources]),
-                       arr([None if c is None else c[3].data_ptr() for _, c in sources]),
+                       arr([None if c is None else _rp(c, 2) for _, c in sources]),
+                       arr([None if c is None else _rp(c, 3) for _, c in sources]),
                        arr([w_ohwi(wt).data_ptr() for wt in weights]), yp, ldy, partials.data_ptr(), n, h, w, cin, a, _st(),
-                       cost=cost, key=f"{k} x ({n}x{h}x{w} {cin}->{a} k1)")
+                       cost=cost, key=(None if _PROF is None else f"{k} x ({n}x{h}x{w} {cin}->{a} k1)"))
 
 
 
@@ -968,7 +986,7 @@ def bn_eval_coefs(gamma, beta, running_mean, running_var, eps):
     c = running_mean.numel()
     coefs = torch.empty((4, c), device=running_mean.device, dtype=torch.float32)
     _call("sh_bn_eval_coefs", gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(), eps, c,
-          coefs[2].data_ptr(), coefs[3].data_ptr(), _st())
+          _rp(coefs, 2), _rp(coefs, 3), _st())
     return coefs
 
 
@@ -997,10 +1015,10 @@ def bn_act(y, coefs, out, relu, residual=None, res_coefs=None, mask=None):
     yp, ldy, yb = pmx(y)
     op, ldo, ob = pmx(out)
     rp, ldr, rb = (None, 0, 0) if residual is None else pmx(residual)
-    _call("sh_bn_act", yp, ldy, coefs[2].data_ptr(), coefs[3].data_ptr(), rp, ldr,
-          None if res_coefs is None else res_coefs[2].data_ptr(), None if res_coefs is None else res_coefs[3].data_ptr(),
+    _call("sh_bn_act", yp, ldy, _rp(coefs, 2), _rp(coefs, 3), rp, ldr,
+          None if res_coefs is None else _rp(res_coefs, 2), None if res_coefs is None else _rp(res_coefs, 3),
           op, ldo, n * h * w, c, int(relu), None if mask is None else mask.data_ptr(), yb | (rb << 1) | (ob << 2), _st(),
-          key=f"{n}x{h}x{w} C{c}" + (" +res" if residual is not None else ""))
+          key=(None if _PROF is None else f"{n}x{h}x{w} C{c}" + (" +res" if residual is not None else "")))
 
 
 class DeferredDy:
@@ -1026,9 +1044,9 @@ class DeferredDy:
             yp, ldy, yb = pmx(self.y)
             dyp, lddy = pmx(dy)[:2]
             cf = self.coefs
-            _call("sh_bn_bwd_apply", gp, ldg, None, 0, yp, ldy, cf[0].data_ptr(), cf[1].data_ptr(), cf[2].data_ptr(), cf[3].data_ptr(),
-                  None if self.gamma is None else self.gamma.data_ptr(), self.red[2].data_ptr(), self.red[3].data_ptr(), dyp, lddy,
-                  None, 0, n * h * w, c, 0, yb | (gb << 2) | (gb << 3), _st(), key=f"{n}x{h}x{w} C{c} (deferred)")
+            _call("sh_bn_bwd_apply", gp, ldg, None, 0, yp, ldy, _rp(cf, 0), _rp(cf, 1), _rp(cf, 2), _rp(cf, 3),
+                  None if self.gamma is None else self.gamma.data_ptr(), _rp(self.red, 2), _rp(self.red, 3), dyp, lddy,
+                  None, 0, n * h * w, c, 0, yb | (gb << 2) | (gb << 3), _st(), key=(None if _PROF is None else f"{n}x{h}x{w} C{c} (deferred)"))
             self._dy = dy
         return self._dy
 
@@ -1097,13 +1115,13 @@ def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None, d
         gmask = None
         if defer and relu:
             gmask = new_act(n, c, h, w, dev, dtype=gdt)
-            if not _call_fused("sh_bn_bwd_reduce", dop, lddo, op, ldo, yp, ldy, coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(),
-                               coefs[3].data_ptr(), partials.data_ptr(), m, c, relu, gmask.data_ptr(), c, af | (dob << 2) | (int(gdt == torch.bfloat16) << 3),
-                               _st(), key=f"{n}x{h}x{w} C{c} +g"):
+            if not _call_fused("sh_bn_bwd_reduce", dop, lddo, op, ldo, yp, ldy, _rp(coefs, 0), _rp(coefs, 1), _rp(coefs, 2),
+                               _rp(coefs, 3), partials.data_ptr(), m, c, relu, gmask.data_ptr(), c, af | (dob << 2) | (int(gdt == torch.bfloat16) << 3),
+                               _st(), key=(None if _PROF is None else f"{n}x{h}x{w} C{c} +g")):
                 gmask, defer = None, False
         if gmask is None:
-            _call("sh_bn_bwd_reduce", dop, lddo, op, ldo, yp, ldy, coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(),
-                  coefs[3].data_ptr(), partials.data_ptr(), m, c, relu, None, 0, af | (dob << 2), _st(), key=f"{n}x{h}x{w} C{c}")
+            _call("sh_bn_bwd_reduce", dop, lddo, op, ldo, yp, ldy, _rp(coefs, 0), _rp(coefs, 1), _rp(coefs, 2),
+                  _rp(coefs, 3), partials.data_ptr(), m, c, relu, None, 0, af | (dob << 2), _st(), key=(None if _PROF is None else f"{n}x{h}x{w} C{c}"))
         else:
             dout, relu, op, ldo = gmask, 0, None, 0          # from here on as a packed gradient: mask applied
             dop, lddo, dob = pmx(dout)
@@ -1120,14 +1138,14 @@ def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None, d
         _call("sh_bn_reduce_partials", partials.data_ptr(), p, c, float(m), 0, local.data_ptr(), _st())
         glob = _all_reduce_sq(local.clone())
         _call("sh_bn_bwd_finalize_sq", local.data_ptr(), glob.data_ptr(), c,
-              red[0].data_ptr(), red[1].data_ptr(), red[2].data_ptr(), red[3].data_ptr(),
-              None if gamma is None else gamma.data_ptr(), coefs[1].data_ptr(), coefs[0].data_ptr(), linp, _st())
+              _rp(red, 0), _rp(red, 1), _rp(red, 2), _rp(red, 3),
+              None if gamma is None else gamma.data_ptr(), _rp(coefs, 1), _rp(coefs, 0), linp, _st())
     else:
         partials, _ = _fold_partials(partials, c, m, 0)
         p = partials.shape[0]
         _call("sh_bn_bwd_finalize", partials.data_ptr(), p, c, None if gamma is None else gamma.data_ptr(),
-              coefs[1].data_ptr(), float(m), red[0].data_ptr(), red[1].data_ptr(), red[2].data_ptr(), red[3].data_ptr(),
-              coefs[0].data_ptr(), linp, _st(), key=f"P{p} C{c}")
+              _rp(coefs, 1), float(m), _rp(red, 0), _rp(red, 1), _rp(red, 2), _rp(red, 3),
+              _rp(coefs, 0), linp, _st(), key=(None if _PROF is None else f"P{p} C{c}"))
     if defer:
         # relu == 0 here: dout is the masked gradient (packed, or stored by the statistics pass), or no mask applies
         return DeferredDy(dout, y, lin, coefs, gamma, red), red[0], red[1], (dout if want_dres else None)
@@ -1139,9 +1157,9 @@ def bn_backward(dout, out, y, coefs, gamma, relu, want_dres=False, dy_ld=None, d
     dyp, lddy = pmx(dy)[:2]
     drp, lddr = (None, 0) if (dres is None or packed) else pmx(dres)[:2]
     gb = int(gdt == torch.bfloat16)
-    _call("sh_bn_bwd_apply", dop, lddo, op, ldo, yp, ldy, coefs[0].data_ptr(), coefs[1].data_ptr(), coefs[2].data_ptr(),
-          coefs[3].data_ptr(), None if gamma is None else gamma.data_ptr(), red[2].data_ptr(), red[3].data_ptr(), dyp, lddy,
-          drp, lddr, m, c, relu, af | (dob << 2) | (gb << 3) | (gb << 4), _st(), key=f"{n}x{h}x{w} C{c}" + (" +dres" if drp else ""))
+    _call("sh_bn_bwd_apply", dop, lddo, op, ldo, yp, ldy, _rp(coefs, 0), _rp(coefs, 1), _rp(coefs, 2),
+          _rp(coefs, 3), None if gamma is None else gamma.data_ptr(), _rp(red, 2), _rp(red, 3), dyp, lddy,
+          drp, lddr, m, c, relu, af | (dob << 2) | (gb << 3) | (gb << 4), _st(), key=(None if _PROF is None else f"{n}x{h}x{w} C{c}" + (" +dres" if drp else "")))
     return dy, red[0], red[1], dres
 
 
@@ -1156,7 +1174,7 @@ def maxpool_fwd(x, want_argmax=True, aff=None):
     ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
     y = new_act(n, c, ho, wo, x.device, dtype=x.dtype)                # stored like its input
     am = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.uint8) if want_argmax else None
-    _call("sh_maxpool_fwd", xp, None if aff is None else aff[2].data_ptr(), None if aff is None else aff[3].data_ptr(), y.data_ptr(),
+    _call("sh_maxpool_fwd", xp, None if aff is None else _rp(aff, 2), None if aff is None else _rp(aff, 3), y.data_ptr(),
           None if am is None else am.data_ptr(), n, h, w, c, xb | (xb << 1), _st())
     return y, am
 
@@ -1250,7 +1268,7 @@ def dense_copy(t, ld=None):
     ones[1].zero_()
     tp, ldt = pm(t)
     op, ldo = pm(out)
-    _call("sh_bn_act", tp, ldt, ones[0].data_ptr(), ones[1].data_ptr(), None, 0, None, None, op, ldo, n * h * w, c, 0, None, 0, _st())
+    _call("sh_bn_act", tp, ldt, _rp(ones, 0), _rp(ones, 1), None, 0, None, None, op, ldo, n * h * w, c, 0, None, 0, _st())
     return out
 
 

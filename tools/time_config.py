@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Step time + per-kernel breakdown of one of the BASELINE configs on the GPU (not the bench metric; a diagnosis aid).
     python tools/time_config.py C4 [batch]      C2 | C4 (R101 3-level RMI, 7/3/2) | C5 (R101 2-level 20f/5c, 1024^2)"""
+import os
 import sys
 import time
 import torch
@@ -81,6 +82,10 @@ def main():
     for k, v in sorted(prof.rows.items(), key=lambda kv: -kv[1]["ms"])[:22]:
         rate = f"{v['flops'] / v['ms'] / 1e9:7.1f} TF  {v['bytes'] / v['ms'] / 1e6:7.0f} GB/s(alg)" if v["flops"] else ""
         print(f"   {k:28s} {v['ms']:8.2f} ms  {v['calls']:5d} calls  {rate}")
+    if os.environ.get("SHAPES"):          # per (entry point, layer shape) rows whose entry-point name contains $SHAPES
+        for (nm, key), r in sorted(prof.shapes.items(), key=lambda kv: -kv[1]["ms"]):
+            if os.environ["SHAPES"] in nm or os.environ["SHAPES"] == "all":
+                print(f"      {nm:28s} {str(key):40s} x{r['calls']:<2d} {r['ms']:7.3f} ms")
 
 
 if __name__ == "__main__":
