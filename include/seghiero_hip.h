@@ -444,7 +444,9 @@ int sh_copy(void* dst, const void* src, int64_t bytes, void* stream);      /* as
  * wtb[i] = [taps][Cin][pad8(Cout)] bf16, zero padded (input-gradient operand); entries of wb / wtb may be NULL.  Host arrays of device pointers. */
 int sh_weights_to_bf16_multi(int n, const float* const* w, void* const* wb, void* const* wtb, const int* cout, const int* taps,
                              const int* cin, void* stream);
-/* act_flags bit 1: y stored as bf16 (else fp32).  in_scale / in_shift (both or neither): x read as relu(x * scale + shift). */
+/* act_flags bit 1: y stored as bf16 (else fp32).  in_scale / in_shift (both or neither): x read as relu(x * scale + shift).
+ * Cout % 8 != 0 (the classifier): ldy >= pad8(Cout), no stat_partials, bias (if any) holds pad8(Cout) floats with zeros in the padding;
+ * y's padding lanes are written (zeros). */
 int sh_conv_fprop_b16(const void* x, int ldx, const float* in_scale, const float* in_shift, const void* w_bf16, const float* bias,
                       void* y, int ldy, float* stat_partials, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                       int pad, int dil, float* workspace, int64_t workspace_bytes, int act_flags, void* stream);
@@ -453,7 +455,9 @@ int sh_conv1x1_grouped_fprop_b16(int ngroups, const void* const* x, const int* l
                                  int N, int H, int W, int Cin, int Cout, int act_flags, void* stream);
 /* act_flags: bit 0 dy is bf16 (else fp32), 1 dx stored bf16, 2 addend bf16, 3 y_prev bf16, 4 out_prev bf16, 5 out_prev = ReLU quad mask.
  * y_lin / lin (both or neither, 1x1 only, dy = the masked gradient g in bf16): operand = lin(g, y_lin) as sh_conv_dgrad_x6_lin.
- * y_prev != NULL: BatchNorm-backward epilogue as sh_conv_dgrad_x6_bnb. */
+ * y_prev != NULL: BatchNorm-backward epilogue as sh_conv_dgrad_x6_bnb.
+ * Strided convs (no hooks: y_lin, y_prev, addend NULL): stride-2 KxK runs by input-parity class; bit 6 = 1x1 strided conv whose result
+ * is ADDED to dx at the strided pixels (sh_conv_dgrad_x6's mode 1: the downsample branch joins the block input's gradient). */
 int sh_conv_dgrad_b16(const void* dy, int lddy, const void* y_lin, int ldyl, const float* lin, const void* wt_bf16, const void* addend,
                       int ldadd, void* dx, int lddx, const void* y_prev, int ldyp, const void* out_prev, int ldop, const float* mean,
                       const float* invstd, const float* scale, const float* shift, int relu, float* stat_partials, int N, int H,

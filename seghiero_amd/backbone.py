@@ -103,8 +103,10 @@ def _block_bwd(blk, saved, dout, gm, prev_rec=None, extra=None, in32=False):
     in32 (bf16 compute mode): the block's input gradient goes to an fp32-only consumer (the max-pool backward)."""
     recs, ds_rec = saved
     chain = blk.chain()
-    # a strided downsample branch scatters into the input gradient with the fp32-accurate kernel: that tensor is fp32 then
-    in32 = in32 or (ds_rec is not None and blk._ds[0].stride[0] > 1)
+    # a strided downsample branch scatters into the input gradient: where only the fp32-accurate kernel takes it, that tensor is fp32
+    if ds_rec is not None and blk._ds[0].stride[0] > 1:
+        dc = blk._ds[0]
+        in32 = in32 or not ops.strided_dgrad_b16_ok(L.W(dc), dc.in_channels, dc.stride[0], dc.padding[0], dc.dilation[0], True)
     # last conv: g = dout * relu-mask feeds BN backward AND (as dres) the identity / downsample path
     conv, bn = chain[-1]
     d, dw, dg, db, dres = L.cba_bwd(recs[-1], bn, dout, need_dx=True, want_dres=True)

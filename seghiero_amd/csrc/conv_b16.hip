@@ -74,10 +74,14 @@ __device__ __forceinline__ F8 quad_mask_load8(const void* base, long long byte_i
 // registers per wave (<= 128 VGPRs), so two blocks = 16 waves per CU, four per SIMD.  Measured on the 512 -> 512 pointwise conv at 128^2
 // (PMC, 4 waves): the matrix pipe busy 25 %, each wave spends 1,680 VALU instructions on its prologue / epilogue against 128 MFMAs, and
 // with two waves per SIMD nothing covers a wave that sits in its epilogue or waits for its first loads.
-template <int MODE, int TN, int AFF, int EPI, int SK, int TAP, int GRP, int A32, int W8 = 0>
+// RM (input gradients of strided convs, plain epilogue): 1 = stride-2 KxK by input-parity class (blockIdx.y = class: an input pixel only sees
+// the taps of its parity, conv_x6p_kernel's plan), 2 = 1x1 strided conv: the GEMM runs on the Ho x Wo grid and its rows are ADDED to the
+// rows of dx at the strided pixels (the downsample branch's gradient joins the block input's gradient)
+template <int MODE, int TN, int AFF, int EPI, int SK, int TAP, int GRP, int A32, int W8 = 0, int RM = 0>
 __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void conv_b16_kernel(const ConvQ p) {
     constexpr int TM = 2, WGN = W8 ? 4 : 2, TNW = W8 ? 1 : TN, NT = 128 * WGN, BM = 128, BN = 32 * TNW * WGN;
     static_assert(!W8 || TN == 2, "the eight-wave form is the 128 x 128 tile");
+    static_assert(!RM || (MODE == DGRAD && AFF == 0 && EPI == 0 && !SK && !GRP && !W8 && TAP == (RM == 1 ? 1 : 0)), "row maps: plain strided input gradients");
     constexpr int A_BUF = BM * 128, B_BUF = BN * 128;                // bytes per LDS buffer
     constexpr int RPP = NT / 8, NA = BM / RPP, NB = BN / RPP;        // loader: 8 lanes x 16 bytes per row, NT / 8 rows per pass
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -101,7 +105,16 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void conv_b16_kernel(co
     const float* const sc_ptr = GRP ? p.gsc[grp] : p.aff_scale;
     const float* const sh_ptr = GRP ? p.gsh[grp] : p.aff_shift;
     const float aff_floor = (GRP && sc_ptr == nullptr) ? -INFINITY : 0.f;
-    const int Mc = p.M, Kt = p.K;
+    int Mc = p.M, Kt = p.K;
+    [[maybe_unused]] int cy = 0, cx = 0, oy0 = 0, ox0 = 0, Hc = p.H, Wc = p.W, ntw = p.KW;
+    if constexpr (RM == 1) {
+        cy = blockIdx.y >> 1; cx = blockIdx.y & 1;
+        oy0 = (cy + p.pad) & 1; ox0 = (cx + p.pad) & 1;
+        Hc = (p.H - oy0 + 1) >> 1; Wc = (p.W - ox0 + 1) >> 1;
+        ntw = (p.KW - cx + 1) >> 1;
+        Mc = p.N * Hc * Wc; Kt = ((p.KH - cy + 1) >> 1) * ntw * p.Kc;
+        if (m0 >= Mc) return;                                    // block-uniform, before any barrier
+    }
     int q_begin = 0, q_end = (Kt + 63) >> 6;                         // tiles of K = 64
     if constexpr (SK) {
         const int per = (q_end + p.ksplit - 1) / p.ksplit;
@@ -121,6 +134,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void conv_b16_kernel(co
     int b_row[NB];
     unsigned b_ok[NB];
     int cur_tap = -1;
+    [[maybe_unused]] int cur_wtap = 0;                           // RM == 1: the tap's index in the weight tensor
     // 1x1, stride 1, no padding (every pointwise conv of the model): pixel m of the output is row m of the operand -- no coordinate
     // arithmetic (eight integer divisions per thread otherwise: ~300 VALU instructions of a kernel that issues 128 MFMAs per wave)
     const bool direct = TAP == 0 && p.stride == 1 && p.pad == 0;
@@ -132,6 +146,9 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void conv_b16_kernel(co
             if constexpr (MODE == FPROP) {
                 const int ow = m % p.Wo, q = m / p.Wo, oh = q % p.Ho, n = q / p.Ho;
                 a_y[i] = oh * p.stride - p.pad; a_x[i] = ow * p.stride - p.pad; a_nb[i] = n * p.H * p.W;
+            } else if constexpr (RM == 1) {
+                const int iwc = m % Wc, q = m / Wc, ihc = q % Hc, n = q / Hc;
+                a_y[i] = 2 * ihc + oy0 + p.pad; a_x[i] = 2 * iwc + ox0 + p.pad; a_nb[i] = n * p.Ho * p.Wo;
             } else {
                 const int iw = m % p.W, q = m / p.W, ih = q % p.H, n = q / p.H;
                 a_y[i] = ih + p.pad; a_x[i] = iw + p.pad; a_nb[i] = n * p.Ho * p.Wo;
@@ -157,10 +174,16 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void conv_b16_kernel(co
             }
             return;
         }
-        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        int kh = tap / p.KW, kw = tap - kh * p.KW;
+        if constexpr (RM == 1) { const int ty = tap / ntw; kh = cy + 2 * ty; kw = cx + 2 * (tap - ty * ntw); cur_wtap = kh * p.KW + kw; }
         const int dh = kh * p.dil, dw = kw * p.dil;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
+            if constexpr (RM == 1) {                             // a_y - kh is even by construction of the class (dil == 1, host check)
+                const int t2h = a_y[i] - dh, t2w = a_x[i] - dw, th = t2h >> 1, tw = t2w >> 1;
+                a_ok[i] = (t2h >= 0 && t2w >= 0 && th < p.Ho && tw < p.Wo) ? ~0u : 0u;
+                a_off[i] = (a_nb[i] + th * p.Wo + tw) * lda;
+            } else
             if constexpr (MODE == FPROP) {
                 const int ih = a_y[i] + dh, iw = a_x[i] + dw;
                 a_ok[i] = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? ~0u : 0u;
@@ -210,7 +233,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void conv_b16_kernel(co
         for (int i = 0; i < NB; ++i) {
             int off;
             if constexpr (MODE == FPROP) off = b_row[i] + k;
-            else off = tap * p.Cin * p.Kc + b_row[i] + cc;
+            else off = (RM == 1 ? cur_wtap : tap) * p.Cin * p.Kc + b_row[i] + cc;
             const unsigned okb = kok & b_ok[i];
             const unsigned voff = (((unsigned)off * 2u) & okb) | (OOB & ~okb);
             R.b[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, voff, 0, 0));
@@ -363,6 +386,16 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void conv_b16_kernel(co
         if constexpr (EPI == 2) { if (nokv) { v_mu = ld8(p.bnb_mean, ncv, 0); v_is = ld8(p.bnb_invstd, ncv, 0); v_sc = ld8(p.bnb_scale, ncv, 0); v_sh = ld8(p.bnb_shift, ncv, 0); } }
         [[maybe_unused]] F8 pend_gs = f8_zero(), pend_gq = f8_zero();
         const int out_bf = MODE == FPROP ? (p.act & 2) : (p.act & B16_OUT_BF);
+        // GEMM row -> row of the output tensor (and of the addend: with RM == 2 that is the output itself)
+        auto orow = [&](long long m) -> long long {
+            if constexpr (RM == 1) {
+                const int mi = (int)m, iwc = mi % Wc, q = mi / Wc, ihc = q % Hc, nb = q / Hc;
+                return ((long long)nb * p.H + 2 * ihc + oy0) * p.W + 2 * iwc + ox0;
+            } else if constexpr (RM == 2) {
+                const int mi = (int)m, ow = mi % p.W, q = mi / p.W, oh = q % p.H, nb = q / p.H;
+                return ((long long)nb * p.sH + oh * p.sstride) * p.sW + ow * p.sstride;
+            } else return m;
+        };
         // Input-gradient epilogues whose tensors are all bf16 (the bf16-gradient step): every load of the wave's 64 x 64 tile -- addend, the
         // BatchNorm-backward y tile, the ReLU quad mask -- is issued up front into the registers the staging sets no longer need (16-byte
         // raw words, widened when used): ONE memory round trip per wave instead of one per two row groups (measured on the 1024 -> 256
@@ -387,7 +420,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void conv_b16_kernel(co
                     const long long m = m0 + wm * 64 + 32 * (q / NRD) + (q % NRD) * RPI + rr;
                     const bool ok = m < Mc && nokv;
                     rad[q] = u32x4{0u, 0u, 0u, 0u};
-                    if (ok && has_add) rad[q] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(p.extra) + m * p.ldadd + ncv);
+                    if (ok && has_add) rad[q] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(p.extra) + (RM ? orow(m) : m) * p.ldadd + ncv);
                     if constexpr (EPI == 2) {
                         ryv[q] = u32x4{0u, 0u, 0u, 0u}; rmk[q] = 0xffffu;
                         if (ok) {
@@ -435,7 +468,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void conv_b16_kernel(co
                                 gs.lo += o.lo; gs.hi += o.hi;
                                 gq.lo += o.lo * ((y8.lo - v_mu.lo) * v_is.lo); gq.hi += o.hi * ((y8.hi - v_mu.hi) * v_is.hi);
                             }
-                            st8(p.c, m * p.ldc + ncv, o, 1);
+                            st8(p.c, (RM ? orow(m) : m) * p.ldc + ncv, o, 1);
                         }
                     }
                     if constexpr (EPI == 2) {
@@ -483,7 +516,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void conv_b16_kernel(co
                     if constexpr (MODE == DGRAD) {
                         ad[kk] = f8_zero();
                         if (mrow[kk] < Mc && nokv) {
-                            if (p.extra != nullptr) ad[kk] = ld8(p.extra, mrow[kk] * p.ldadd + ncv, p.act & B16_ADD_BF);
+                            if (p.extra != nullptr) ad[kk] = ld8(p.extra, (RM ? orow(mrow[kk]) : mrow[kk]) * p.ldadd + ncv, p.act & B16_ADD_BF);
                             if constexpr (EPI == 2) {
                                 yv[kk] = ld8(p.bnb_y, mrow[kk] * p.bnb_ldy + ncv, p.act & 4);
                                 if (p.bnb_out != nullptr)
@@ -511,7 +544,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void conv_b16_kernel(co
                                 gq.lo += o.lo * ((yv[kk].lo - v_mu.lo) * v_is.lo); gq.hi += o.hi * ((yv[kk].hi - v_mu.hi) * v_is.hi);
                             }
                         }
-                        st8(p.c, mrow[kk] * p.ldc + ncv, o, out_bf);
+                        st8(p.c, (RM ? orow(mrow[kk]) : mrow[kk]) * p.ldc + ncv, o, out_bf);
                     }
                 }
             }
@@ -573,11 +606,11 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void conv_b16_kernel(co
 
 // ---------------------------------------------------------------------------------------- host side
 static int b16_w8() { static int v = -2; if (v == -2) { const char* e = getenv("SEGHIERO_B16_W8"); v = e ? atoi(e) : 1; } return v; }
-template <int MODE, int TN, int AFF, int EPI, int SK, int TAP, int GRP, int A32, int W8 = 0>
+template <int MODE, int TN, int AFF, int EPI, int SK, int TAP, int GRP, int A32, int W8 = 0, int RM = 0>
 static int launch_b16(ConvQ& p, hipStream_t st) {
     // (the lin loader needs more than the 128 registers of the eight-wave form; the input gradient's eight-wave form has the all-bf16
     // epilogue only)
-    if constexpr (TN == 2 && !W8 && !A32 && AFF != 2) {
+    if constexpr (TN == 2 && !W8 && !A32 && AFF != 2 && !RM) {
         bool ok8 = b16_w8() != 0;
         // input gradients: opt-in (SEGHIERO_B16_W8=2).  Measured on the configs[4] step, same box, alternating rounds of 20 steps: the
         // four-wave form 27.16 / 27.06 / 27.39 / 27.13 ms, the eight-wave form 27.64 / 35.07 / 29.03 / 26.80 ms -- sixteen 128-register waves
@@ -594,14 +627,14 @@ static int launch_b16(ConvQ& p, hipStream_t st) {
     if (lds > 160 * 1024) return SH_X6P_NO;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b16_kernel<MODE, TN, AFF, EPI, SK, TAP, GRP, A32, W8>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b16_kernel<MODE, TN, AFF, EPI, SK, TAP, GRP, A32, W8, RM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         attr_done = true;
     }
-    p.tiles_m = (int)sh_cdiv(p.M, BM);
+    p.tiles_m = (int)sh_cdiv(p.M, BM);                      // (RM == 1: p.M is the largest parity class)
     p.tiles_n = (int)sh_cdiv(p.Nn, BN);
-    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), SK ? (unsigned)p.ksplit : 1u);
-    conv_b16_kernel<MODE, TN, AFF, EPI, SK, TAP, GRP, A32, W8><<<grid, W8 ? 512 : 256, lds, st>>>(p);
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), RM == 1 ? 4u : (SK ? (unsigned)p.ksplit : 1u));
+    conv_b16_kernel<MODE, TN, AFF, EPI, SK, TAP, GRP, A32, W8, RM><<<grid, W8 ? 512 : 256, lds, st>>>(p);
     return sh_launch_status();
 }
 template <int MODE, int AFF, int EPI, int A32>
@@ -626,7 +659,10 @@ static int pick_b16(ConvQ& p, hipStream_t st) {
 int sh_b16_launch(int mode, ConvQ& p, int a32, hipStream_t st) {
     const bool aff = p.aff_scale != nullptr, bnb = p.bnb_y != nullptr, lin = p.lin != nullptr;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-    if ((p.Kc & 7) || (p.lda & 7) || !al16(p.a) || !al16(p.b) || p.parity || p.scatter || (p.stride != 1 && mode == DGRAD)) return SH_X6P_NO;
+    if ((p.Kc & 7) || (p.lda & 7) || !al16(p.a) || !al16(p.b)) return SH_X6P_NO;
+    const int rm = p.parity ? 1 : p.scatter ? 2 : 0;
+    if (rm && (mode != DGRAD || aff || bnb || lin || p.ksplit > 1)) return SH_X6P_NO;
+    if (!rm && p.stride != 1 && mode == DGRAD) return SH_X6P_NO;
     if (a32 && ((p.lda & 3) != 0)) return SH_X6P_NO;
     const int obf = mode == FPROP ? (p.act & 2) : (p.act & B16_OUT_BF);
     // the epilogue moves 8 columns per lane: 16-byte rows of bf16 tensors, 2 x 16 bytes of fp32 ones
@@ -648,6 +684,18 @@ int sh_b16_launch(int mode, ConvQ& p, int a32, hipStream_t st) {
         return aff ? pick_b16<FPROP, 1, 1, 0>(p, st) : pick_b16<FPROP, 0, 1, 0>(p, st);
     }
     if (aff) return SH_EINVAL;
+    if (rm == 1) {                // stride-2 KxK by parity class: no addend, whole K = 64 tiles per tap
+        if (p.extra != nullptr || p.dil != 1 || p.KH * p.KW == 1 || (p.Kc & 63)) return SH_X6P_NO;
+        if (p.Nn > 64) return a32 ? launch_b16<DGRAD, 2, 0, 0, 0, 1, 0, 1, 0, 1>(p, st) : launch_b16<DGRAD, 2, 0, 0, 0, 1, 0, 0, 0, 1>(p, st);
+        return a32 ? launch_b16<DGRAD, 1, 0, 0, 0, 1, 0, 1, 0, 1>(p, st) : launch_b16<DGRAD, 1, 0, 0, 0, 1, 0, 0, 0, 1>(p, st);
+    }
+    if (rm == 2) {                // 1x1 strided conv: rows of the Ho x Wo GEMM are added to dx's rows at the strided pixels
+        if (p.extra != nullptr || p.KH * p.KW != 1) return SH_X6P_NO;
+        p.extra = p.c; p.ldadd = p.ldc;
+        p.act = (p.act & ~B16_ADD_BF) | ((p.act & B16_OUT_BF) ? B16_ADD_BF : 0);
+        if (p.Nn > 64) return a32 ? launch_b16<DGRAD, 2, 0, 0, 0, 0, 0, 1, 0, 2>(p, st) : launch_b16<DGRAD, 2, 0, 0, 0, 0, 0, 0, 0, 2>(p, st);
+        return a32 ? launch_b16<DGRAD, 1, 0, 0, 0, 0, 0, 1, 0, 2>(p, st) : launch_b16<DGRAD, 1, 0, 0, 0, 0, 0, 0, 0, 2>(p, st);
+    }
     if (a32) {
         if (lin) return SH_X6P_NO;                                // lin(g, y): g is a bf16 tensor in this mode
         return bnb ? pick_b16<DGRAD, 0, 2, 1>(p, st) : pick_b16<DGRAD, 0, 0, 1>(p, st);
@@ -706,7 +754,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_b16_kernel(const
     const int brc = t % BCPR, bk0 = t / BCPR;
     const int co = m0 + 8 * arc;
     const int nn = n0 + 8 * brc;
-    const unsigned a_col_ok = co < p.M ? ~0u : 0u, b_col_ok = nn < p.Nn ? ~0u : 0u;       // M, Nn multiples of 8 on this path
+    const unsigned a_col_ok = co < p.M ? ~0u : 0u, b_col_ok = nn < p.Nn ? ~0u : 0u;       // Nn a multiple of 8; M: rows of pad8(M), zero padding
     const int tap = nn / p.Cin, wg_ci = nn - tap * p.Cin;
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
     const int wg_dh = kh * p.dil - p.pad, wg_dw = kw * p.dil - p.pad;
@@ -931,7 +979,8 @@ static int pick_wgrad_b16_src(ConvQ& p, int dy32, bool one, int wgm, int wgn, in
 int sh_b16_wgrad_launch(ConvQ& p, int dy32, int wgm, int wgn, int splits, hipStream_t st) {
     const bool aff = p.aff_scale != nullptr, lin = p.lin != nullptr;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-    if ((p.M & 7) || (p.Cin & 7) || (p.lda & 7) || (p.ldb & 7) || !al16(p.a) || !al16(p.b)) return SH_X6P_NO;
+    // (M = Cout need not be a multiple of 8: the caller guarantees dy rows of pad8(Cout) with zeroed padding lanes -- sh_conv_wgrad_b16)
+    if ((lin && (p.M & 7)) || (p.Cin & 7) || (p.lda & 7) || (p.ldb & 7) || !al16(p.a) || !al16(p.b)) return SH_X6P_NO;
     if (lin && ((p.lda2 & 7) || !al16(p.a2))) return SH_X6P_NO;
     const bool one = p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0;
     if (!one && (64 / p.Wo + 1 >= p.Ho)) return SH_X6P_NO;          // the 64-pixel coordinate step carries at most one image boundary

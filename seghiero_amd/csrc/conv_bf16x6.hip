@@ -1413,9 +1413,13 @@ extern "C" int sh_conv_fprop_b16(const void* x, int ldx, const float* in_scale, 
     if (!x || !w_bf16 || !y || !geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil) || (act_flags & ~2)) return SH_EINVAL;
     if ((in_scale == nullptr) != (in_shift == nullptr) || (((uintptr_t)in_scale | (uintptr_t)in_shift) & 15)) return SH_EINVAL;
     if (ldx < Cin || ldy < Cout) return SH_EINVAL;
+    // Cout % 8 != 0 (the classifier): the tile's columns run to pad8(Cout) -- the weight rows beyond Cout lie past the operand's extent and
+    // read as zeros, so y's padding lanes receive bias[c] (the caller's bias then holds pad8(Cout) floats, zeros in the padding)
+    const int CoutP8 = (Cout + 7) & ~7;
+    if ((Cout & 7) && (stat_partials || ldy < CoutP8)) return SH_EUNSUPPORTED;
     p.act = 1 | (act_flags & 2);
     p.a = (const float*)x; p.b = (const float*)w_bf16; p.c = (float*)y; p.extra = bias; p.partials = stat_partials; p.lda = ldx; p.ldc = ldy;
-    p.M = N * p.Ho * p.Wo; p.Nn = Cout; p.K = KH * KW * Cin; p.Kc = Cin;
+    p.M = N * p.Ho * p.Wo; p.Nn = CoutP8; p.K = KH * KW * Cin; p.Kc = Cin;
     p.n_partials = (int)sh_cdiv(p.M, 64);
     p.aff_scale = in_scale; p.aff_shift = in_shift;
     if ((ldy & 3) == 0 && ((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0)) use_splitk(p, workspace, workspace_bytes, 1);
@@ -1455,25 +1459,41 @@ extern "C" int sh_conv1x1_grouped_fprop_b16(int ngroups, const void* const* x, c
 //   y_lin / lin (1x1 convs) it is the masked gradient g (bf16 only) and the operand is lin(g, y_lin) as sh_conv_dgrad_x6_lin;
 //   wt_bf16: sh_weights_to_bf16_multi's transposed copy; addend (bit 2: bf16) summed into the result; dx stored bf16 (bit 1) or fp32;
 //   y_prev != NULL: BatchNorm-backward epilogue as sh_conv_dgrad_x6_bnb (bit 3: y_prev bf16, bit 4: out_prev bf16, bit 5: out_prev is the
-//   ReLU quad mask).  Stride-1 geometries; SH_EUNSUPPORTED: run the fp32-accurate entry point.
+//   ReLU quad mask).  Strided geometries without hooks: stride-2 KxK (input-parity classes), and -- act_flags bit 6 -- 1x1 strided convs
+//   whose result is ADDED to dx at the strided pixels (sh_conv_dgrad_x6's mode 1).  SH_EUNSUPPORTED: run the fp32-accurate entry point.
 extern "C" int sh_conv_dgrad_b16(const void* dy, int lddy, const void* y_lin, int ldyl, const float* lin, const void* wt_bf16, const void* addend,
                                  int ldadd, void* dx, int lddx, const void* y_prev, int ldyp, const void* out_prev, int ldop, const float* mean,
                                  const float* invstd, const float* scale, const float* shift, int relu, float* stat_partials, int N, int H,
                                  int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, float* workspace,
                                  int64_t workspace_bytes, int act_flags, void* stream) {
     ConvQ p{};
-    if (!dy || !wt_bf16 || !dx || !geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil) || (act_flags & ~63)) return SH_EINVAL;
+    if (!dy || !wt_bf16 || !dx || !geom(p, N, H, W, Cin, Cout, KH, KW, stride, pad, dil) || (act_flags & ~127)) return SH_EINVAL;
     const int CoutP = (Cout + 7) & ~7;
-    const bool dy_bf = act_flags & 1, qmask = (act_flags & 32) != 0;
+    const bool dy_bf = act_flags & 1, qmask = (act_flags & 32) != 0, scatter = (act_flags & 64) != 0;
     if (lddy < CoutP || lddx < Cin || (addend && ldadd < Cin)) return SH_EINVAL;
     if ((y_lin == nullptr) != (lin == nullptr) || (y_lin && (ldyl < Cout || KH * KW != 1))) return SH_EINVAL;
     if (y_prev && (!mean || !invstd || !scale || !shift || !stat_partials || ldyp < Cin)) return SH_EINVAL;
     if (out_prev && (!y_prev || (qmask ? ldop * 4 : ldop) < Cin || (qmask && (Cin & 3)))) return SH_EINVAL;
-    if (stride != 1 || (y_lin && !dy_bf)) return SH_EUNSUPPORTED;
+    if (y_lin && !dy_bf) return SH_EUNSUPPORTED;
+    const bool hooks = y_lin || y_prev || addend;
+    if (scatter) {               // 1x1 strided conv (the downsample branch): the result is ADDED to dx at the strided pixels
+        if (KH != 1 || KW != 1 || pad != 0 || hooks) return SH_EINVAL;
+    } else if (stride != 1) {    // stride-2 KxK: by input-parity class, plain epilogue
+        if (stride != 2 || dil != 1 || KH * KW == 1 || hooks) return SH_EUNSUPPORTED;
+    }
     p.act = (y_lin ? 16 : 0) | ((act_flags & 2) ? 128 : 0) | ((act_flags & 4) ? 256 : 0) | ((act_flags & 8) ? 4 : 0) | ((act_flags & 16) ? 8 : 0) | (qmask ? 64 : 0);
     p.a = (const float*)dy; p.lda = lddy; p.a2 = (const float*)y_lin; p.lda2 = ldyl; p.lin = lin;
     p.b = (const float*)wt_bf16; p.c = (float*)dx; p.extra = (const float*)addend; p.ldadd = ldadd; p.ldc = lddx;
     p.Nn = Cin; p.Kc = CoutP; p.K = KH * KW * CoutP; p.M = N * H * W;
+    const long long dy_rows = (long long)N * p.Ho * p.Wo;
+    if (scatter) {
+        p.scatter = 1; p.sH = H; p.sW = W; p.sstride = stride;
+        p.H = p.Ho; p.W = p.Wo; p.stride = 1;
+        p.M = N * p.Ho * p.Wo;
+    } else if (stride == 2) {
+        p.parity = 1;
+        p.M = N * ((H + 1) / 2) * ((W + 1) / 2);        // tiles over the largest class
+    }
     bool al = (lddx & 3) == 0 && ((uintptr_t)dx & 15) == 0 && (!addend || ((ldadd & 3) == 0 && ((uintptr_t)addend & 15) == 0));
     if (y_prev) {
         p.partials = stat_partials; p.n_partials = (int)sh_cdiv(p.M, 64);
@@ -1483,7 +1503,7 @@ extern "C" int sh_conv_dgrad_b16(const void* dy, int lddy, const void* y_lin, in
              (!out_prev || qmask || ((ldop & 3) == 0 && ((uintptr_t)out_prev & 15) == 0));
     }
     if (al) use_splitk(p, workspace, workspace_bytes, 1);
-    const long long a = ((long long)N * p.Ho * p.Wo - 1) * lddy + CoutP, b = (long long)KH * KW * Cin * CoutP;
+    const long long a = (dy_rows - 1) * lddy + CoutP, b = (long long)KH * KW * Cin * CoutP;
     if (a * 4 >= (1ll << 31) || b * 2 >= (1ll << 31)) return SH_EUNSUPPORTED;
     p.a_bytes = (unsigned)(a * (dy_bf ? 2 : 4)); p.b_bytes = (unsigned)(b * 2);
     if (y_lin) {
@@ -1506,7 +1526,8 @@ extern "C" int sh_conv_wgrad_b16(const void* x, int ldx, const float* in_scale, 
     if ((y_lin == nullptr) != (lin == nullptr) || (y_lin && ldyl < Cout)) return SH_EINVAL;
     if (lddy < Cout || ldx < Cin) return SH_EINVAL;
     const bool dy_bf = act_flags & 1;
-    if ((Cout & 7) || (y_lin && !dy_bf) || ((uintptr_t)dw & 15)) return SH_EUNSUPPORTED;
+    const int CoutP8 = (Cout + 7) & ~7;                    // the loader reads 8 channels of dy at a time: rows of pad8(Cout), padding lanes zero
+    if (lddy < CoutP8 || (y_lin && ((Cout & 7) || !dy_bf)) || ((uintptr_t)dw & 15)) return SH_EUNSUPPORTED;
     p.a = (const float*)dy; p.b = (const float*)x; p.c = workspace; p.lda = lddy; p.ldb = ldx;
     p.M = Cout; p.Nn = KH * KW * Cin; p.K = N * p.Ho * p.Wo;
     p.aff_scale = in_scale; p.aff_shift = in_shift;
@@ -1522,7 +1543,7 @@ extern "C" int sh_conv_wgrad_b16(const void* x, int ldx, const float* in_scale, 
     p.kchunk = g.kchunk;
     p.scatter = g.per_xcd;
     hipStream_t st = (hipStream_t)stream;
-    const long long ab = ((long long)p.K - 1) * lddy + Cout, bb = ((long long)N * H * W - 1) * ldx + Cin;
+    const long long ab = ((long long)p.K - 1) * lddy + CoutP8, bb = ((long long)N * H * W - 1) * ldx + Cin;
     if (ab * 4 >= (1ll << 31) || bb * 2 >= (1ll << 31)) return SH_EUNSUPPORTED;
     p.a_bytes = (unsigned)(ab * (dy_bf ? 2 : 4)); p.b_bytes = (unsigned)(bb * 2);
     int rc = sh_b16_wgrad_launch(p, dy_bf ? 0 : 1, g.wgm, g.wgn, g.splits, st);

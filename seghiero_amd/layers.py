@@ -253,9 +253,10 @@ def cba_bwd(rec, bn, dout, need_dx=True, addend=None, want_dres=False, scatter_i
     `scatter_into` (1x1 strided convs) accumulates the result into an existing dx instead.  dx32: dx goes to an fp32-only consumer."""
     s, p, d = rec.geom
     # bf16 compute mode: dy (the gradient w.r.t. this conv's raw output) is stored like that output, except where its consumers are
-    # the fp32-accurate kernels: strided input gradients (parity classes / scatter) and convs whose input is an fp32 tensor
+    # the fp32-accurate kernels: convs whose input is an fp32 tensor, and strided input gradients the one-product kernel does not take
     xin = rec.x.y if isinstance(rec.x, Lazy) else rec.x
-    dy32 = s > 1 or scatter_into is not None or xin.dtype == torch.float32
+    strided = s > 1 or scatter_into is not None
+    dy32 = xin.dtype == torch.float32 or (strided and not ops.strided_dgrad_b16_ok(rec.weight, xin.shape[1], s, p, d, scatter_into is not None))
     # ReLU mask: from `out` only where a residual was added; otherwise recomputed from y (one activation read less).
     # dout may be a GradPack (mask applied, statistics partials done by the consumer's dgrad epilogue).
     mode = 0 if not rec.relu else (1 if rec.has_res else 2)
@@ -342,7 +343,7 @@ def conv_fwd(x, weight, bias, geom):
     n, _, h, w = x.shape
     o, _, kh, kw = weight.shape
     ho, wo = ops.conv_out_hw(h, w, kh, kw, s, p, d)
-    ld = ops.pad4(o)
+    ld = ops.pad8(o) if ops.b16() else ops.pad4(o)          # bf16 compute mode: the one-product kernels move 8 columns per lane
     y = ops.new_act(n, o, ho, wo, x.device, ld=ld, zero=ld != o)
     _fprop(x, weight, bias, y, None, s, p, d)
     return y
@@ -363,9 +364,10 @@ def grad_as_nhwc_padded(g, c):
     """Incoming autograd gradient -> NHWC tensor whose pixel stride is a multiple of 4 with zeroed padding."""
     g = ops.to_nhwc(g)
     ld = ops.pm(g)[1]
-    if ld == c and c % 4 == 0:
+    q = 8 if ops.b16() else 4                       # bf16 compute mode: rows of pad8(c) for the one-product kernels' 8-channel loads
+    if ld == c and c % q == 0:
         return g
-    return ops.dense_copy(g, ld=ops.pad4(c))
+    return ops.dense_copy(g, ld=ops.pad8(c) if q == 8 else ops.pad4(c))
 
 
 class GradMap:

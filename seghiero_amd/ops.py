@@ -294,6 +294,12 @@ def _fprop_b16(x, in_coefs, weight, bias, y, partials, stride, pad, dil):
     yp, ldy, yb = pmx(y)
     ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
     m = n * ho * wo
+    if o % 8:
+        # the classifier: columns to pad8(o) (see sh_conv_fprop_b16) -- a padded row stride, no statistics, the bias zero-padded
+        if ldy < pad8(o) or partials is not None:
+            return False
+        if bias is not None:
+            bias = torch.cat([bias.detach(), bias.new_zeros(pad8(o) - o)])
     ws, nb = _splitk_ws(0, n, h, w, cin, o, kh, kw, stride, pad, dil, 0, x.device)
     wb, _ = weights_bf16(weight)
     return _call_fused("sh_conv_fprop_b16", xp, ldx, None if in_coefs is None else _rp(in_coefs, 2),
@@ -449,17 +455,20 @@ def weights_bf16(weight):
     return item[1], item[2]
 
 
-def _dgrad_b16(dy, weight, dx, stride, pad, dil, addend=None, lin=None, bnb=None):
+def _dgrad_b16(dy, weight, dx, stride, pad, dil, addend=None, lin=None, bnb=None, scatter=False):
     """bf16 compute mode input gradient.  dy: fp32 or bf16 tensor (lin = (y, lin coefficients): dy is the masked gradient g, bf16);
-    bnb = (y_prev, coefs, relu, partials, out_prev or None): BatchNorm-backward epilogue.  False = no instantiation."""
+    bnb = (y_prev, coefs, relu, partials, out_prev or None): BatchNorm-backward epilogue.  Strided convs (no hooks): stride-2 KxK, and
+    scatter=True -- a 1x1 strided conv whose result is added to dx at the strided pixels.  False = no instantiation."""
     n, cin, h, w = dx.shape
     o, _, kh, kw = weight.shape
     dyp, lddy, dyb = pmx(dy)
-    if lddy < pad8(o) or stride != 1:
+    if lddy < pad8(o):
+        return False
+    if (stride != 1 or scatter) and (addend is not None or lin is not None or bnb is not None):
         return False
     dxp, lddx, dxb = pmx(dx)
     ap, lda, ab = (None, 0, 0) if addend is None else pmx(addend)
-    flags = dyb | (dxb << 1) | (ab << 2)
+    flags = dyb | (dxb << 1) | (ab << 2) | (64 if scatter else 0)
     ylp, ldyl, linp = None, 0, None
     if lin is not None:
         ylp, ldyl, ylb = pmx(lin[0])
@@ -494,6 +503,8 @@ def conv_dgrad(dy, weight, dx, stride, pad, dil, addend=None, mode=0):
     n, cin, h, w = dx.shape
     o, _, kh, kw = weight.shape
     if _B16 and mode == 0 and _dgrad_b16(dy, weight, dx, stride, pad, dil, addend=addend):
+        return
+    if _B16 and mode == 1 and addend is None and _dgrad_b16(dy, weight, dx, stride, pad, dil, scatter=True):
         return
     if dx.dtype != torch.float32:
         raise SegHieroHipError("the fp32-accurate input-gradient kernels write fp32 tensors")
@@ -738,13 +749,15 @@ def _wgrad_b16(x, dy, dweight, stride, pad, dil, side, aff):
     g = dd.g if dd is not None else dy
     if dd is not None and not (dd.g.dtype == torch.bfloat16 and dd.y.dtype == torch.bfloat16):
         return False
-    if o % 8 or cin % 8 or not dweight.is_contiguous(memory_format=torch.channels_last if kh * kw > 1 and cin > 1 else torch.contiguous_format):
+    if cin % 8 or not dweight.is_contiguous(memory_format=torch.channels_last if kh * kw > 1 and cin > 1 else torch.contiguous_format):
         return False
     need = LIB.raw("sh_conv_wgrad_x6_workspace")(n, h, w, cin, o, kh, kw, stride, pad, dil)
     if need < 0:
         return False
     xp, ldx, _ = pmx(x)
     gp, ldg, gb = pmx(g)
+    if ldg < pad8(o) or (o % 8 and dd is not None):
+        return False                                   # the loader reads 8 channels of dy at a time (padding lanes zero)
     ylp, ldyl = (None, 0) if dd is None else pmx(dd.y)[:2]
     ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, dil)
     m = n * ho * wo
@@ -1067,6 +1080,17 @@ def grad_dtype(like, fp32_consumer=False):
     if _B16 and GRAD_BF16 and not fp32_consumer and like is not None and like.dtype == torch.bfloat16:
         return torch.bfloat16
     return torch.float32
+
+
+def strided_dgrad_b16_ok(weight, cin, stride, pad, dil, scatter):
+    """bf16 compute mode: does the one-product kernel take this strided input gradient (so that dy and dx may be bf16 tensors)?
+    scatter: the 1x1 strided conv whose gradient is added into an existing dx; otherwise stride-2 KxK by parity class."""
+    o, _, kh, kw = weight.shape
+    if not (_B16 and GRAD_BF16 and CONV_IMPL == "x6" and cin % 8 == 0 and o % 8 == 0):
+        return False
+    if scatter:
+        return kh == 1 and kw == 1 and pad == 0
+    return stride == 2 and dil == 1 and kh * kw > 1 and o % 64 == 0
 
 
 def lin_ok(x_shape, weight, stride, pad, dil):

@@ -872,6 +872,98 @@ def test_conv_bf16_compute_mode_matches_exact_products_of_the_rounded_operands(o
                     np.testing.assert_allclose(dw.cpu().double().numpy(), ref_dw.numpy(), **tol(ref_dw))
 
 
+@pytest.mark.parametrize("case", [(2, 16, 16, 512, 25), (1, 24, 20, 64, 13), (2, 8, 8, 128, 20)])
+def test_conv_bf16_compute_mode_classifier_channel_counts(ops, case):
+    """Cout % 8 != 0 (the classifier, 512 -> n_fine) in bf16 compute mode: the forward writes rows of pad8(Cout) (padding lanes zero, bias
+    zero-padded by ops), the input gradient and the weight gradient read the loss gradient from rows of pad8(Cout) with zeroed padding."""
+    n, h, w, cin, cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    bf = lambda t: t.to(torch.bfloat16)
+    x = bf(torch.randn(n, cin, h, w, generator=g))
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    bias = torch.randn(cout, generator=g)
+    wq = bf(wt).double()
+    scale, shift = torch.randn(cin, generator=g), 0.3 * torch.randn(cin, generator=g)
+    coefs = torch.stack([torch.zeros(cin), torch.ones(cin), scale, shift]).to(DEV).contiguous()
+    pre = (x.double() * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)).float()
+    act = bf(torch.relu(pre))
+    xg, wg, bg = nhwc_bf16(x), wl(wt), bias.to(DEV)
+    ld = ops.pad8(cout)
+    tol = lambda r: dict(rtol=2e-5, atol=2e-5 * float(r.abs().max()))
+    with ops.compute_as(torch.bfloat16):
+        for coef, xin in ((None, x), (coefs, act)):
+            ref = F.conv2d(xin.double(), wq, bias.double())
+            y = ops.new_act(n, cout, h, w, DEV, ld=ld)
+            y.fill_(float("nan"))
+            assert ops._fprop_b16(xg, coef, wg, bg, y, None, 1, 0, 1), "no bf16 instantiation for the classifier"
+            np.testing.assert_allclose(y.cpu().double().numpy(), ref.numpy(), **tol(ref))
+            full = torch.as_strided(y, (n, h, w, ld), (h * w * ld, w * ld, ld, 1))
+            assert torch.equal(full[..., cout:], torch.zeros_like(full[..., cout:])), "padding lanes of the logits rows are written as zeros"
+        dyq = bf(torch.randn(n, cout, h, w, generator=g))
+        dy32 = ops.new_act(n, cout, h, w, DEV, ld=ld, zero=True)
+        dy32.copy_(dyq.float().to(DEV))
+        ref_dx = torch.nn.grad.conv2d_input((n, cin, h, w), wq, dyq.double())
+        for dxdt in (torch.float32, torch.bfloat16):
+            dx = ops.new_act(n, cin, h, w, DEV, dtype=dxdt)
+            assert ops._dgrad_b16(dy32, wg, dx, 1, 0, 1)
+            e = float((dx.cpu().double() - ref_dx).abs().max() / ref_dx.abs().max())
+            assert e < (2e-5 if dxdt == torch.float32 else 2 ** -8), (dxdt, e)
+        for xin, coef in ((x, None), (act, coefs)):
+            ref_dw = torch.nn.grad.conv2d_weight(xin.double(), (cout, cin, 1, 1), dyq.double())
+            dw = torch.empty_like(wg)
+            assert ops._wgrad_b16(xg, dy32, dw, 1, 0, 1, False, coef), "no bf16 weight-gradient instantiation for the classifier"
+            np.testing.assert_allclose(dw.cpu().double().numpy(), ref_dw.numpy(), **tol(ref_dw))
+
+
+B16_STRIDED = [
+    # n, h, w, cin, cout, k, pad
+    (2, 16, 16, 128, 128, 3, 1),           # layer2.0.conv2's plan: 3 x 3 stride 2, four parity classes
+    (1, 17, 13, 64, 64, 3, 1),             # odd sizes: classes of different extent, rows beyond the smaller classes
+    (2, 12, 20, 32, 64, 3, 1),             # 128 x 64 tiles (Cin = 32)
+    (2, 16, 16, 256, 512, 1, 0),           # the downsample branch: 1 x 1 stride 2, added into dx at the even pixels
+    (1, 15, 11, 64, 128, 1, 0),            # odd sizes
+]
+
+
+@pytest.mark.parametrize("case", B16_STRIDED)
+def test_conv_bf16_compute_mode_strided_input_gradients(ops, case):
+    """Input gradients of the strided convs in bf16 compute mode (conv_b16_kernel's row maps): stride-2 K x K by input-parity class and
+    the 1 x 1 strided conv whose result is ADDED to an existing dx at the strided pixels (sh_conv_dgrad_b16 act_flags bit 6) -- against
+    fp64 gradients of the bf16-rounded operands, fp32 and bf16 gradient operand, fp32 and bf16 result (one rounding of the sum)."""
+    n, h, w, cin, cout, k, p = case
+    g = torch.Generator().manual_seed(sum(case) + 7)
+    bf = lambda t: t.to(torch.bfloat16)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cout * k * k) ** 0.5
+    wq, wg = bf(wt).double(), wl(wt)
+    ho, wo = (h + 2 * p - k) // 2 + 1, (w + 2 * p - k) // 2 + 1
+    dyq = bf(torch.randn(n, cout, ho, wo, generator=g))
+    ref = torch.nn.grad.conv2d_input((n, cin, h, w), wq, dyq.double(), 2, p, 1)
+    ldy = ops.pad8(cout)
+    dy32 = ops.new_act(n, cout, ho, wo, DEV, ld=ldy, zero=True)
+    dy32.copy_(dyq.float().to(DEV))
+    dy16 = nhwc_bf16(dyq, ld=ldy)
+    tol = dict(rtol=2e-5, atol=2e-5 * float(ref.abs().max()))
+    scatter = k == 1
+    base = bf(torch.randn(n, cin, h, w, generator=g))               # what dx holds before the scatter-add
+    with ops.compute_as(torch.bfloat16):
+        for dyt in (dy32, dy16):
+            dx = ops.new_act(n, cin, h, w, DEV)
+            if scatter:
+                dx.copy_(base.float().to(DEV))
+            else:
+                dx.fill_(float("nan"))                               # every pixel belongs to exactly one class and is written
+            assert ops._dgrad_b16(dyt, wg, dx, 2, p, 1, scatter=scatter), "no bf16 instantiation for a model shape"
+            want = ref + base.double() if scatter else ref
+            np.testing.assert_allclose(dx.cpu().double().numpy(), want.numpy(), **tol)
+            dxb = nhwc_bf16(base) if scatter else ops.new_act(n, cin, h, w, DEV, dtype=torch.bfloat16)
+            assert ops._dgrad_b16(dyt, wg, dxb, 2, p, 1, scatter=scatter)
+            err = float((dxb.cpu().double() - want).abs().max() / want.abs().max())
+            assert err < 2 ** -8, ("bf16 result", err)
+        # hooks do not combine with the row maps: nothing is launched, the caller runs the fp32-accurate kernel
+        dx = ops.new_act(n, cin, h, w, DEV)
+        assert not ops._dgrad_b16(dy16, wg, dx, 2, p, 1, addend=nhwc_bf16(base), scatter=scatter)
+
+
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 256), (1, 24, 16, 128, 512), (4, 16, 16, 512, 2048), (2, 32, 32, 64, 128)])
 def test_conv_bf16_compute_mode_deferred_batchnorm_backward(ops, case):
     """lin(g, y) in the bf16 loaders (1x1 input gradient and weight gradient; g and y bf16 tensors): the operand is
