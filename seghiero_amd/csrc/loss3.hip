@@ -11,6 +11,7 @@
 //                        :509-513) + the closed-form backward matrices K1, K2.
 //   sh_rmi_dprob       : dL/dP at every pixel = 3x3 col2im of (K1*la + K2*pr).
 //   sh_hiera3_loss_bwd : tiled gather-form backward (as loss.hip) adding the RMI gradient through sigmoid'.
+#include <type_traits>
 #include "loss_common.h"
 
 #define MAXF3 64
@@ -220,47 +221,65 @@ __global__ __launch_bounds__(256) void rmi_gram_kernel(const float* __restrict__
 #pragma unroll
     for (int k = 0; k < 45; ++k) acc[k] = 0.0;
     const bool active = x < nW;
-    double pr[9], la[9];      // window, index = 3*dy + dx
+    // (r3) The 3 x 3 window lives in a ring of three row slots: the loop is unrolled by three so that every step addresses its rows at
+    // compile time (no 12 f64 moves per row to slide the window), the next row's six loads are issued before this row's arithmetic,
+    // and each product is accumulated with one fused multiply-add (45 v_fma_f64 per row and wave instead of 45 v_mul + 45 v_add; the
+    // f64 accumulation order per entry is unchanged).  Measured on configs[3] (12 channels, 512^2, B = 16): 1.38 -> see DESIGN.md.
+    double pw[3][3], lw[3][3];      // [ring slot][dx]
     if (active) {
+        float pn[3]; uint8_t ln[3];
+        auto fetch = [&](int row) {
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
+            for (int dx = 0; dx < 3; ++dx) { pn[dx] = P[(long long)row * W + x + dx]; ln[dx] = L[(long long)row * W + x + dx]; }
+        };
+        auto park = [&](int slot) {
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                pr[3 * (dy + 1) + dx] = (double)P[(long long)(y0 + dy) * W + x + dx];
-                la[3 * (dy + 1) + dx] = (double)lut[L[(long long)(y0 + dy) * W + x + dx]];
-            }
-        for (int y = y0; y < y1; ++y) {
+            for (int dx = 0; dx < 3; ++dx) { pw[slot][dx] = (double)pn[dx]; lw[slot][dx] = (double)lut[ln[dx]]; }
+        };
+        fetch(y0); park(0);
+        fetch(y0 + 1); park(1);
+        fetch(y0 + 2);                                   // row y0 + 2 of the first window: parked by the first step
+        auto step = [&](auto kk, int y) {
+            constexpr int K = decltype(kk)::value;       // window rows top -> bottom = slots K, K+1, K+2 (mod 3); the new row goes to K+2
+            park((K + 2) % 3);
+            if (y + 1 < y1) fetch(y + 3);                // next window's new row: in flight during this window's arithmetic
+            double pr[9], la[9];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) { pr[k] = pr[k + 3]; la[k] = la[k + 3]; }
+            for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                pr[6 + dx] = (double)P[(long long)(y + 2) * W + x + dx];
-                la[6 + dx] = (double)lut[L[(long long)(y + 2) * W + x + dx]];
-            }
+                for (int dx = 0; dx < 3; ++dx) { pr[3 * dy + dx] = pw[(K + dy) % 3][dx]; la[3 * dy + dx] = lw[(K + dy) % 3][dx]; }
             if (grp == 0) {            // pp upper triangle
                 int e = 0;
 #pragma unroll
                 for (int i = 0; i < 9; ++i)
 #pragma unroll
-                    for (int j = i; j < 9; ++j) acc[e++] += pr[i] * pr[j];
+                    for (int j = i; j < 9; ++j) { acc[e] = __builtin_fma(pr[i], pr[j], acc[e]); ++e; }
             } else if (grp == 1) {     // lp rows 0..4
 #pragma unroll
                 for (int i = 0; i < 5; ++i)
 #pragma unroll
-                    for (int j = 0; j < 9; ++j) acc[i * 9 + j] += la[i] * pr[j];
+                    for (int j = 0; j < 9; ++j) acc[i * 9 + j] = __builtin_fma(la[i], pr[j], acc[i * 9 + j]);
             } else if (grp == 2) {     // lp rows 5..8
 #pragma unroll
                 for (int i = 5; i < 9; ++i)
 #pragma unroll
-                    for (int j = 0; j < 9; ++j) acc[(i - 5) * 9 + j] += la[i] * pr[j];
+                    for (int j = 0; j < 9; ++j) acc[(i - 5) * 9 + j] = __builtin_fma(la[i], pr[j], acc[(i - 5) * 9 + j]);
             } else {                   // ll upper triangle
                 int e = 0;
 #pragma unroll
                 for (int i = 0; i < 9; ++i)
 #pragma unroll
-                    for (int j = i; j < 9; ++j) acc[e++] += la[i] * la[j];
+                    for (int j = i; j < 9; ++j) { acc[e] = __builtin_fma(la[i], la[j], acc[e]); ++e; }
             }
+        };
+        int y = y0;
+        for (; y + 2 < y1; y += 3) {
+            step(std::integral_constant<int, 0>{}, y);
+            step(std::integral_constant<int, 1>{}, y + 1);
+            step(std::integral_constant<int, 2>{}, y + 2);
         }
+        if (y < y1) step(std::integral_constant<int, 0>{}, y);
+        if (y + 1 < y1) step(std::integral_constant<int, 1>{}, y + 1);
     }
     const int cnt = grp == 2 ? 36 : 45;
     const int off = grp == 0 ? 0 : grp == 1 ? 45 : grp == 2 ? 90 : 126;
@@ -404,6 +423,7 @@ __global__ void rmi_value_kernel(const double* __restrict__ rmi, int B, int C, f
 }
 
 // dP[bc][y][x] = sum over the <=9 windows containing (y,x) as element k of (K1[k,:] . la_win + K2[k,:] . pr_win)
+#define RMI_DP_ROWS 16
 __global__ __launch_bounds__(256) void rmi_dprob_kernel(const float* __restrict__ probs, const uint8_t* __restrict__ labels, const H3Tab T,
                                                         const double* __restrict__ K1, const double* __restrict__ K2, float* __restrict__ dprob,
                                                         int H, int W, int C) {
@@ -426,23 +446,45 @@ __global__ __launch_bounds__(256) void rmi_dprob_kernel(const float* __restrict_
         a1[threadIdx.x] = s1; a2[threadIdx.x] = s2;
     }
     __syncthreads();
-    // block = 256 columns x 4 rows, thread = 4 consecutive pixels of one row.  The (256+4) x (4+4) neighbourhood is staged once
-    // in LDS; a thread reads its 5 x 8 window with 16-byte LDS reads and each correlation coefficient once for its 4 pixels.
+    // block = 256 columns x RMI_DP_ROWS rows, thread = 4 consecutive pixels of one row in each of the RMI_DP_ROWS / 4 row groups.  The
+    // (256+4) x (rows+4) neighbourhood is staged once in LDS; a thread reads its 5 x 8 window with 16-byte LDS reads and each correlation
+    // coefficient once for its 4 pixels.  (r3: 16 rows per block instead of 4 -- the halo rows were half of all staged bytes and the
+    // per-block set-up (81 + 81 coefficients, the 25 + 25 collapsed ones) ran 49 152 times -- and fused multiply-adds.)
     constexpr int TW = 264;                                  // 256 + 4 halo columns, padded to a multiple of 4 floats
-    __shared__ __attribute__((aligned(16))) float tp[8][TW], tl[8][TW];
-    const int bx0 = blockIdx.x * 256 - 2, by0 = blockIdx.y * 4 - 2;
+    __shared__ __attribute__((aligned(16))) float tp[RMI_DP_ROWS + 4][TW], tl[RMI_DP_ROWS + 4][TW];
+    const int bx0 = blockIdx.x * 256 - 2, by0 = blockIdx.y * RMI_DP_ROWS - 2;
     const float* P = probs + (long long)bc * H * W;
     const uint8_t* L = labels + (long long)n * H * W;
-    for (int i = threadIdx.x; i < 8 * TW; i += 256) {
-        const int ry = i / TW, rx = i - ry * TW, yy = by0 + ry, xx = bx0 + rx;
-        const bool ok = rx < 260 && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        tp[ry][rx] = ok ? P[(long long)yy * W + xx] : 0.f;
-        tl[ry][rx] = ok ? lut[L[(long long)yy * W + xx]] : 0.f;
+    // staging in chunks of 7 elements per thread: all 14 global loads of a chunk are issued before the first dependent look-up / LDS store
+    // (one element at a time the loop was a chain of 21 exposed load latencies per block)
+    constexpr int NEL = (RMI_DP_ROWS + 4) * TW, NST = (NEL + 255) / 256, CHK = 7;
+    for (int s0 = 0; s0 < NST; s0 += CHK) {
+        float pq[CHK]; int lq[CHK]; bool okq[CHK];
+#pragma unroll
+        for (int u = 0; u < CHK; ++u) {
+            const int i = (s0 + u) * 256 + (int)threadIdx.x;
+            const int ry = i / TW, rx = i - ry * TW, yy = by0 + ry, xx = bx0 + rx;
+            okq[u] = i < NEL && rx < 260 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            pq[u] = okq[u] ? P[(long long)yy * W + xx] : 0.f;
+            lq[u] = okq[u] ? (int)L[(long long)yy * W + xx] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < CHK; ++u) {
+            const int i = (s0 + u) * 256 + (int)threadIdx.x;
+            if (i < NEL) { const int ry = i / TW, rx = i - ry * TW; tp[ry][rx] = pq[u]; tl[ry][rx] = okq[u] ? lut[lq[u]] : 0.f; }
+        }
     }
     __syncthreads();
-    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
-    const int x0 = blockIdx.x * 256 + 4 * lx, y = blockIdx.y * 4 + ly;
-    if (x0 >= W || y >= H) return;
+    const int lx = threadIdx.x & 63;
+    const int x0 = blockIdx.x * 256 + 4 * lx;
+    if (x0 >= W) return;
+    const int nrows = min(RMI_DP_ROWS, H - (int)blockIdx.y * RMI_DP_ROWS);
+#pragma unroll 1
+    for (int ly = threadIdx.x >> 6; ly < nrows; ly += 4) {
+    // the coefficient tables (a1 / a2, k1 / k2: 212 doubles in LDS) are loop-invariant; hoisted out of this loop they took all 512
+    // registers and spilled 212 -- the memory clobber keeps their loads inside the iteration
+    asm volatile("" ::: "memory");
+    const int y = blockIdx.y * RMI_DP_ROWS + ly;
     float pv[5][8], lv[5][8];
 #pragma unroll
     for (int dy = 0; dy < 5; ++dy) {
@@ -462,7 +504,7 @@ __global__ __launch_bounds__(256) void rmi_dprob_kernel(const float* __restrict_
             for (int dx = 0; dx < 5; ++dx) {
                 const double c1 = a1[dy * 5 + dx], c2 = a2[dy * 5 + dx];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] += c1 * (double)lv[dy][q + dx] + c2 * (double)pv[dy][q + dx];
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_fma(c2, (double)pv[dy][q + dx], __builtin_fma(c1, (double)lv[dy][q + dx], acc[q]));
             }
     } else {
 #pragma unroll
@@ -473,7 +515,7 @@ __global__ __launch_bounds__(256) void rmi_dprob_kernel(const float* __restrict_
 #pragma unroll
                 for (int dy = 0; dy < 5; ++dy)
 #pragma unroll
-                    for (int dx = 0; dx < 5; ++dx) acc[q] += a1[dy * 5 + dx] * (double)lv[dy][q + dx] + a2[dy * 5 + dx] * (double)pv[dy][q + dx];
+                    for (int dx = 0; dx < 5; ++dx) acc[q] = __builtin_fma(a2[dy * 5 + dx], (double)pv[dy][q + dx], __builtin_fma(a1[dy * 5 + dx], (double)lv[dy][q + dx], acc[q]));
                 continue;
             }
 #pragma unroll
@@ -499,6 +541,7 @@ __global__ __launch_bounds__(256) void rmi_dprob_kernel(const float* __restrict_
     } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) if (x0 + q < W) dst[q] = (float)acc[q];
+    }
     }
 }
 
@@ -688,7 +731,7 @@ extern "C" int sh_rmi_loss(const float* probs, const uint8_t* labels, const int*
     rmi_solve_kernel<<<(unsigned)BC, 192, 0, st>>>(partials, parts, BC, rmi, K1, K2);
     rmi_value_kernel<<<1, 64, 0, st>>>(rmi, N, C, rmi_out);
     if (dprob) {
-        dim3 g2((unsigned)sh_cdiv(W, 256), (unsigned)sh_cdiv(H, 4), (unsigned)BC);
+        dim3 g2((unsigned)sh_cdiv(W, 256), (unsigned)sh_cdiv(H, RMI_DP_ROWS), (unsigned)BC);
         rmi_dprob_kernel<<<g2, 256, 0, st>>>(probs, labels, T, K1, K2, dprob, H, W, C);
     }
     return sh_launch_status();
