@@ -392,10 +392,13 @@ int sh_combine_loss(const float* main_loss, const float* trip_out, const float* 
  *   loss_out (device float[1]) <- 0.5*5*(bce_f/(nv*nf)+bce_m/(nv*nm)+bce_h/(nv*nh)) + (ce_f+ce_m+ce_h)/npix
  *   probs (optional): planar f32 [N][C][H][W] <- sigmoid(z)*valid + 1e-6 (the RMI input, :496).
  *   mid_out / high_out (optional, both or neither): uint8 [N][H][W] <- the target maps of _prepare_targets_three_level
- *   (:21-63): 255 where the fine label is 255, else fine_to_mid[f] / fine_to_high[f]. */
+ *   (:21-63): 255 where the fine label is 255, else fine_to_mid[f] / fine_to_high[f].
+ *   grad_out (optional; ldg = 16 or 32 >= C, sh_loss_bwd_workspace(N,H,W,ldg) bytes): the same pass leaves d(loss_out)/d(interpolated
+ *   logits) of every full-resolution pixel, [N*H*W][ldg], for sh_hiera3_loss_bwd(..., workspace_has_grad = 1). */
 int sh_hiera3_loss_fwd(const float* logits, int ldl, const uint8_t* labels, const int* f2m_host, const int* f2h_host,
                        int n_fine, int n_mid, int n_high, double* sums, float* loss_out, float* partials, float* probs,
-                       uint8_t* mid_out, uint8_t* high_out, int N, int h, int w, int H, int W, void* stream);
+                       uint8_t* mid_out, uint8_t* high_out, int N, int h, int w, int H, int W, float* grad_out,
+                       int64_t grad_out_bytes, int ldg, void* stream);
 /* RMI lower bound (:292-317, :479-517): per (image, channel) f64 9x9 Gram matrices over the 3x3 windows, inverse, Schur
  * complement, Cholesky log-det; rmi_out (device float[1]) <- sum_c mean_b(0.5*logdet)/9.  dprob (optional, planar like
  * probs) <- d(0.5*logdet_{b,c})/dP (the 1/(9N) and lambda factors are applied by sh_hiera3_loss_bwd's rmi_coef). */
@@ -407,11 +410,12 @@ int sh_rmi_loss(const float* probs, const uint8_t* labels, const int* f2m_host, 
                 int n_high, void* workspace, float* rmi_out, float* dprob, int N, int H, int W, void* stream);
 /* dlogits [N,h,w,lddl] <- gscale*gscale_dev[0] * d(loss_out + rmi_coef * <dprob, P>)/d(logits)  (tiled gather form; with a
  * workspace of sh_loss_bwd_workspace(N,H,W,lddl) bytes and upsampled logits: the two streaming passes of sh_hiera2_loss_bwd,
- * bit-identical). */
+ * bit-identical).  workspace_has_grad: the workspace is sh_hiera3_loss_fwd's grad_out (row stride lddl); the RMI term is added to it in
+ * one streaming pass (probs = that forward's planar probabilities, needed with dprob), then the scaled adjoint of the resize. */
 int sh_hiera3_loss_bwd(const float* logits, int ldl, const uint8_t* labels, const int* f2m_host, const int* f2h_host,
                        int n_fine, int n_mid, int n_high, const double* sums, const float* dprob, float rmi_coef,
                        const float* gscale_dev, float gscale, float* dlogits, int lddl, int N, int h, int w, int H, int W,
-                       float* workspace, int64_t workspace_bytes, void* stream);
+                       float* workspace, int64_t workspace_bytes, int workspace_has_grad, const float* probs, void* stream);
 /* out = (a + alpha*b[0]) -- device scalar combine used for lambda*rmi + rest. */
 int sh_scalar_axpy(const float* a, const float* b, float alpha, float* out, void* stream);
 

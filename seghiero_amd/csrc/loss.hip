@@ -491,6 +491,10 @@ static int launch_gather_from_grad(const float* gfull, const float* gscale_dev, 
                                                                gscale_dev, gscale, 1);
     return sh_launch_status();
 }
+int sh_launch_gather_from_grad(const float* gfull, const float* gscale_dev, float gscale, float* dlogits, int lddl, int N, int h, int w,
+                               int H, int W, hipStream_t st) {       // (loss3.hip: the 3-level loss's gather-only backward)
+    return launch_gather_from_grad(gfull, gscale_dev, gscale, dlogits, lddl, N, h, w, H, W, st);
+}
 template <int MAXC, int MODE>
 static int launch_loss_bwd_two_pass(const float* logits, int ldl, const uint8_t* labels, const H2Tab& T, int C, const double* sums,
                                     const float* gscale_dev, float gscale, float* dlogits, int lddl, int N, int h, int w, int H, int W,

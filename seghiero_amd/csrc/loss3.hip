@@ -125,14 +125,41 @@ __device__ __forceinline__ void hiera3_pixel(const float (&z)[MAXC], int tf, con
 }
 
 // ------------------------------------------------------------------------------------------ forward
-template <int MAXC>
+// valid-label count ahead of a forward that also emits the gradient (its normaliser n_valid): cnt[0] += #(label != 255)
+__global__ __launch_bounds__(256) void valid_count_kernel(const uint8_t* __restrict__ labels, long long total, unsigned long long* __restrict__ cnt) {
+    __shared__ unsigned int red[4];
+    unsigned int a = 0;
+    const long long n4 = (((uintptr_t)labels & 3) == 0) ? total / 4 : 0, gs = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += gs) {
+        const unsigned v = reinterpret_cast<const unsigned*>(labels)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a += ((v >> (8 * k)) & 255u) != (unsigned)IGN;
+    }
+    for (long long i = 4 * n4 + (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += gs) a += labels[i] != IGN;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(cnt, (unsigned long long)((red[0] + red[1]) + (red[2] + red[3])));
+}
+// GRAD (r3): every pixel's d(loss_out)/d(interpolated logits) -- everything but the RMI term, at unit upstream gradient -- goes to
+// gfull [N*H*W][L] in the same pass (as hiera2_fwd_kernel); cnt[0] = n_valid from valid_count_kernel.  The backward is then
+// hiera3_rmi_add_kernel (the RMI term, a streaming pass) and the scaled adjoint of the resize.
+template <int MAXC, bool GRAD>
 __global__ __launch_bounds__(256) void hiera3_fwd_kernel(const float* __restrict__ logits, long long ldl, const uint8_t* __restrict__ labels,
                                                          const H3Tab T, float* __restrict__ partials, float* __restrict__ probs,
                                                          uint8_t* __restrict__ mid_out, uint8_t* __restrict__ high_out,
-                                                         int h, int w, int H, int W, float sy, float sx, long long total) {
+                                                         int h, int w, int H, int W, float sy, float sx, long long total,
+                                                         const unsigned long long* __restrict__ cnt, float* __restrict__ gfull, int L) {
     const bool identity = (h == H && w == W);
     const int C = T.nf + T.nm + T.nh;
     float v[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, b = 0.f;
+    if (GRAD) {          // the coefficients of hiera3_grad_fullres_kernel at unit upstream gradient
+        const double nv = cnt[0] < 1 ? 1.0 : (double)cnt[0];
+        a0 = 0.5f * (float)(5.0 / (nv * T.nf)); a1 = 0.5f * (float)(5.0 / (nv * T.nm)); a2 = 0.5f * (float)(5.0 / (nv * T.nh));
+        b = (float)(1.0 / (double)total);
+    }
     const long long base = (long long)blockIdx.x * LOSS_PIX_PER_BLOCK;
 #pragma unroll 1
     for (int it = 0; it < LOSS_PIX_PER_BLOCK / 256; ++it) {
@@ -147,6 +174,11 @@ __global__ __launch_bounds__(256) void hiera3_fwd_kernel(const float* __restrict
         const long long q = i / W;
         const int oy = (int)(q % H);
         const long long n = q / H;
+        if (GRAD && f == IGN) {
+#pragma unroll
+            for (int j = 0; j < MAXC; j += 4)
+                if (j < L) st4(gfull + i * L + j, f32x4{0.f, 0.f, 0.f, 0.f});
+        }
         if (f == IGN && probs == nullptr) continue;
         const Lerp ly = lerp_src(oy, sy, h), lx = lerp_src(ox, sx, w);
         float z[MAXC], g[MAXC], o[6];
@@ -157,7 +189,16 @@ __global__ __launch_bounds__(256) void hiera3_fwd_kernel(const float* __restrict
                 if (j < C) probs[((n * C + j) * H + oy) * W + ox] = (f == IGN ? 0.f : sigmoidf_(z[j])) + 1e-6f;
         }
         if (f == IGN) continue;
-        hiera3_pixel<MAXC, false>(z, f, T, 0.f, 0.f, 0.f, 0.f, o, g);
+        if (GRAD) {
+#pragma unroll
+            for (int j = 0; j < MAXC; ++j) g[j] = 0.f;
+        }
+        hiera3_pixel<MAXC, GRAD>(z, f, T, a0, a1, a2, b, o, g);
+        if (GRAD) {
+#pragma unroll
+            for (int j = 0; j < MAXC; j += 4)
+                if (j < L) st4(gfull + i * L + j, f32x4{g[j], g[j + 1], g[j + 2], g[j + 3]});
+        }
 #pragma unroll
         for (int j = 0; j < 6; ++j) v[j] += o[j];
         v[6] += 1.f;
@@ -588,6 +629,32 @@ __global__ __launch_bounds__(256) void hiera3_grad_fullres_kernel(const float* _
     }
 }
 
+// the RMI term of the gradient added to the forward's per-pixel gradient (unit upstream gradient): g[j] += coef * dL/dP_j * sigmoid'(z_j) at
+// valid pixels, sigmoid(z_j) recovered from the stored P = sigmoid(z) + 1e-6.  Thread = one pixel: plane reads coalesced along x, its own
+// 4 * L bytes of gfull read and written once.
+template <int MAXC>
+__global__ __launch_bounds__(256) void hiera3_rmi_add_kernel(float* __restrict__ gfull, int L, const float* __restrict__ probs, const float* __restrict__ dprob,
+                                                             const uint8_t* __restrict__ labels, float coef, int C, long long HW, long long total) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        if (labels[i] == IGN) continue;
+        const long long n = i / HW, pix = i - n * HW;
+        float pj[MAXC], dj[MAXC];
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j)
+            if (j < C) { pj[j] = probs[(n * C + j) * HW + pix]; dj[j] = dprob[(n * C + j) * HW + pix]; }
+        float* dst = gfull + i * L;
+#pragma unroll
+        for (int j = 0; j < MAXC; j += 4) {
+            if (j >= L) break;
+            f32x4 g = ld4(dst + j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (j + e < C) { const float p = pj[j + e] - 1e-6f; g[e] += coef * dj[j + e] * p * (1.f - p); }
+            st4(dst + j, g);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ tiled backward
 template <int MAXC>
 __global__ __launch_bounds__(256) void hiera3_bwd_tile_kernel(const float* __restrict__ logits, long long ldl, const uint8_t* __restrict__ labels,
@@ -680,9 +747,12 @@ static bool make_tab3(H3Tab& T, const int* f2m, const int* f2h, int nf, int nm, 
     return true;
 }
 
+// grad_out (optional, with ldg in {16, 32} >= C and sh_loss_bwd_workspace(N, H, W, ldg) bytes): the per-pixel gradient of everything but the
+// RMI term at unit upstream gradient, for sh_hiera3_loss_bwd(..., workspace_has_grad = 1)
 extern "C" int sh_hiera3_loss_fwd(const float* logits, int ldl, const uint8_t* labels, const int* f2m_host, const int* f2h_host, int n_fine,
                                   int n_mid, int n_high, double* sums, float* loss_out, float* partials, float* probs, uint8_t* mid_out,
-                                  uint8_t* high_out, int N, int h, int w, int H, int W, void* stream) {
+                                  uint8_t* high_out, int N, int h, int w, int H, int W, float* grad_out, int64_t grad_out_bytes, int ldg,
+                                  void* stream) {
     H3Tab T;
     if (!logits || !labels || !sums || !loss_out || !partials || N <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SH_EINVAL;
     if ((mid_out == nullptr) != (high_out == nullptr)) return SH_EINVAL;
@@ -692,8 +762,15 @@ extern "C" int sh_hiera3_loss_fwd(const float* logits, int ldl, const uint8_t* l
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
     hipStream_t st = (hipStream_t)stream;
     const int C = n_fine + n_mid + n_high;
-    if (C <= 16) hiera3_fwd_kernel<16><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, probs, mid_out, high_out, h, w, H, W, sy, sx, total);
-    else hiera3_fwd_kernel<32><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, probs, mid_out, high_out, h, w, H, W, sy, sx, total);
+    if (grad_out != nullptr) {
+        if (ldg < C || (ldg != 16 && ldg != 32) || ((uintptr_t)grad_out & 15) || grad_out_bytes < (int64_t)total * ldg * 4 || h > H || w > W) return SH_EINVAL;
+        unsigned long long* cnt = reinterpret_cast<unsigned long long*>(sums + 7);     // scratch until hiera3_finalize_kernel writes sums[7]
+        if (hipMemsetAsync(cnt, 0, sizeof(unsigned long long), st) != hipSuccess) return SH_ELAUNCH;
+        valid_count_kernel<<<256, 256, 0, st>>>(labels, total, cnt);
+        if (ldg == 16) hiera3_fwd_kernel<16, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, probs, mid_out, high_out, h, w, H, W, sy, sx, total, cnt, grad_out, ldg);
+        else hiera3_fwd_kernel<32, true><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, probs, mid_out, high_out, h, w, H, W, sy, sx, total, cnt, grad_out, ldg);
+    } else if (C <= 16) hiera3_fwd_kernel<16, false><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, probs, mid_out, high_out, h, w, H, W, sy, sx, total, nullptr, nullptr, 0);
+    else hiera3_fwd_kernel<32, false><<<nblk, 256, 0, st>>>(logits, ldl, labels, T, partials, probs, mid_out, high_out, h, w, H, W, sy, sx, total, nullptr, nullptr, 0);
     int rc = sh_launch_status();
     if (rc != SH_OK) return rc;
     hiera3_finalize_kernel<<<1, 256, 0, st>>>(partials, nblk, (double)total, n_fine, n_mid, n_high, sums, loss_out);
@@ -749,14 +826,31 @@ static int pick_tile3(int h, int w, int H, int W, int C, int budget_bytes, int& 
     return best;
 }
 // d/dlogits of  gscale*gscale_dev[0] * ( 0.5*hiera3 + ce_f + ce_m + ce_h + rmi_coef * sum_pixels dprob*dP/dz ), into [N,h,w,lddl]
+// workspace_has_grad: the workspace is the grad_out of sh_hiera3_loss_fwd (row stride lddl); `probs` (that forward's planar probabilities)
+// is then needed with dprob: the RMI term is added to the workspace in one streaming pass, the backward itself is the scaled adjoint of the resize
 extern "C" int sh_hiera3_loss_bwd(const float* logits, int ldl, const uint8_t* labels, const int* f2m_host, const int* f2h_host, int n_fine,
                                   int n_mid, int n_high, const double* sums, const float* dprob, float rmi_coef, const float* gscale_dev,
                                   float gscale, float* dlogits, int lddl, int N, int h, int w, int H, int W, float* workspace,
-                                  int64_t workspace_bytes, void* stream) {
+                                  int64_t workspace_bytes, int workspace_has_grad, const float* probs, void* stream) {
     H3Tab T;
     if (!logits || !labels || !sums || !dlogits || N <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || h > H || w > W) return SH_EINVAL;
     const int C = n_fine + n_mid + n_high;
     if (!make_tab3(T, f2m_host, f2h_host, n_fine, n_mid, n_high) || ldl < C || lddl < C || lddl > 32) return SH_EINVAL;
+    if (workspace_has_grad) {
+        const long long full = (long long)N * H * W;
+        if (!workspace || (lddl != 16 && lddl != 32) || workspace_bytes < full * lddl * 4 || (((uintptr_t)workspace | (uintptr_t)dlogits) & 15) ||
+            (dprob && !probs)) return SH_EINVAL;
+        hipStream_t st0 = (hipStream_t)stream;
+        if (dprob) {
+            long long ga = sh_cdiv(full, 256);
+            if (ga > 16384) ga = 16384;
+            if (lddl == 16) hiera3_rmi_add_kernel<16><<<(unsigned)ga, 256, 0, st0>>>(workspace, lddl, probs, dprob, labels, rmi_coef, C, (long long)H * W, full);
+            else hiera3_rmi_add_kernel<32><<<(unsigned)ga, 256, 0, st0>>>(workspace, lddl, probs, dprob, labels, rmi_coef, C, (long long)H * W, full);
+            const int rc0 = sh_launch_status();
+            if (rc0 != SH_OK) return rc0;
+        }
+        return sh_launch_gather_from_grad(workspace, gscale_dev, gscale, dlogits, lddl, N, h, w, H, W, st0);
+    }
     if (workspace && workspace_bytes >= (int64_t)N * H * W * lddl * 4 && (h < H || w < W) && (lddl & 3) == 0 &&
         (((uintptr_t)workspace | (uintptr_t)dlogits) & 15) == 0) {
         // two streaming passes (see sh_hiera2_loss_bwd): same arithmetic and summation order as the tile kernel => bit-identical

@@ -83,6 +83,9 @@ __device__ __forceinline__ void fetch_logits(const float* __restrict__ base, lon
 
 // loss.hip: adjoint of the bilinear resize as a gather from a full-resolution gradient [N*H*W][lddl] (not scaled)
 int sh_launch_resize_adjoint_gather(const float* gfull, float* dlogits, int lddl, int N, int h, int w, int H, int W, hipStream_t st);
+// ... from a workspace that holds the gradient at unit upstream gradient (written by a forward), scaled by gscale * gscale_dev[0]
+int sh_launch_gather_from_grad(const float* gfull, const float* gscale_dev, float gscale, float* dlogits, int lddl, int N, int h, int w,
+                               int H, int W, hipStream_t st);
 
 // log-softmax CE of z[off..off+n) against target tgt: returns -log p_tgt; optionally adds coef*(softmax - onehot) to g
 template <int MAXC, bool GRAD>

@@ -282,8 +282,13 @@ class _Hiera3Fn(torch.autograd.Function):
         f2m, f2h = mod._f2m, mod._f2h
         lam, lw = mod.loss_weight_lambda, mod.loss_weight
         need_grad = ctx.needs_input_grad[0]
-        rest, sums, probs = ops.hiera3_fwd(logits, label8, nf, nm, nh, f2m, f2h, want_probs=True)
+        ctx.grad_ws = (None, 0)                                    # (workspace, row stride): the forward's per-pixel gradient
+        if need_grad:
+            rest, sums, probs, ctx.grad_ws = ops.hiera3_fwd(logits, label8, nf, nm, nh, f2m, f2h, want_probs=True, want_grad=True)
+        else:
+            rest, sums, probs = ops.hiera3_fwd(logits, label8, nf, nm, nh, f2m, f2h, want_probs=True)
         rmi, dprob = ops.rmi_loss(probs, label8, nf, nm, nh, f2m, f2h, want_grad=need_grad)
+        ctx.probs = probs if (need_grad and ctx.grad_ws[0] is not None) else None
         main = ops.scalar_axpy(rest, rmi, lam)
         masks, ok = mod.triplet_loss.tables(logits.device)
         trip, ws = ops.triplet_fwd(emb, label8, masks, ok, 200, 0.6)
@@ -309,7 +314,8 @@ class _Hiera3Fn(torch.autograd.Function):
         dlogits = None
         if ctx.needs_input_grad[0]:
             dlogits = ops.hiera3_bwd(logits, label8, nf, nm, nh, f2m, f2h, sums, dprob if ctx.has_dprob else None,
-                                     lam / (9.0 * batch), g, lw)
+                                     lam / (9.0 * batch), g, lw, grad_ws=ctx.grad_ws, probs=ctx.probs)
+            ctx.probs = None
         demb = None
         if ctx.needs_input_grad[1]:
             gt = g if ctx.ready is None else g * (ctx.ready > 0).float()

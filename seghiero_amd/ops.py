@@ -1496,8 +1496,10 @@ def _ints(values):
     return (ctypes.c_int * max(len(vals), 1))(*vals)
 
 
-def hiera3_fwd(logits, labels8, n_fine, n_mid, n_high, f2m, f2h, want_probs, want_targets=False):
-    """-> (loss_rest[1] f32, sums[8] f64, probs planar [N,C,H,W] or None[, (mid u8, high u8) target maps])."""
+def hiera3_fwd(logits, labels8, n_fine, n_mid, n_high, f2m, f2h, want_probs, want_targets=False, want_grad=False):
+    """-> (loss_rest[1] f32, sums[8] f64, probs planar [N,C,H,W] or None[, (mid u8, high u8) target maps]).  want_grad: the same pass
+    leaves the per-pixel gradient of everything but the RMI term and a fourth value is returned: (workspace or None, its row stride) for
+    hiera3_bwd(grad_ws=...)."""
     n, c, h, w = logits.shape
     _, H, W = labels8.shape
     lp, ldl = pm(logits)
@@ -1509,11 +1511,23 @@ def hiera3_fwd(logits, labels8, n_fine, n_mid, n_high, f2m, f2h, want_probs, wan
     probs = torch.empty((n, c, H, W), device=dev, dtype=torch.float32) if want_probs else None
     mid = torch.empty_like(labels8) if want_targets else None
     high = torch.empty_like(labels8) if want_targets else None
+    gw, gbytes, ldg = (None, 0, 0)
+    if want_grad and LOSS_FWD_GRAD and LOSS_BWD_TWO_PASS and (h < H or w < W) and c <= 32:
+        ldg = 16 if c <= 16 else 32
+        gbytes = n * H * W * ldg * 4
+        gw = STEP_SCOPE.get("lossgrad3") if STEP_SCOPE is not None else None
+        if gw is None or gw.numel() * 4 < gbytes or gw.device != dev:
+            gw = torch.empty((gbytes // 4,), device=dev, dtype=torch.float32)
+            if STEP_SCOPE is not None:
+                STEP_SCOPE["lossgrad3"] = gw
     _call("sh_hiera3_loss_fwd", lp, ldl, labels8.data_ptr(), _ints(f2m), _ints(f2h), n_fine, n_mid, n_high, sums.data_ptr(),
           loss.data_ptr(), partials.data_ptr(), None if probs is None else probs.data_ptr(),
-          None if mid is None else mid.data_ptr(), None if high is None else high.data_ptr(), n, h, w, H, W, _st())
+          None if mid is None else mid.data_ptr(), None if high is None else high.data_ptr(), n, h, w, H, W,
+          None if gw is None else gw.data_ptr(), gbytes, ldg, _st())
     if want_targets:
         return loss, sums, probs, (mid, high)
+    if want_grad:
+        return loss, sums, probs, (gw, ldg)
     return loss, sums, probs
 
 
@@ -1536,16 +1550,25 @@ def rmi_values(n, c, H, W, device):
     return ws[off:off + 8 * n * c].view(torch.float64).reshape(n, c).clone()
 
 
-def hiera3_bwd(logits, labels8, n_fine, n_mid, n_high, f2m, f2h, sums, dprob, rmi_coef, gscale_dev, gscale):
+def hiera3_bwd(logits, labels8, n_fine, n_mid, n_high, f2m, f2h, sums, dprob, rmi_coef, gscale_dev, gscale, grad_ws=None, probs=None):
+    """grad_ws = (workspace, ldg) left by hiera3_fwd(want_grad=True): the gather-only backward (+ the RMI term from dprob and probs)."""
     n, c, h, w = logits.shape
     _, H, W = labels8.shape
     lp, ldl = pm(logits)
+    if grad_ws is not None and grad_ws[0] is not None:
+        gw, ldg = grad_ws
+        d = new_act(n, c, h, w, logits.device, ld=ldg)
+        dp, ldd = pm(d)
+        _call("sh_hiera3_loss_bwd", lp, ldl, labels8.data_ptr(), _ints(f2m), _ints(f2h), n_fine, n_mid, n_high, sums.data_ptr(),
+              None if dprob is None else dprob.data_ptr(), float(rmi_coef), None if gscale_dev is None else gscale_dev.data_ptr(),
+              float(gscale), dp, ldd, n, h, w, H, W, gw.data_ptr(), gw.numel() * 4, 1, None if probs is None else probs.data_ptr(), _st())
+        return d
     d = new_act(n, c, h, w, logits.device, ld=pad4(c))
     dp, ldd = pm(d)
     ws, nb = _loss_bwd_ws(n, h, w, H, W, ldd, logits.device)
     _call("sh_hiera3_loss_bwd", lp, ldl, labels8.data_ptr(), _ints(f2m), _ints(f2h), n_fine, n_mid, n_high, sums.data_ptr(),
           None if dprob is None else dprob.data_ptr(), float(rmi_coef), None if gscale_dev is None else gscale_dev.data_ptr(),
-          float(gscale), dp, ldd, n, h, w, H, W, ws, nb, _st())
+          float(gscale), dp, ldd, n, h, w, H, W, ws, nb, 0, None, _st())
     return d
 
 

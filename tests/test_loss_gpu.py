@@ -336,6 +336,7 @@ def test_three_level_backward_two_pass_equals_tile_kernel(sa, lam, monkeypatch):
     e = F.normalize(torch.randn(2, 16, 6, 5, generator=g), dim=1)
     label = _blocky(g, 2, 96, 80, 7, cell=8)
     grads = []
+    monkeypatch.setattr(ops, "LOSS_FWD_GRAD", False)           # (the forward-emits-gradient form has its own test below)
     for two_pass in (True, False):
         monkeypatch.setattr(ops, "LOSS_BWD_TWO_PASS", two_pass)
         zg = z.to(DEV).requires_grad_(True)
@@ -343,6 +344,30 @@ def test_three_level_backward_two_pass_equals_tile_kernel(sa, lam, monkeypatch):
         fn(20000, e.to(DEV), None, zg, label.to(DEV)).backward()
         grads.append(zg.grad.clone())
     assert torch.equal(grads[0], grads[1])
+
+
+@pytest.mark.parametrize("lam", [0.0, 0.5])
+def test_three_level_forward_emits_gradient_equals_two_pass(sa, lam, monkeypatch):
+    """r3: sh_hiera3_loss_fwd leaves the per-pixel gradient of the BCE / CE terms (unit upstream gradient), the backward adds the RMI term
+    in one streaming pass (sigmoid recovered from the stored probabilities) and gathers with the scale -- against the two-pass backward
+    that recomputes every pixel: same terms, the scale applied after instead of inside the sums (1e-5 of the largest entry), same loss."""
+    _, loss, ops = sa
+    g = torch.Generator().manual_seed(37)
+    z = 1.5 * torch.randn(2, 12, 24, 20, generator=g)
+    e = F.normalize(torch.randn(2, 16, 6, 5, generator=g), dim=1)
+    label = _blocky(g, 2, 96, 80, 7, cell=8)
+    label[0, :16, :24] = 255
+    grads, vals = [], []
+    for fwd_grad in (True, False):
+        monkeypatch.setattr(ops, "LOSS_FWD_GRAD", fwd_grad)
+        zg = z.to(DEV).requires_grad_(True)
+        fn = loss.RMIHieraTripletLoss(7, 3, 2, torch.tensor(F2M), torch.tensor(F2H), loss_weight_lambda=lam).to(DEV)
+        v = fn(20000, e.to(DEV), None, zg, label.to(DEV))
+        (3.0 * v).backward()                                   # a non-unit upstream gradient: the scale is applied by the gather
+        grads.append(zg.grad.clone()); vals.append(float(v))
+    assert vals[0] == vals[1]
+    a, b = grads[0].cpu().double(), grads[1].cpu().double()
+    assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), float((a - b).abs().max() / b.abs().max())
 
 
 def test_rmi_loss_wide_image_matches_oracle(sa):
