@@ -7,6 +7,8 @@ import subprocess
 import sys
 
 import numpy as np
+import ctypes
+
 import pytest
 import torch
 
@@ -49,6 +51,23 @@ def test_abi_rejects_bad_arguments_without_launching(built):
     assert LIB.raw("sh_bn_fold_partials")(None, 4096, 64, 262144.0, 64, 64, None, None) == -1
     assert LIB.raw("sh_bilinear_bwd_workspace")(0, 4, 4, 64) == -1 and LIB.raw("sh_bilinear_bwd_workspace")(2, 4, 4, 64) == 2 * 2 * 16 * 64 * 4
     assert LIB.raw("sh_resize_bilinear_coeffs")(0, 8, None, None, 0) < 0
+    # round-3 entry points and flags (argument checks precede every launch: dummy non-NULL pointers are never dereferenced on the host)
+    P = 4096
+    dg = LIB.raw("sh_conv_dgrad_b16")
+    def dgrad(kh, stride, pad, flags, addend=None, n=1):
+        return dg(P, 64, None, 0, None, P, addend, 64 if addend else 0, P, 64, None, 0, None, 0, None, None, None, None, 0, None,
+                  n, 8, 8, 64, 64, kh, kh, stride, pad, 1, None, 0, flags, None)
+    assert dgrad(1, 2, 0, 128) == -1                      # unknown act_flags bit
+    assert dgrad(3, 2, 1, 64) == -1                       # scatter-add is the 1x1 strided conv's form
+    assert dgrad(1, 2, 0, 64, addend=P) == -1             # ... and takes no hooks
+    assert dgrad(3, 2, 1, 0, addend=P) == -3              # stride-2 KxK with an addend: SH_EUNSUPPORTED (the fp32-accurate entry point takes it)
+    assert dgrad(3, 3, 1, 0) == -3                        # stride 3: no parity plan
+    h3 = LIB.raw("sh_hiera3_loss_fwd")
+    f2m = (ctypes.c_int * 7)(0, 1, 1, 1, 1, 2, 2); f2h = (ctypes.c_int * 7)(0, 1, 1, 1, 1, 1, 1)
+    assert h3(P, 12, P, f2m, f2h, 7, 3, 2, P, P, P, None, None, None, 1, 8, 8, 32, 32, P, 0, 16, None) == -1      # grad_out too small
+    assert h3(P, 12, P, f2m, f2h, 7, 3, 2, P, P, P, None, None, None, 1, 8, 8, 32, 32, P, 1 << 20, 12, None) == -1  # ldg must be 16 or 32
+    h3b = LIB.raw("sh_hiera3_loss_bwd")
+    assert h3b(P, 12, P, f2m, f2h, 7, 3, 2, P, P, 0.1, None, 1.0, P, 16, 1, 8, 8, 32, 32, P, 1 << 20, 1, None, None) == -1   # dprob without probs
 
 
 def test_header_is_plain_c_and_links_from_c(built, tmp_path):
