@@ -472,6 +472,21 @@ int sh_conv_wgrad_b16(const void* x, int ldx, const float* in_scale, const float
                       int ldyl, const float* lin, float* dw, float* workspace, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                       int stride, int pad, int dil, int act_flags, void* stream);
 
+/* ---- RCCL communicator for a host without PyTorch (the Python package uses torch.distributed, backend "nccl" = RCCL) ----
+ * One process per GPU.  Rank 0 makes a 128-byte id, the launcher hands it to every rank, every rank calls sh_comm_init on its current HIP
+ * device (collective: returns when all ranks have joined).  Collectives are in place.  dtype: 0 f32, 1 f64, 2 i64; op: 0 sum, 1 min, 2 max.
+ * sh_comm_all_reduce runs in order on `stream`.  sh_comm_all_reduce_async runs on the communicator's own side stream, which first waits
+ * for everything `producer_stream` has queued (event hand-off) -- the gradient buckets of a backward that keeps running;
+ * sh_comm_wait makes `consumer_stream` wait for everything issued on the side stream so far (before the optimizer step).
+ * RCCL is loaded on first use (dlopen): SH_EUNSUPPORTED if librccl is not found. */
+int sh_comm_unique_id(void* id128);
+int sh_comm_init(const void* id128, int world, int rank, void** comm_out);
+int sh_comm_destroy(void* comm);
+int sh_comm_all_reduce(void* comm, void* buf, int64_t count, int dtype, int op, void* stream);
+int sh_comm_all_reduce_async(void* comm, void* buf, int64_t count, int dtype, int op, void* producer_stream);
+int sh_comm_wait(void* comm, void* consumer_stream);
+int sh_comm_broadcast(void* comm, void* buf, int64_t bytes, int root, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ for part in 3 4 5 6 1 2; do
   fi
   OBJS+=("conv_x6p_$part.o")
 done
-for f in conv_b16 conv_gemm conv_bf16x6 bn_elementwise pool_resample dwconv loss loss3 sgd; do
+for f in conv_b16 conv_gemm conv_bf16x6 bn_elementwise pool_resample dwconv loss loss3 sgd comm; do
   if stale "$f.o" "$f.hip"; then
     $HIPCC $FLAGS -c "$f.hip" -o "$f.o" &
     pids+=($!)
@@ -25,5 +25,5 @@ for f in conv_b16 conv_gemm conv_bf16x6 bn_elementwise pool_resample dwconv loss
   OBJS+=("$f.o")
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done          # (set -e: a failed compile stops the build here)
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libseghiero_hip.so "${OBJS[@]}"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libseghiero_hip.so "${OBJS[@]}" -ldl
 echo "built $(cd .. && pwd)/libseghiero_hip.so"

@@ -505,3 +505,40 @@ def test_ddp_exact_normalisers_sharded_equals_full_batch(cuts):
     assert tot < 5e-4 and worst[0] < 5e-3, (tot, worst)
     upd = _rel(np.concatenate([res[0]["after"][k].ravel() for k in ks]), np.concatenate([full["after"][k].ravel() for k in ks]))
     assert upd < 1e-6, upd
+
+
+def test_c_abi_rccl_communicator_world1_runs_every_entry_point():
+    """sh_comm_* (the RCCL communicator for a host without PyTorch): at world size 1 every entry point runs for real on the GPU --
+    id, init, in-order and side-stream all-reduces of each dtype / op with the event hand-off, wait, broadcast, destroy -- and leaves the
+    data what a one-rank reduction must leave.  (More than one rank needs more than one GPU: unmeasured, like the torch.distributed path.)"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from seghiero_amd.comm import Comm
+    from seghiero_amd._lib import SegHieroHipError
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    comm = Comm(Comm.unique_id(), 1, 0)
+    try:
+        g = torch.Generator().manual_seed(3)
+        for dt in (torch.float32, torch.float64, torch.int64):
+            for op in ("sum", "min", "max"):
+                ref = (torch.randn(100003, generator=g) * 100).to(dt)
+                t = ref.to(dev)
+                comm.all_reduce(t, op)
+                assert torch.equal(t.cpu(), ref), (dt, op)
+        # side stream: the reduction must see what the compute stream produced before it, and the consumer must see the result
+        bucket = torch.zeros(1 << 22, device=dev)
+        for k in range(3):
+            bucket.add_(1.0)                              # producer kernel on the compute stream
+            comm.all_reduce_async(bucket)
+            comm.wait()
+            bucket.mul_(2.0)                              # consumer kernel on the compute stream
+        torch.cuda.synchronize()
+        assert float(bucket.min()) == float(bucket.max()) == 14.0        # ((0 + 1) * 2 + 1) * 2 + 1) * 2
+        w = torch.arange(1000, device=dev, dtype=torch.float32)
+        comm.broadcast(w, 0)
+        assert torch.equal(w.cpu(), torch.arange(1000, dtype=torch.float32))
+        with pytest.raises(SegHieroHipError):
+            comm.all_reduce(torch.zeros(4, device=dev, dtype=torch.float16))
+    finally:
+        comm.close()

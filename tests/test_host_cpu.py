@@ -66,6 +66,8 @@ def test_abi_rejects_bad_arguments_without_launching(built):
     f2m = (ctypes.c_int * 7)(0, 1, 1, 1, 1, 2, 2); f2h = (ctypes.c_int * 7)(0, 1, 1, 1, 1, 1, 1)
     assert h3(P, 12, P, f2m, f2h, 7, 3, 2, P, P, P, None, None, None, 1, 8, 8, 32, 32, P, 0, 16, None) == -1      # grad_out too small
     assert h3(P, 12, P, f2m, f2h, 7, 3, 2, P, P, P, None, None, None, 1, 8, 8, 32, 32, P, 1 << 20, 12, None) == -1  # ldg must be 16 or 32
+    assert LIB.raw("sh_comm_unique_id")(None) == -1 and LIB.raw("sh_comm_init")(None, 2, 0, None) == -1
+    assert LIB.raw("sh_comm_all_reduce")(None, P, 4, 0, 0, None) == -1 and LIB.raw("sh_comm_wait")(None, None) == -1
     h3b = LIB.raw("sh_hiera3_loss_bwd")
     assert h3b(P, 12, P, f2m, f2h, 7, 3, 2, P, P, 0.1, None, 1.0, P, 16, 1, 8, 8, 32, 32, P, 1 << 20, 1, None, None) == -1   # dprob without probs
 
