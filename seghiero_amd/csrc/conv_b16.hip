@@ -776,6 +776,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_b16_kernel(const
         }
     }
     if constexpr (LIN || AFF) __syncthreads();
+    // AFF without LIN: a thread's 8 im2col columns (one tap, 8 channels) are the same for every tile, so its 16 coefficients live in
+    // registers (162-165 of the 256 available at two waves per SIMD) instead of four LDS reads per stored chunk -- the table reads were
+    // 2-way bank conflicts (19 % of the kernel's LDS cycles, profiles/r03a_pmc_b16_sep1pw.json)
+    [[maybe_unused]] float aff_sc[8], aff_sh[8];
+    if constexpr (AFF && !LIN) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { aff_sc[e] = aff_c[8 * brc + e]; aff_sh[e] = aff_c[BN + 8 * brc + e]; }
+    }
     // pixel coordinates of this thread's B k-rows for the NEXT tile, advanced by 64 pixels per tile: (ow, oh, n) += (64 % Wo, 64 / Wo, 0)
     // with one carry each (host check: 64 / Wo + 1 < Ho, so a step crosses at most one image boundary)
     [[maybe_unused]] int px_ow[NB], px_oh[NB], px_n[NB];
@@ -869,10 +877,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_b16_kernel(const
             if constexpr (!AFF) { *reinterpret_cast<u32x4*>(dst) = R.b[i]; continue; }
             const bool ok = (R.okm >> i) & 1u;
             float v[8], sc[8], sh[8];
+            if constexpr (LIN) {          // (with the lin table in play the coefficients stay in LDS: 48 more registers spilled)
 #pragma unroll
-            for (int e = 0; e < 8; e += 4) {
-                *reinterpret_cast<f32x4*>(sc + e) = *reinterpret_cast<const f32x4*>(aff_c + 8 * brc + e);
-                *reinterpret_cast<f32x4*>(sh + e) = *reinterpret_cast<const f32x4*>(aff_c + BN + 8 * brc + e);
+                for (int e = 0; e < 8; e += 4) {
+                    *reinterpret_cast<f32x4*>(sc + e) = *reinterpret_cast<const f32x4*>(aff_c + 8 * brc + e);
+                    *reinterpret_cast<f32x4*>(sh + e) = *reinterpret_cast<const f32x4*>(aff_c + BN + 8 * brc + e);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { sc[e] = aff_sc[e]; sh[e] = aff_sh[e]; }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(R.b[i][e] << 16); v[2 * e + 1] = __uint_as_float(R.b[i][e] & 0xffff0000u); }
