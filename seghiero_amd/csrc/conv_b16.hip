@@ -67,6 +67,20 @@ __device__ __forceinline__ F8 quad_mask_load8(const void* base, long long byte_i
 
 // act bits used here (conv_x6.h): 1 fprop x bf16 (always set in this mode), 2 fprop y bf16, 4 bnb_y bf16, 8 bnb_out bf16, 16 lin y bf16,
 // 64 bnb_out = ReLU quad mask, 128 dgrad output (dx / g) bf16, 256 dgrad addend bf16
+// BatchNorm + ReLU of two bf16 values held in one 32-bit word (the loaders' transform): widen, ONE packed fused multiply-add, round both
+// to bf16, ReLU as a packed 16-bit max on the rounded pair -- 6 vector instructions per pair instead of 8 (the loaders run ~8 VALU
+// instructions per MFMA in these kernels, as many issue cycles as the MFMA itself takes).  Rounding and max(., floor) commute (both are
+// monotonic, floor is 0 or "none"); the 16-bit max only has to order a value against +0 / against the most negative pattern, which the
+// sign bit decides for every bf16 pattern of magnitude < 2^121 (beyond that the fp16 reading is a NaN).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned aff_pair(unsigned raw, f32x2_t sc, f32x2_t sh, unsigned floor_bits) {
+    const f32x2_t x = {__uint_as_float(raw << 16), __uint_as_float(raw & 0xffff0000u)};
+    const f32x2_t r = __builtin_elementwise_fma(x, sc, sh);
+    const unsigned pk = pk_bf16(r[0], r[1]);
+    const h16x2_t m = __builtin_elementwise_max(__builtin_bit_cast(h16x2_t, pk), __builtin_bit_cast(h16x2_t, floor_bits));
+    return __builtin_bit_cast(unsigned, m);
+}
 #define B16_OUT_BF 128
 #define B16_ADD_BF 256
 
@@ -287,8 +301,16 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void conv_b16_kernel(co
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], c0[e], c1[e]), aff_floor);
                 }
-                u32x4 o = {pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
+                u32x4 o;
+                if constexpr (AFF == 1 && !A32) {      // (the unpacked v[] above is dead code in this case)
+                    const unsigned okw = ((R.okm >> i) & 1u) ? ~0u : 0u, fl = aff_floor == 0.f ? 0u : 0xfc00fc00u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        o[e] = aff_pair(R.a[i][0][e], f32x2_t{c0[2 * e], c0[2 * e + 1]}, f32x2_t{c1[2 * e], c1[2 * e + 1]}, fl) & okw;
+                } else {
+                o = u32x4{pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
                 if constexpr (AFF == 1) { const unsigned okw = ((R.okm >> i) & 1u) ? ~0u : 0u; o[0] &= okw; o[1] &= okw; o[2] &= okw; o[3] &= okw; }
+                }
                 *reinterpret_cast<u32x4*>(ad + RPP * i * 128) = o;
             }
         }
@@ -887,12 +909,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_wgrad_b16_kernel(const
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { sc[e] = aff_sc[e]; sh[e] = aff_sh[e]; }
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(R.b[i][e] << 16); v[2 * e + 1] = __uint_as_float(R.b[i][e] & 0xffff0000u); }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);      // (as conv_b16_kernel's loader: fused, masked after the pack)
             const unsigned okw = ok ? ~0u : 0u;
-            *reinterpret_cast<u32x4*>(dst) = u32x4{pk_bf16(v[0], v[1]) & okw, pk_bf16(v[2], v[3]) & okw, pk_bf16(v[4], v[5]) & okw, pk_bf16(v[6], v[7]) & okw};
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)          // (as conv_b16_kernel's loader: packed, fused, masked after the pack)
+                o[e] = aff_pair(R.b[i][e], f32x2_t{sc[2 * e], sc[2 * e + 1]}, f32x2_t{sh[2 * e], sh[2 * e + 1]}, 0u) & okw;
+            (void)v;
+            *reinterpret_cast<u32x4*>(dst) = o;
         }
     };
     f32x16 acc[2][2];
