@@ -171,7 +171,8 @@ def _train(n_steps, sync, syncbn=False):
     torch.manual_seed(0)
     dev = torch.device("cuda", torch.cuda.current_device())
     ops.SYNC_BN = syncbn
-    tr = SegHieroTrainer(device=dev, **TR_KW)
+    b16 = os.environ.get("SEGHIERO_TEST_B16") == "1"              # (inherited by the spawned ranks)
+    tr = SegHieroTrainer(device=dev, compute_dtype=torch.bfloat16 if b16 else torch.float32, **TR_KW)
     if sync:
         ddp.broadcast_module_state(list(tr.modules().values()))
         tr.grad_sync = ddp.GradSync(tr.params, bucket_mb=4.0)
@@ -198,12 +199,14 @@ def _ddp_worker(rank, world, port, q, backend="gloo"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("backend", ["gloo", "nccl"])
-def test_ddp_two_ranks_same_batch_equals_single_rank(backend):
+@pytest.mark.parametrize("backend,mode", [("gloo", "f32"), ("gloo", "b16"), ("nccl", "f32")])
+def test_ddp_two_ranks_same_batch_equals_single_rank(backend, mode, monkeypatch):
+    """... also in bf16 compute mode (r3): the exchange works on the fp32 weight gradients whatever the compute mode."""
     if not torch.cuda.is_available():
         pytest.skip("needs the MI355X")
     if backend not in _backends():
         pytest.skip("two ranks over RCCL need two GPUs (RCCL refuses two ranks on one device)")
+    monkeypatch.setenv("SEGHIERO_TEST_B16", "1" if mode == "b16" else "0")
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
