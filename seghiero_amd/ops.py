@@ -384,24 +384,32 @@ def prepare_dgrad_weights(weights, cache):
     handed out by weight_transpose() until release_dgrad_weights(); the caller guarantees that the weights do not change in
     between (the training step: prepare -> forward -> backward -> release -> SGD)."""
     global _WT_ACTIVE
-    todo = []
-    for w in weights:
-        hit = cache.get(id(w))
-        if hit is None or hit[0] is not w or hit[1].device != w.device:
-            o, i, kh, kw = w.shape
-            hit = (w, torch.empty((kh * kw, i, pad4(o)), device=w.device, dtype=torch.float32))
-            cache[id(w)] = hit
-        todo.append(hit)
-    cap = 40                                                   # SH_WT_MAX
-    for a in range(0, len(todo), cap):
-        chunk = todo[a:a + cap]
-        k = len(chunk)
-        wa = (ctypes.c_void_p * k)(*[w_ohwi(w).data_ptr() for w, _ in chunk])
-        ta = (ctypes.c_void_p * k)(*[t.data_ptr() for _, t in chunk])
-        co = (ctypes.c_int * k)(*[w.shape[0] for w, _ in chunk])
-        tp = (ctypes.c_int * k)(*[w.shape[2] * w.shape[3] for w, _ in chunk])
-        ci = (ctypes.c_int * k)(*[w.shape[1] for w, _ in chunk])
-        _call("sh_weight_transpose_multi", k, wa, ta, co, tp, ci, _st())
+    # The launch tables (pointer / shape arrays) are kept with the buffers: the step boundary is the one place where the GPU queue is
+    # empty, so host time spent here is idle device time (measured: 250 us before this launch, tools/gap_analysis.sh).  They are rebuilt
+    # when any weight's storage has moved.
+    sig = tuple(w.data_ptr() for w in weights)
+    plan = cache.get("__plan__")
+    if plan is None or plan[0] != sig:
+        todo = []
+        for w in weights:
+            hit = cache.get(id(w))
+            if hit is None or hit[0] is not w or hit[1].device != w.device:
+                o, i, kh, kw = w.shape
+                hit = (w, torch.empty((kh * kw, i, pad4(o)), device=w.device, dtype=torch.float32))
+                cache[id(w)] = hit
+            todo.append(hit)
+        cap = 40                                                   # SH_WT_MAX
+        launches = []
+        for a in range(0, len(todo), cap):
+            chunk = todo[a:a + cap]
+            k = len(chunk)
+            launches.append((k, (ctypes.c_void_p * k)(*[w_ohwi(w).data_ptr() for w, _ in chunk]), (ctypes.c_void_p * k)(*[t.data_ptr() for _, t in chunk]),
+                             (ctypes.c_int * k)(*[w.shape[0] for w, _ in chunk]), (ctypes.c_int * k)(*[w.shape[2] * w.shape[3] for w, _ in chunk]),
+                             (ctypes.c_int * k)(*[w.shape[1] for w, _ in chunk])))
+        plan = cache["__plan__"] = (sig, launches)
+    st = _st()
+    for k, wa, ta, co, tp, ci in plan[1]:
+        _call("sh_weight_transpose_multi", k, wa, ta, co, tp, ci, st)
     _WT_ACTIVE = cache
 
 
@@ -420,29 +428,43 @@ def _wb_buffers(w):
             torch.empty((kh * kw, i, pad8(o)), device=w.device, dtype=torch.bfloat16))
 
 
-def _wb_launch(items):
+def _wb_tables(items):
     cap = 40                                                   # SH_WT_MAX
+    out = []
     for a in range(0, len(items), cap):
         chunk = items[a:a + cap]
         k = len(chunk)
         vp = ctypes.c_void_p
-        _call("sh_weights_to_bf16_multi", k, (vp * k)(*[w_ohwi(w).data_ptr() for w, _, _ in chunk]), (vp * k)(*[b.data_ptr() for _, b, _ in chunk]),
-              (vp * k)(*[t.data_ptr() for _, _, t in chunk]), (ctypes.c_int * k)(*[w.shape[0] for w, _, _ in chunk]),
-              (ctypes.c_int * k)(*[w.shape[2] * w.shape[3] for w, _, _ in chunk]), (ctypes.c_int * k)(*[w.shape[1] for w, _, _ in chunk]), _st())
+        out.append((k, (vp * k)(*[w_ohwi(w).data_ptr() for w, _, _ in chunk]), (vp * k)(*[b.data_ptr() for _, b, _ in chunk]),
+                    (vp * k)(*[t.data_ptr() for _, _, t in chunk]), (ctypes.c_int * k)(*[w.shape[0] for w, _, _ in chunk]),
+                    (ctypes.c_int * k)(*[w.shape[2] * w.shape[3] for w, _, _ in chunk]), (ctypes.c_int * k)(*[w.shape[1] for w, _, _ in chunk])))
+    return out
+
+
+def _wb_launch(items):
+    st = _st()
+    for args in _wb_tables(items):
+        _call("sh_weights_to_bf16_multi", *args, st)
 
 
 def prepare_bf16_weights(weights, cache):
     """bf16 compute mode: the bf16 copies (forward operand and transposed input-gradient operand) of all dense conv `weights`, made
     once per step in a few launches; handed out by weights_bf16() until release_dgrad_weights().  Contract as prepare_dgrad_weights."""
     global _WB_ACTIVE
-    todo = []
-    for w in weights:
-        hit = cache.get(id(w))
-        if hit is None or hit[0] is not w or hit[1].device != w.device:
-            hit = (w,) + _wb_buffers(w)
-            cache[id(w)] = hit
-        todo.append(hit)
-    _wb_launch(todo)
+    sig = tuple(w.data_ptr() for w in weights)                 # (launch tables kept across steps: see prepare_dgrad_weights)
+    plan = cache.get("__plan__")
+    if plan is None or plan[0] != sig:
+        todo = []
+        for w in weights:
+            hit = cache.get(id(w))
+            if hit is None or hit[0] is not w or hit[1].device != w.device:
+                hit = (w,) + _wb_buffers(w)
+                cache[id(w)] = hit
+            todo.append(hit)
+        plan = cache["__plan__"] = (sig, _wb_tables(todo))
+    st = _st()
+    for args in plan[1]:
+        _call("sh_weights_to_bf16_multi", *args, st)
     _WB_ACTIVE = cache
 
 
@@ -1477,17 +1499,29 @@ def weights_key(w):
     return (w.data_ptr(), w._version, WEIGHT_EPOCH)
 
 
+_SGD_PLAN = {}          # (first parameter's address, count) -> (signature, launch tables): one entry per optimizer in the process
+
+
 def sgd_step(params, grads, bufs, lr, momentum, weight_decay, first_step, gscale=1.0):
     global WEIGHT_EPOCH
     WEIGHT_EPOCH += 1
     st = _st()
-    for i in range(0, len(params), SGD_MAX):
-        ps, gs, vs = params[i:i + SGD_MAX], grads[i:i + SGD_MAX], bufs[i:i + SGD_MAX]
-        k = len(ps)
-        wa = (ctypes.c_void_p * k)(*[p.data_ptr() for p in ps])
-        ga = (ctypes.c_void_p * k)(*[g.data_ptr() for g in gs])
-        va = (ctypes.c_void_p * k)(*[v.data_ptr() for v in vs])
-        na = (ctypes.c_longlong * k)(*[p.numel() for p in ps])
+    # the weight / momentum / size tables are the same every step (only the gradient tensors are new): kept until a pointer moves
+    sig = (tuple(p.data_ptr() for p in params), tuple(v.data_ptr() for v in bufs))
+    key = (sig[0][0], len(params))
+    plan = _SGD_PLAN.get(key)
+    if plan is None or plan[0] != sig:
+        chunks = []
+        for i in range(0, len(params), SGD_MAX):
+            ps, vs = params[i:i + SGD_MAX], bufs[i:i + SGD_MAX]
+            k = len(ps)
+            chunks.append((i, k, (ctypes.c_void_p * k)(*[p.data_ptr() for p in ps]), (ctypes.c_void_p * k)(*[v.data_ptr() for v in vs]),
+                           (ctypes.c_longlong * k)(*[p.numel() for p in ps])))
+        if len(_SGD_PLAN) > 16:
+            _SGD_PLAN.clear()
+        plan = _SGD_PLAN[key] = (sig, chunks)
+    for i, k, wa, va, na in plan[1]:
+        ga = (ctypes.c_void_p * k)(*[g.data_ptr() for g in grads[i:i + k]])
         _call("sh_sgd_step", k, wa, ga, va, na, float(lr), float(momentum), float(weight_decay), int(first_step),
               float(gscale), st)
 
