@@ -670,7 +670,15 @@ def test_weight_transpose_multi_matches_single(ops):
             assert got.data_ptr() != ref.data_ptr() and torch.equal(got, ref)
     finally:
         ops.release_dgrad_weights()
-    assert ops.weight_transpose(ws[0]).data_ptr() not in [t.data_ptr() for _, t in cache.values()]
+    bufs = [v[1] for k, v in cache.items() if k != "__plan__"]          # ("__plan__": the launch tables kept with the buffers)
+    assert len(bufs) == len(ws)
+    assert ops.weight_transpose(ws[0]).data_ptr() not in [t.data_ptr() for t in bufs]
+    # a second prepare with the same weights reuses the tables and reproduces the copies
+    ops.prepare_dgrad_weights(ws, cache)
+    try:
+        assert all(torch.equal(ops.weight_transpose(w), ref) for w, ref in zip(ws, singles))
+    finally:
+        ops.release_dgrad_weights()
 
 
 def test_layout_and_axpy_helpers(ops):
