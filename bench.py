@@ -206,6 +206,8 @@ def main():
         pass
     # the north-star unit (BASELINE.json): ASPP depthwise-separable branch forward, timed on its own
     roof_units = None
+    ops.SYNC_BN = False          # from here on only rank 0 is running: no collective may be issued (the other ranks have returned)
+    ddp.EXACT = False
     if not args.no_units:
         try:
             from seghiero_amd import units
